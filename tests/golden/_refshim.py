@@ -1,0 +1,69 @@
+"""Harness that lets the read-only reference (/root/reference) run on CPU in THIS container.
+
+Only used by tests/golden/make_golden.py (fixture generation).  Nothing here ships to the GPU box as a
+dependency: the generated .npz fixtures are data (inputs + expected outputs).
+
+Adaptations (none touch reference files):
+  1. device="cuda" -> "cpu" rewriting through a TorchFunctionMode + no-op .cuda()/.to("cuda").
+  2. edm2.attention.attention_modules.compiled_flex_attention replaced by a dense SDPA whose mask is
+     block_mask.to_dense() (expanded to token granularity) AND mask_mod  -- this is what the compiled
+     FlexAttention kernel computes on GPU, and it supports autograd on CPU.
+"""
+import sys
+import torch
+from torch.overrides import TorchFunctionMode
+
+REF = "/root/reference"
+
+
+def _fix(v):
+    if isinstance(v, str) and v.startswith("cuda"):
+        return "cpu"
+    if isinstance(v, torch.device) and v.type == "cuda":
+        return torch.device("cpu")
+    return v
+
+
+class CudaToCpu(TorchFunctionMode):
+    def __torch_function__(self, func, types, args=(), kwargs=None):
+        kwargs = dict(kwargs or {})
+        if "device" in kwargs:
+            kwargs["device"] = _fix(kwargs["device"])
+        args = tuple(_fix(a) for a in args)
+        return func(*args, **kwargs)
+
+
+_mode = None
+
+
+def install():
+    """Import the reference with the shim active; returns the `edm2` package."""
+    global _mode
+    if _mode is None:
+        _mode = CudaToCpu()
+        _mode.__enter__()
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        torch.nn.Module.cuda = lambda self, *a, **k: self
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    import edm2  # noqa
+    import edm2.networks_edm2  # noqa
+    from edm2.attention import attention_modules as am
+
+    def dense_flex(q, k, v, score_mod=None, block_mask=None):
+        Lq, Lk = q.shape[-2], k.shape[-2]
+        qi = torch.arange(Lq)[:, None]
+        ki = torch.arange(Lk)[None, :]
+        if block_mask is not None:
+            dense = block_mask.to_dense()[0, 0].bool()          # (nq_blocks, nk_blocks)
+            bq, bk = block_mask.BLOCK_SIZE
+            allowed = dense.repeat_interleave(bq, 0).repeat_interleave(bk, 1)[:Lq, :Lk]
+            if block_mask.mask_mod is not None:
+                allowed = allowed & block_mask.mask_mod(0, 0, qi, ki)
+        else:
+            neg = score_mod(torch.zeros(Lq, Lk), 0, 0, qi, ki)
+            allowed = torch.isfinite(neg)
+        return torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
+
+    am.compiled_flex_attention = dense_flex
+    return edm2
