@@ -1,0 +1,715 @@
+// VideoAttention / FrameAttention kernels for gfx950 (head dim 64, MFMA 32x32x16 bf16 -> fp32).
+//
+// Flash-style block-sparse attention that consumes the reference's BlockMask table (128-token kv blocks per
+// 128-token q block, bit-exact copy of make_train_mask / make_infer_mask) and applies mask_mod per element on
+// partially masked tiles -- the semantics of the compiled FlexAttention kernel.
+//
+// Forward / dQ: one workgroup = 128 query rows (4 waves x 32 rows), S^T = K.Q^T is computed with the KEY index on
+// the MFMA rows and the QUERY on the lanes, so a lane owns one query row: row max / row sum are 32 in-register ops
+// plus one cross-half shuffle, and the S^T accumulator is directly the B operand of O^T += V^T.P^T (no LDS round
+// trip).  K / V^T tiles (64 keys) are staged in LDS with padded rows (144 B / 136 B: conflict-free 16 B / 8 B
+// fragment reads).  dK/dV: one workgroup = 128 keys, lane = key, S = Q.K^T with queries on the rows, P and dS feed
+// dV^T += dO^T.P and dK^T += Q^T.dS straight from registers.  The k-contiguous operands (V^T, K^T, Q^T, dO^T) are
+// read from transposed copies that the rope/transposition kernel writes once per layer (L x 64 per head: tiny).
+#include "common.h"
+#include "../../include/oniris.h"
+
+#define NEG_BIG (-1.0e30f)
+#define SCALE_LOG2 (0.125f * 1.4426950408889634f)
+#define KROW 144   // bytes per row of a [64 tok][64 ch] bf16 tile (128 + 16 pad)
+#define TROW 136   // bytes per row of a [64 ch][64 tok] bf16 tile (128 + 8 pad)
+
+struct AttnDev {
+  OnirisAttnArgs a;
+  int pshift;     // log2(P)
+  int qf_off;     // (Lk - Lq) / P  (frame offset of the queries inside the key sequence, mask_mode 1)
+};
+
+// ---- mask_mod on token indices ---------------------------------------------------------------------------------
+template <int MODE>
+__device__ __forceinline__ bool tok_allowed(int qtok, int ktok, int pshift, int T, int qf_off) {
+  if (MODE == 0) return true;
+  const int qf = qtok >> pshift, kf = ktok >> pshift;
+  if (MODE == 1) return kf <= qf + qf_off;
+  // TrainingMask (attention_masking.py:15-24): clean q sees clean kf <= qf; noisy q (f = qf-T) sees clean kf < f
+  // and its own noisy frame.
+  if (qf < T) return kf <= qf;
+  return (kf < T && kf < qf - T) || (kf == qf);
+}
+
+// 0 = nothing allowed, 1 = partially masked, 2 = everything allowed, for token ranges [q0,q1] x [k0,k1]
+template <int MODE>
+__device__ __forceinline__ int classify(int q0, int q1, int k0, int k1, int pshift, int T, int qf_off) {
+  if (MODE == 0) return 2;
+  const int qa = q0 >> pshift, qb = q1 >> pshift, ka = k0 >> pshift, kb = k1 >> pshift;
+  if (MODE == 1) {
+    if (kb <= qa + qf_off) return 2;
+    if (ka > qb + qf_off) return 0;
+    return 1;
+  }
+  if (qb < T) {                       // clean queries (a 128-token block never straddles the clean|noisy border)
+    if (kb <= qa) return 2;
+    if (ka > qb) return 0;
+    return 1;
+  }
+  if (kb < T) {                       // noisy queries, clean keys
+    if (kb < qa - T) return 2;
+    if (ka >= qb - T) return 0;
+    return 1;
+  }
+  if (ka == kb && qa == qb && ka == qa) return 2;
+  if (kb < qa || ka > qb) return 0;
+  return 1;
+}
+
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
+  bf16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = f2bf(v[8 * s2 + e]);
+  return o;
+}
+
+// stage a [64 tok][64 ch] tile (row-major, global row stride C elements) into LDS rows of KROW bytes
+__device__ __forceinline__ void stage_rows(unsigned char* lds, const bf16* g, int tok0, int L, int C, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 256;
+    const int row = e >> 3, part = e & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (tok0 + row < L) v = *(const uint4*)(g + (size_t)(tok0 + row) * C + part * 8);
+    *(uint4*)(lds + row * KROW + part * 16) = v;
+  }
+}
+// stage a [64 ch][64 tok] tile from a transposed tensor (row stride L elements) into LDS rows of TROW bytes
+__device__ __forceinline__ void stage_cols(unsigned char* lds, const bf16* gt, int tok0, int L, int tid) {
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = tid + i * 256;
+    const int row = e >> 3, part = e & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (tok0 + part * 8 < L) v = *(const uint4*)(gt + (size_t)row * L + tok0 + part * 8);
+    *(uint2*)(lds + row * TROW + part * 16) = make_uint2(v.x, v.y);
+    *(uint2*)(lds + row * TROW + part * 16 + 8) = make_uint2(v.z, v.w);
+  }
+}
+// fragment of a transposed tile: row `row`, the 8 tokens {16*s2 + 4h + 0..3, 16*s2 + 8 + 4h + 0..3} (+ base)
+__device__ __forceinline__ bf16x8 tfrag(const unsigned char* lds, int row, int tokbase, int h) {
+  const unsigned char* p = lds + row * TROW + (tokbase + 4 * h) * 2;
+  const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 16);
+  return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+}
+
+// ================================================================================================================
+// forward
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * KROW + 64 * TROW];
+  unsigned char* K_lds = smem;
+  unsigned char* Vt_lds = smem + 64 * KROW;
+  const OnirisAttnArgs& a = d.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int nqb = gridDim.x;
+  const int qb = nqb - 1 - blockIdx.x;             // heaviest (latest) query blocks first
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, Lq = a.Lq, Lk = a.Lk;
+  const int qw0 = qb * 128 + wave * 32;
+  const int qrow = qw0 + r;
+
+  const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
+  const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
+  const bf16* vtg = (const bf16*)a.vt + (size_t)(b * a.heads + head) * 64 * Lk;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (qrow < Lq) v = *(const uint4*)(qg + (size_t)qrow * C + ks * 16 + h * 8);
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+  f32x16 o[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
+  float m = NEG_BIG, l = 0.f;
+
+  const int nkv = a.kv_num ? a.kv_num[qb] : (Lk + 127) / 128;
+  for (int j = 0; j < nkv; ++j) {
+    const int kb = a.kv_idx ? a.kv_idx[(size_t)qb * a.tab_cols + j] : j;
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kb * 128 + sub * 64;
+      if (key0 >= Lk) break;
+      __syncthreads();
+      stage_rows(K_lds, kg, key0, Lk, C, tid);
+      stage_cols(Vt_lds, vtg, key0, Lk, tid);
+      __syncthreads();
+      int cls = classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
+      if (key0 + 63 >= Lk && cls == 2) cls = 1;
+      if (cls == 0 || qw0 >= Lq) continue;
+
+      f32x16 s[2];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
+          s[kt] = mfma32(kf, qf[ks], s[kt]);
+        }
+      }
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          float v = s[kt][rr] * SCALE_LOG2;
+          if (cls == 1) {
+            const int key = key0 + kt * 32 + mfma_row(rr, lane);
+            if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) v = NEG_BIG;
+          }
+          s[kt][rr] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m, mx);
+      const float m_use = (m_new == NEG_BIG) ? 0.f : m_new;
+      const float alpha = exp2f(m - m_use);
+      float rs = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const float p = exp2f(s[kt][rr] - m_use);
+          s[kt][rr] = p;
+          rs += p;
+        }
+      rs += __shfl_xor(rs, 32);
+      l = l * alpha + rs;
+      m = m_new;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pb = pack8(s[kt], s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 vf = tfrag(Vt_lds, dt * 32 + r, kt * 32 + 16 * s2, h);
+            o[dt] = mfma32(vf, pb, o[dt]);
+          }
+        }
+    }
+  }
+  if (qrow >= Lq) return;
+  const float inv = (l > 0.f) ? 1.f / l : 0.f;
+  bf16* og = (bf16*)a.out + ((size_t)b * Lq + qrow) * C + head * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 ov;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ov[k] = f2bf(o[dt][4 * g + k] * inv);
+      *(bf16x4*)(og + dt * 32 + 8 * g + 4 * h) = ov;
+    }
+  if (a.lse && h == 0) a.lse[(size_t)(b * a.heads + head) * Lq + qrow] = m + log2f(fmaxf(l, 1e-30f));
+}
+
+// ================================================================================================================
+// backward: dQ   (same loop structure as the forward, lane = query row)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW + 64 * TROW];
+  unsigned char* K_lds = smem;
+  unsigned char* V_lds = smem + 64 * KROW;
+  unsigned char* Kt_lds = smem + 2 * 64 * KROW;
+  const OnirisAttnArgs& a = d.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int nqb = gridDim.x;
+  const int qb = nqb - 1 - blockIdx.x;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, Lq = a.Lq, Lk = a.Lk;
+  const int qw0 = qb * 128 + wave * 32;
+  const int qrow = qw0 + r;
+
+  const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
+  const bf16* dog = (const bf16*)a.dout + (size_t)b * Lq * C + head * 64;
+  const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
+  const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
+  const bf16* ktg = (const bf16*)a.kt + (size_t)(b * a.heads + head) * 64 * Lk;
+
+  bf16x8 qf[4], dof[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+    if (qrow < Lq) {
+      v = *(const uint4*)(qg + (size_t)qrow * C + ks * 16 + h * 8);
+      w = *(const uint4*)(dog + (size_t)qrow * C + ks * 16 + h * 8);
+    }
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+    dof[ks] = __builtin_bit_cast(bf16x8, w);
+  }
+  float lse = 0.f, delta = 0.f;
+  if (qrow < Lq) {
+    lse = a.lse[(size_t)(b * a.heads + head) * Lq + qrow];
+    delta = a.delta[(size_t)(b * a.heads + head) * Lq + qrow];
+  }
+  f32x16 dq[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
+
+  const int nkv = a.kv_num ? a.kv_num[qb] : (Lk + 127) / 128;
+  for (int j = 0; j < nkv; ++j) {
+    const int kb = a.kv_idx ? a.kv_idx[(size_t)qb * a.tab_cols + j] : j;
+    for (int sub = 0; sub < 2; ++sub) {
+      const int key0 = kb * 128 + sub * 64;
+      if (key0 >= Lk) break;
+      __syncthreads();
+      stage_rows(K_lds, kg, key0, Lk, C, tid);
+      stage_rows(V_lds, vg, key0, Lk, C, tid);
+      stage_cols(Kt_lds, ktg, key0, Lk, tid);
+      __syncthreads();
+      int cls = classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
+      if (key0 + 63 >= Lk && cls == 2) cls = 1;
+      if (cls == 0 || qw0 >= Lq) continue;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
+          s = mfma32(kf, qf[ks], s);
+          const bf16x8 vf = *(const bf16x8*)(V_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
+          dp = mfma32(vf, dof[ks], dp);
+        }
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          float p = exp2f(s[rr] * SCALE_LOG2 - lse);
+          if (cls == 1) {
+            const int key = key0 + kt * 32 + mfma_row(rr, lane);
+            if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
+          }
+          s[rr] = p * (dp[rr] - delta) * 0.125f;          // dS (scaled)
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 db = pack8(s, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 ktf = tfrag(Kt_lds, dt * 32 + r, kt * 32 + 16 * s2, h);
+            dq[dt] = mfma32(ktf, db, dq[dt]);
+          }
+        }
+      }
+    }
+  }
+  if (qrow >= Lq) return;
+  bf16* og = (bf16*)a.dq + ((size_t)b * Lq + qrow) * C + head * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 ov;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ov[k] = f2bf(dq[dt][4 * g + k]);
+      *(bf16x4*)(og + dt * 32 + 8 * g + 4 * h) = ov;
+    }
+}
+
+// ================================================================================================================
+// backward: dK, dV   (lane = key)
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW + 2 * 64 * TROW + 2 * 64 * 4];
+  unsigned char* Q_lds = smem;
+  unsigned char* dO_lds = smem + 64 * KROW;
+  unsigned char* Qt_lds = smem + 2 * 64 * KROW;
+  unsigned char* dOt_lds = Qt_lds + 64 * TROW;
+  float* lse_lds = (float*)(dOt_lds + 64 * TROW);
+  float* del_lds = lse_lds + 64;
+  const OnirisAttnArgs& a = d.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int kb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int C = a.C, Lq = a.Lq, Lk = a.Lk;
+  const int kw0 = kb * 128 + wave * 32;
+  const int krow = kw0 + r;
+
+  const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
+  const bf16* dog = (const bf16*)a.dout + (size_t)b * Lq * C + head * 64;
+  const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
+  const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
+  const bf16* qtg = (const bf16*)a.qt + (size_t)(b * a.heads + head) * 64 * Lq;
+  const bf16* dotg = (const bf16*)a.doutt + (size_t)(b * a.heads + head) * 64 * Lq;
+  const float* lseg = a.lse + (size_t)(b * a.heads + head) * Lq;
+  const float* delg = a.delta + (size_t)(b * a.heads + head) * Lq;
+
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+    if (krow < Lk) {
+      v = *(const uint4*)(kg + (size_t)krow * C + ks * 16 + h * 8);
+      w = *(const uint4*)(vg + (size_t)krow * C + ks * 16 + h * 8);
+    }
+    kf[ks] = __builtin_bit_cast(bf16x8, v);
+    vf[ks] = __builtin_bit_cast(bf16x8, w);
+  }
+  f32x16 dk[2], dv[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+  const int nq = a.q_num ? a.q_num[kb] : (Lq + 127) / 128;
+  for (int j = 0; j < nq; ++j) {
+    const int qblk = a.q_idx ? a.q_idx[(size_t)kb * a.qtab_cols + j] : j;
+    for (int sub = 0; sub < 2; ++sub) {
+      const int q0 = qblk * 128 + sub * 64;
+      if (q0 >= Lq) break;
+      __syncthreads();
+      stage_rows(Q_lds, qg, q0, Lq, C, tid);
+      stage_rows(dO_lds, dog, q0, Lq, C, tid);
+      stage_cols(Qt_lds, qtg, q0, Lq, tid);
+      stage_cols(dOt_lds, dotg, q0, Lq, tid);
+      if (tid < 64) lse_lds[tid] = (q0 + tid < Lq) ? lseg[q0 + tid] : 0.f;
+      else if (tid < 128) del_lds[tid - 64] = (q0 + tid - 64 < Lq) ? delg[q0 + tid - 64] : 0.f;
+      __syncthreads();
+      if (kw0 >= Lk) continue;
+#pragma unroll
+      for (int qt = 0; qt < 2; ++qt) {
+        const int qq0 = q0 + qt * 32;
+        int cls = classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off);
+        if ((qq0 + 31 >= Lq || kw0 + 31 >= Lk) && cls == 2) cls = 1;
+        if (cls == 0 || qq0 >= Lq) continue;
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 qa = *(const bf16x8*)(Q_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
+          s = mfma32(qa, kf[ks], s);                       // S[q][key]
+          const bf16x8 da = *(const bf16x8*)(dO_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
+          dp = mfma32(da, vf[ks], dp);                     // dP[q][key]
+        }
+        f32x16 pv;
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int ql = qt * 32 + mfma_row(rr, lane);
+          float p = exp2f(s[rr] * SCALE_LOG2 - lse_lds[ql]);
+          if (cls == 1) {
+            const int qtok = q0 + ql;
+            if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
+          }
+          pv[rr] = p;
+          s[rr] = p * (dp[rr] - del_lds[ql]) * 0.125f;     // dS (scaled)
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pb = pack8(pv, s2);
+          const bf16x8 db = pack8(s, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            const bf16x8 dof = tfrag(dOt_lds, dt * 32 + r, qt * 32 + 16 * s2, h);
+            dv[dt] = mfma32(dof, pb, dv[dt]);              // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+            const bf16x8 qtf = tfrag(Qt_lds, dt * 32 + r, qt * 32 + 16 * s2, h);
+            dk[dt] = mfma32(qtf, db, dk[dt]);              // dK^T[d][key]  += Q^T[d][q] dS[q][key]
+          }
+        }
+      }
+    }
+  }
+  if (krow >= Lk) return;
+  bf16* dkg = (bf16*)a.dk + ((size_t)b * Lk + krow) * C + head * 64;
+  bf16* dvg = (bf16*)a.dv + ((size_t)b * Lk + krow) * C + head * 64;
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 o1, o2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { o1[k] = f2bf(dk[dt][4 * g + k]); o2[k] = f2bf(dv[dt][4 * g + k]); }
+      *(bf16x4*)(dkg + dt * 32 + 8 * g + 4 * h) = o1;
+      *(bf16x4*)(dvg + dt * 32 + 8 * g + 4 * h) = o2;
+    }
+}
+
+// ================================================================================================================
+// small HBM-bound helpers
+
+// qkv [tok][3C] (channel = s*C + head*64 + c) -> q,k,v [tok][C], each 64-vector normalised: x / (eps + |x|/8)
+__global__ void qkv_norm_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ q, bf16* __restrict__ k,
+                                bf16* __restrict__ v, long long nvec, int C) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vec = gid >> 3;
+  const int part = (int)(gid & 7);
+  if (vec >= nvec) return;
+  const int hpt = 3 * C / 64;                       // vectors per token
+  const long long tok = vec / hpt;
+  const int vi = (int)(vec % hpt);                  // = s*heads + head
+  const int s = vi / (C / 64), hd = vi % (C / 64);
+  const bf16x8 x = *(const bf16x8*)(qkv + tok * 3 * C + (size_t)vi * 64 + part * 8);
+  float f[8], ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { f[i] = bf2f(x[i]); ss += f[i] * f[i]; }
+  ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+  const float inv = 1.f / (1e-4f + sqrtf(ss) * 0.125f);
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f2bf(f[i] * inv);
+  bf16* dst = (s == 0) ? q : (s == 1) ? k : v;
+  *(bf16x8*)(dst + tok * C + hd * 64 + part * 8) = o;
+}
+
+__global__ void qkv_norm_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dq,
+                                    const bf16* __restrict__ dk, const bf16* __restrict__ dv,
+                                    bf16* __restrict__ dqkv, long long nvec, int C) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vec = gid >> 3;
+  const int part = (int)(gid & 7);
+  if (vec >= nvec) return;
+  const int hpt = 3 * C / 64;
+  const long long tok = vec / hpt;
+  const int vi = (int)(vec % hpt);
+  const int s = vi / (C / 64), hd = vi % (C / 64);
+  const bf16x8 x = *(const bf16x8*)(qkv + tok * 3 * C + (size_t)vi * 64 + part * 8);
+  const bf16* src = (s == 0) ? dq : (s == 1) ? dk : dv;
+  const bf16x8 g = *(const bf16x8*)(src + tok * C + hd * 64 + part * 8);
+  float f[8], gg[8], ss = 0.f, dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { f[i] = bf2f(x[i]); gg[i] = bf2f(g[i]); ss += f[i] * f[i]; dot += f[i] * gg[i]; }
+  ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+  dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+  const float n = sqrtf(ss), sden = 1e-4f + n * 0.125f;
+  const float k1 = 1.f / sden, k2 = (n > 0.f) ? dot * 0.125f / (sden * sden * n) : 0.f;
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f2bf(gg[i] * k1 - f[i] * k2);
+  *(bf16x8*)(dqkv + tok * 3 * C + (size_t)vi * 64 + part * 8) = o;
+}
+
+// rotary embedding over the frame index (+ optional transposed copy); one workgroup = 64 tokens x 1 head
+__global__ __launch_bounds__(256) void rope_kernel(const bf16* __restrict__ x, bf16* __restrict__ xr,
+                                                   bf16* __restrict__ xt, const float* __restrict__ cos_t,
+                                                   const float* __restrict__ sin_t, const float* __restrict__ scale_t,
+                                                   int mode, int L, int P, int C, int heads, int pos_offset,
+                                                   int pos_mod) {
+  __shared__ float tile[64][65];
+  const int tid = threadIdx.x;
+  const int tok0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
+  const bf16* xg = x + (size_t)b * L * C + head * 64;
+  {
+    const int row = tid >> 2, part = tid & 3;       // 16 channels per thread
+    const int tok = tok0 + row;
+    bf16x8 v0, v1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { v0[i] = f2bf(0.f); v1[i] = f2bf(0.f); }
+    if (tok < L) {
+      v0 = *(const bf16x8*)(xg + (size_t)tok * C + part * 16);
+      v1 = *(const bf16x8*)(xg + (size_t)tok * C + part * 16 + 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { tile[row][part * 16 + i] = bf2f(v0[i]); tile[row][part * 16 + 8 + i] = bf2f(v1[i]); }
+  }
+  __syncthreads();
+  if (mode != 0) {
+    const int row = tid >> 2, part = tid & 3;
+    const int tok = tok0 + row;
+    float out[16];
+    if (tok < L) {
+      const int pos = pos_offset + ((tok / P) % pos_mod);
+      const float* cs = cos_t + (size_t)pos * 64;
+      const float* sn = sin_t + (size_t)pos * 64;
+      const float* sc = scale_t + (size_t)pos * 64;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int c = part * 16 + i;
+        const float a0 = tile[row][c];
+        const float a1 = tile[row][c ^ 32];
+        float sg = (c < 32) ? -1.f : 1.f;            // rotate_half: [-x2, x1]
+        if (mode >= 3) sg = -sg;                     // adjoint
+        float val = a0 * cs[c] + sg * a1 * sn[c];
+        const float scl = sc[c];
+        val = (mode == 1 || mode == 3) ? val * scl : val / scl;
+        out[i] = val;
+      }
+    }
+    __syncthreads();
+    if (tok < L) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tile[row][part * 16 + i] = out[i];
+    }
+    __syncthreads();
+  }
+  if (xr) {
+    const int row = tid >> 2, part = tid & 3;
+    const int tok = tok0 + row;
+    if (tok < L) {
+      bf16x8 v0, v1;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { v0[i] = f2bf(tile[row][part * 16 + i]); v1[i] = f2bf(tile[row][part * 16 + 8 + i]); }
+      bf16* dst = xr + (size_t)b * L * C + head * 64 + (size_t)tok * C + part * 16;
+      *(bf16x8*)dst = v0;
+      *(bf16x8*)(dst + 8) = v1;
+    }
+  }
+  if (xt) {
+    const int ch = tid >> 2, part = tid & 3;        // 16 tokens per thread
+    bf16* dst = xt + ((size_t)(b * heads + head) * 64 + ch) * L + tok0 + part * 16;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      if (tok0 + part * 16 + hh * 8 < L) {
+        bf16x8 v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = f2bf(tile[part * 16 + hh * 8 + i][ch]);
+        *(bf16x8*)(dst + hh * 8) = v;
+      }
+    }
+  }
+}
+
+// delta[b][h][tok] = sum_c dO * O
+__global__ void attn_delta_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out, float* __restrict__ delta,
+                                  long long nvec, int L, int C, int heads) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vec = gid >> 3;
+  const int part = (int)(gid & 7);
+  if (vec >= nvec) return;
+  const long long tokg = vec / heads;                // b*L + tok
+  const int hd = (int)(vec % heads);
+  const bf16x8 a = *(const bf16x8*)(dout + tokg * C + hd * 64 + part * 8);
+  const bf16x8 o = *(const bf16x8*)(out + tokg * C + hd * 64 + part * 8);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += bf2f(a[i]) * bf2f(o[i]);
+  s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
+  if (part == 0) {
+    const long long bb = tokg / L, tok = tokg % L;
+    delta[(bb * heads + hd) * L + tok] = s;
+  }
+}
+
+// ================================================================================================================
+// host entry points
+static int ilog2_exact(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return ((1 << s) == v) ? s : -1;
+}
+
+static int attn_prepare(const OnirisAttnArgs* args, AttnDev& d, const char* who) {
+  if (!args) { oniris_set_error("%s: null args", who); return ONIRIS_EINVAL; }
+  d.a = *args;
+  const OnirisAttnArgs& a = d.a;
+  if (!(a.B > 0 && a.heads > 0 && a.Lq > 0 && a.Lk > 0 && a.C == a.heads * 64)) {
+    oniris_set_error("%s: bad sizes (C must be heads*64)", who); return ONIRIS_EINVAL;
+  }
+  if (a.Lk % 8 != 0 || a.Lq % 8 != 0) { oniris_set_error("%s: Lq, Lk must be multiples of 8", who); return ONIRIS_EINVAL; }
+  d.pshift = 0; d.qf_off = 0;
+  if (a.mask_mode != 0) {
+    d.pshift = ilog2_exact(a.P);
+    if (d.pshift < 0) { oniris_set_error("%s: P=%d must be a power of two", who, a.P); return ONIRIS_EUNSUPPORTED; }
+    if (a.mask_mode == 1) d.qf_off = (a.Lk - a.Lq) / a.P;
+    if (a.mask_mode == 2 && (a.Lq != a.Lk || a.Lq != 2 * a.T * a.P || (a.T * a.P) % 128 != 0)) {
+      oniris_set_error("%s: training mask needs Lq == Lk == 2*T*P and T*P %% 128 == 0", who); return ONIRIS_EINVAL;
+    }
+  }
+  if (a.mask_mode < 0 || a.mask_mode > 2) { oniris_set_error("%s: bad mask_mode", who); return ONIRIS_EINVAL; }
+  return ONIRIS_OK;
+}
+
+#define ATTN_DISPATCH(KERN, GRID)                                                                     \
+  switch (d.a.mask_mode) {                                                                            \
+    case 0: hipLaunchKernelGGL(KERN<0>, GRID, dim3(256), 0, stream, d); break;                        \
+    case 1: hipLaunchKernelGGL(KERN<1>, GRID, dim3(256), 0, stream, d); break;                        \
+    default: hipLaunchKernelGGL(KERN<2>, GRID, dim3(256), 0, stream, d); break;                       \
+  }
+
+extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnDev d;
+  int rc = attn_prepare(args, d, "attn_fwd");
+  if (rc) return rc;
+  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.vt && d.a.out, "attn_fwd: null pointer");
+  const dim3 grid(cdiv(d.a.Lq, 128), d.a.heads, d.a.B);
+  ATTN_DISPATCH(attn_fwd_kernel, grid);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnDev d;
+  int rc = attn_prepare(args, d, "attn_bwd_dq");
+  if (rc) return rc;
+  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.kt && d.a.dout && d.a.lse && d.a.delta && d.a.dq,
+                   "attn_bwd_dq: null pointer");
+  const dim3 grid(cdiv(d.a.Lq, 128), d.a.heads, d.a.B);
+  ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnDev d;
+  int rc = attn_prepare(args, d, "attn_bwd_dkv");
+  if (rc) return rc;
+  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.qt && d.a.dout && d.a.doutt && d.a.lse && d.a.delta && d.a.dk && d.a.dv,
+                   "attn_bwd_dkv: null pointer");
+  const dim3 grid(cdiv(d.a.Lk, 128), d.a.heads, d.a.B);
+  ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_qkv_norm(const void* qkv, void* q, void* k, void* v, int64_t n_tokens, int C,
+                               oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(qkv && q && k && v && n_tokens > 0 && C > 0 && C % 64 == 0, "qkv_norm: bad arguments");
+  const long long nvec = (long long)n_tokens * 3 * C / 64;
+  const long long nthr = nvec * 8;
+  hipLaunchKernelGGL(qkv_norm_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
+                     (bf16*)q, (bf16*)k, (bf16*)v, nvec, C);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_qkv_norm_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv,
+                                   int64_t n_tokens, int C, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(qkv && dq && dk && dv && dqkv && n_tokens > 0 && C > 0 && C % 64 == 0, "qkv_norm_bwd: bad arguments");
+  const long long nvec = (long long)n_tokens * 3 * C / 64;
+  const long long nthr = nvec * 8;
+  hipLaunchKernelGGL(qkv_norm_bwd_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16*)qkv, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (bf16*)dqkv, nvec, C);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const float* sin_t,
+                           const float* scale_t, int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod,
+                           oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(x && (xr || xt) && B > 0 && frames > 0 && P > 0 && C % 64 == 0 && mode >= 0 && mode <= 4,
+                   "rope: bad arguments");
+  ONIRIS_CHECK_ARG(mode == 0 || (cos_t && sin_t && scale_t && pos_mod > 0), "rope: tables missing");
+  const int L = frames * P;
+  ONIRIS_CHECK_ARG(L % 8 == 0, "rope: frames*P must be a multiple of 8");
+  const dim3 grid(cdiv(L, 64), C / 64, B);
+  hipLaunchKernelGGL(rope_kernel, grid, dim3(256), 0, stream, (const bf16*)x, (bf16*)xr, (bf16*)xt, cos_t, sin_t,
+                     scale_t, mode, L, P, C, C / 64, pos_offset, pos_mod > 0 ? pos_mod : 1);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* doutt, int B, int heads,
+                                    int L, int C, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(dout && out && delta && B > 0 && heads > 0 && L > 0 && C == heads * 64, "attn_bwd_prep: bad arguments");
+  const long long nvec = (long long)B * L * heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16*)dout, (const bf16*)out, delta, nvec, L, C, heads);
+  ONIRIS_LAUNCH_CHECK();
+  if (doutt) return oniris_rope(dout, nullptr, doutt, nullptr, nullptr, nullptr, 0, B, L, 1, C, 0, 1, stream_);
+  return ONIRIS_OK;
+}

@@ -1,0 +1,79 @@
+// Shared device/host helpers for liboniris_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define ONIRIS_OK 0
+#define ONIRIS_EINVAL (-1)
+#define ONIRIS_ELAUNCH (-2)
+#define ONIRIS_EUNSUPPORTED (-3)
+
+// thread-local last error (C-ABI: oniris_last_error)
+void oniris_set_error(const char* fmt, ...);
+
+#define ONIRIS_CHECK_ARG(cond, ...)                \
+  do {                                             \
+    if (!(cond)) {                                 \
+      oniris_set_error(__VA_ARGS__);               \
+      return ONIRIS_EINVAL;                        \
+    }                                              \
+  } while (0)
+
+#define ONIRIS_LAUNCH_CHECK()                                            \
+  do {                                                                   \
+    hipError_t e_ = hipGetLastError();                                   \
+    if (e_ != hipSuccess) {                                              \
+      oniris_set_error("%s:%d launch failed: %s", __FILE__, __LINE__,    \
+                       hipGetErrorString(e_));                           \
+      return ONIRIS_ELAUNCH;                                             \
+    }                                                                    \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int roundup(int a, int b) { return cdiv(a, b) * b; }
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float bf2f(bf16 v) { return (float)v; }
+__device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
+
+// MFMA 32x32x16 bf16:  D[i][j] += sum_k A[i][k] * B[k][j]
+//   lane l: A[i = l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j = l&31], e = 0..7
+//   D: lane holds col j = l&31, rows i = (r&3) + 8*(r>>2) + 4*(l>>5), r = 0..15
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (multiple of 64); `red` >= 16 floats of LDS
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+#endif

@@ -1,0 +1,307 @@
+// Implicit-GEMM gated causal convolution for gfx950 (MFMA 32x32x16 bf16 -> fp32).
+//
+// Data layout in HBM: activations [frame][H][W][C] bf16 (channels-last, C % 16 == 0), packed weights
+// [tap][CoutP][CinP] bf16 (ci contiguous).  One 256-thread workgroup (4 waves) computes a tile of
+//   128 positions (FT frames x PH x PW patch)  x  S slots (clean|noised)  x  BN = 32*NT output channels.
+// Wave w owns positions [32w, 32w+32): MFMA D[i = co][j = position], so every lane is ONE position and the
+// epilogue (gate combine, emb-scale+SiLU, mp_sum+clip) is lane-local.
+// Per 32-channel K chunk:  phase OWN: the S*HALO input pixels of the patch (+1 halo) are staged ONCE in LDS and
+// reused by the 9 taps (each tap is a constant row offset into the halo image); phases CTX0/CTX1 do the same for
+// the two previous clean frames whose product is SHARED by the clean and the noised slot (one accumulator).
+// LDS rows are padded by 16 B (row = CK*2+16 bytes) which makes the 16-byte fragment reads conflict-free.
+// Roofline: MFMA-bound for C >= 64 (intensity ~ 27*C FLOP/B of activation), HBM-bound below.
+#pragma once
+#include "common.h"
+#include "../../include/oniris.h"
+
+template <int PW_>
+struct Patch {
+  static constexpr int PW = PW_;
+  static constexpr int PH = (PW_ == 16) ? 8 : PW_;
+  static constexpr int FT = 128 / (PW * PH);
+  static constexpr int HW = PW + 2, HH = PH + 2;
+  static constexpr int HALO = FT * HH * HW;
+};
+
+struct ConvDev {
+  OnirisConvArgs a;
+  int ntx, nty, ntt, ncob;
+};
+
+template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW>
+struct ConvCfg {
+  using P = Patch<PW>;
+  static constexpr int BN = 32 * NT;
+  static constexpr int ROWB = CK * 2 + 16;
+  static constexpr int PARTS = CK / 8;
+  static constexpr int AROWS = (TAPS == 9) ? S * P::HALO : S * 128;
+  static constexpr int CROWS = (TAPS == 9) ? P::HALO : 128;
+  static constexpr int WROWS = TAPS * BN;
+  static constexpr int LDS_BYTES = (AROWS + WROWS) * ROWB;
+};
+
+template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW>
+__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
+  using Cfg = ConvCfg<S, TAPS, CK, NT, HAS_CTX, PW>;
+  using P = Patch<PW>;
+  constexpr int BN = Cfg::BN, ROWB = Cfg::ROWB, PARTS = Cfg::PARTS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* A_lds = smem;
+  unsigned char* W_lds = smem + Cfg::AROWS * ROWB;
+
+  const OnirisConvArgs& a = d.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, T = a.T, Cin = a.Cin, HWp = a.H * a.W;
+
+  // ---- tile decode
+  int bid = blockIdx.x;
+  int t0 = 0, y0 = 0, x0 = 0, q0 = 0;
+  if constexpr (TAPS == 9) {
+    const int tx = bid % d.ntx; bid /= d.ntx;
+    const int ty = bid % d.nty; bid /= d.nty;
+    const int tc = bid % d.ntt; bid /= d.ntt;
+    t0 = tc * P::FT; y0 = ty * P::PH; x0 = tx * P::PW;
+  } else {
+    const int tq = bid % d.ntt; bid /= d.ntt;      // ntt = number of 128-position tiles per (b,s)
+    q0 = tq * 128;
+  }
+  const int b = bid % a.B;
+  const int co0 = (bid / a.B) * BN;
+
+  // ---- this lane's position
+  const int p = wave * 32 + r;
+  int ft = 0, py = 0, px = 0, arow = p;
+  if constexpr (TAPS == 9) {
+    ft = p / (P::PH * P::PW); py = (p / P::PW) % P::PH; px = p % P::PW;
+    arow = (ft * P::HH + py) * P::HW + px;
+  }
+
+  f32x16 acc[S][NT];
+  f32x16 accc[NT];
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[s][n][i] = 0.f;
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accc[n][i] = 0.f;
+
+  const bf16* xg = (const bf16*)a.x;
+  const bf16* cg = (const bf16*)a.ctx;
+  const int nchunk = (Cin + CK - 1) / CK;
+  constexpr int NPH = HAS_CTX ? 3 : 1;
+
+  for (int ch = 0; ch < nchunk; ++ch) {
+    const int c0 = ch * CK;
+#pragma unroll 1
+    for (int ph = 0; ph < NPH; ++ph) {
+      // ------------------------------------------------------------------ stage A (activations) into LDS
+      if (ph == 0) {
+        constexpr int TOT = Cfg::AROWS * PARTS;
+        constexpr int NI = (TOT + 255) / 256;
+        uint4 v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int e = tid + i * 256;
+          v[i] = make_uint4(0, 0, 0, 0);
+          if (e < TOT) {
+            const int row = e / PARTS, part = e % PARTS;
+            const int ci = c0 + part * 8;
+            if constexpr (TAPS == 9) {
+              const int s = row / P::HALO, hr = row % P::HALO;
+              const int f_ = hr / (P::HH * P::HW), rem = hr % (P::HH * P::HW);
+              const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1, t = t0 + f_;
+              if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin)
+                v[i] = *(const uint4*)(xg + ((size_t)((b * S + s) * T + t) * HWp + y * W + x) * Cin + ci);
+            } else {
+              const int s = row / 128, q = q0 + (row % 128);
+              if (q < T * HWp && ci < Cin)
+                v[i] = *(const uint4*)(xg + ((size_t)(b * S + s) * T * HWp + q) * Cin + ci);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int e = tid + i * 256;
+          if (e < TOT) *(uint4*)(A_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = v[i];
+        }
+      } else {
+        constexpr int TOT = Cfg::CROWS * PARTS;
+        constexpr int NI = (TOT + 255) / 256;
+        const int coff = (ph == 1) ? a.coff0 : a.coff1;
+        const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.ctx_fill));
+        const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
+        uint4 v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int e = tid + i * 256;
+          v[i] = make_uint4(0, 0, 0, 0);
+          if (e < TOT) {
+            const int row = e / PARTS, part = e % PARTS;
+            const int ci = c0 + part * 8;
+            const int f_ = row / (P::HH * P::HW), rem = row % (P::HH * P::HW);
+            const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1, t = t0 + f_;
+            if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin) {
+              const int f = t + coff;
+              if (f >= 0 && f < a.ctx_T)
+                v[i] = *(const uint4*)(cg + ((size_t)(b * a.ctx_bstride + f) * HWp + y * W + x) * Cin + ci);
+              else
+                v[i] = make_uint4(fill2, fill2, fill2, fill2);
+            }
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int e = tid + i * 256;
+          if (e < TOT) *(uint4*)(A_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = v[i];
+        }
+      }
+      // ------------------------------------------------------------------ stage W (packed weights) into LDS
+      {
+        const bf16* wg = (ph == 0) ? (const bf16*)a.w_own
+                                   : (const bf16*)a.w_ctx + (size_t)(ph - 1) * TAPS * a.CoutP * a.CinP;
+        constexpr int TOT = Cfg::WROWS * PARTS;
+        constexpr int NI = (TOT + 255) / 256;
+        uint4 v[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int e = tid + i * 256;
+          if (e < TOT) {
+            const int row = e / PARTS, part = e % PARTS;
+            const int tap = row / BN, co = row % BN;
+            v[i] = *(const uint4*)(wg + ((size_t)tap * a.CoutP + co0 + co) * a.CinP + c0 + part * 8);
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+          const int e = tid + i * 256;
+          if (e < TOT) *(uint4*)(W_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = v[i];
+        }
+      }
+      __syncthreads();
+      // ------------------------------------------------------------------ MFMA over taps x k-steps
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int off = (TAPS == 9) ? ((tap / 3) * P::HW + (tap % 3)) : 0;
+#pragma unroll
+        for (int ks = 0; ks < CK / 16; ++ks) {
+          bf16x8 wf[NT];
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+            wf[n] = *(const bf16x8*)(W_lds + (tap * BN + n * 32 + r) * ROWB + ks * 32 + h * 16);
+          if (ph == 0) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+              const int srow = (TAPS == 9) ? s * P::HALO : s * 128;
+              const bf16x8 xf = *(const bf16x8*)(A_lds + (srow + arow + off) * ROWB + ks * 32 + h * 16);
+#pragma unroll
+              for (int n = 0; n < NT; ++n) acc[s][n] = mfma32(wf[n], xf, acc[s][n]);
+            }
+          } else {
+            const bf16x8 xf = *(const bf16x8*)(A_lds + (arow + off) * ROWB + ks * 32 + h * 16);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) accc[n] = mfma32(wf[n], xf, accc[n]);
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // -------------------------------------------------------------------- epilogue (lane-local per position)
+  bool valid;
+  size_t pix;       // pixel index inside the (b,s) block of T frames
+  int tloc;
+  if constexpr (TAPS == 9) {
+    tloc = t0 + ft;
+    valid = tloc < T;
+    pix = (size_t)tloc * HWp + (y0 + py) * W + (x0 + px);
+  } else {
+    const int q = q0 + p;
+    valid = q < T * HWp;
+    tloc = valid ? q / HWp : 0;
+    pix = (size_t)q;
+  }
+  if (!valid) return;
+  bf16* og = (bf16*)a.out;
+  const float gain = (a.epi == ONIRIS_EPI_EMB_SILU) ? *a.emb_gain : 0.f;
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    const int n = (b * S + s) * T + tloc;
+    const float cown = a.coef_own ? a.coef_own[n] : 1.f;
+    float cctx = 0.f;
+    if constexpr (HAS_CTX) cctx = a.coef_ctx ? a.coef_ctx[n] : 1.f;
+    const size_t obase = ((size_t)(b * S + s) * T * HWp + pix) * a.Cout;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int co = co0 + nt * 32 + 8 * g + 4 * h;
+        if (co >= a.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          v[k] = cown * acc[s][nt][4 * g + k];
+          if constexpr (HAS_CTX) v[k] += cctx * accc[nt][4 * g + k];
+        }
+        if (a.epi == ONIRIS_EPI_MPSUM) {
+          const bf16x4 rv = *(const bf16x4*)((const bf16*)a.res + obase + co);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            float o = a.ta * bf2f(rv[k]) + a.tb * v[k];
+            if (a.clip > 0.f) o = fminf(fmaxf(o, -a.clip), a.clip);
+            v[k] = o;
+          }
+        }
+        bf16x4 ov;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ov[k] = f2bf(v[k]);
+        *(bf16x4*)(og + obase + co) = ov;
+        if (a.epi == ONIRIS_EPI_EMB_SILU) {
+          const bf16x4 ev = *(const bf16x4*)((const bf16*)a.escale + (size_t)n * a.Cout + co);
+          bf16x4 uv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float z = bf2f(ov[k]) * (1.f + gain * bf2f(ev[k]));
+            uv[k] = f2bf(z / (1.f + __expf(-z)) * (1.f / 0.596f));
+          }
+          *(bf16x4*)((bf16*)a.out2 + obase + co) = uv;
+        }
+      }
+    }
+  }
+}
+
+template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW>
+static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
+  using Cfg = ConvCfg<S, TAPS, CK, NT, HAS_CTX, PW>;
+  using P = Patch<PW>;
+  ConvDev d;
+  d.a = a;
+  d.ncob = a.CoutP / Cfg::BN;
+  if (TAPS == 9) {
+    d.ntx = a.W / P::PW; d.nty = a.H / P::PH; d.ntt = cdiv(a.T, P::FT);
+  } else {
+    d.ntx = 1; d.nty = 1; d.ntt = cdiv(a.T * a.H * a.W, 128);
+  }
+  const long long nblk = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
+  if (nblk <= 0 || nblk > 0x7fffffffLL) { oniris_set_error("conv_fwd: bad grid %lld", nblk); return ONIRIS_EINVAL; }
+  auto kern = conv_fwd_kernel<S, TAPS, CK, NT, HAS_CTX, PW>;
+  if (Cfg::LDS_BYTES > 64 * 1024) {
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) !=
+          hipSuccess) {
+        oniris_set_error("conv_fwd: cannot raise dynamic LDS to %d", Cfg::LDS_BYTES);
+        return ONIRIS_ELAUNCH;
+      }
+      attr_done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, stream, d);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}

@@ -1,0 +1,248 @@
+// Weight gradient of the (gated causal) convolution as an implicit GEMM over positions:
+//   dW[tap][co][ci] += sum_pos dy[pos][co] * x[pos + tap][ci]          (MFMA 32x32x16 bf16 -> fp32)
+// Both operands are channel-contiguous in HBM but the reduction runs over positions, so tiles are staged
+// row-major ([position][channel]) in LDS and the k-contiguous MFMA fragments are produced by the gfx950
+// transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group).  The x tile is the halo image
+// of the patch, shared by the 9 taps.  A workgroup owns a (32*CT co) x (32*IT ci) x 9-tap output tile and walks
+// a strided subset of the position tiles (split-K); partial sums are added with fp32 global atomics whose wave
+// shape is two 128-byte row segments (full atomic rate on gfx950).
+#include "conv_kernels.h"
+
+struct WgradDev {
+  OnirisWgradArgs a;
+  int ntx, nty, ntt, ntiles, ncib;
+};
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base0, const unsigned char* base1) {
+  // two transposing reads -> 8 k-contiguous bf16 for this lane's channel
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)base0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)base1);
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int TAPS, int PW, int CT, int IT>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
+  using P = Patch<PW>;
+  constexpr int NTILE = CT * IT;          // 32x32 output tiles per tap in this workgroup
+  constexpr int NKS = 4 / NTILE;          // waves sharing one tile split the k-steps
+  constexpr int DYB = CT * 64, XB = IT * 64;
+  constexpr int DY_ROWB = (CT == 1) ? 64 : 192;
+  constexpr int X_ROWB = (IT == 1) ? 64 : 192;
+  constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* dy_lds = smem;
+  unsigned char* x_lds = smem + 128 * DY_ROWB;
+
+  const OnirisWgradArgs& a = d.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = a.H, W = a.W, T = a.T, HWp = H * W;
+  const int my_tile = wave % NTILE, my_ks = wave / NTILE;
+  const int ct = my_tile % CT, it = my_tile / CT;
+  const int cib = blockIdx.y % d.ncib, cob = blockIdx.y / d.ncib;
+  const int co0 = cob * 32 * CT, ci0 = cib * 32 * IT;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  const bf16* xg = (const bf16*)a.x;
+  const bf16* dyg = (const bf16*)a.dy;
+  // lane roles for the transposing reads
+  const int grp = lane >> 4, hh = grp >> 1, q = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
+
+  for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+    int bid = tile;
+    int t0 = 0, y0 = 0, x0 = 0, q0 = 0;
+    if constexpr (TAPS == 9) {
+      const int tx = bid % d.ntx; bid /= d.ntx;
+      const int ty = bid % d.nty; bid /= d.nty;
+      const int tc = bid % d.ntt; bid /= d.ntt;
+      t0 = tc * P::FT; y0 = ty * P::PH; x0 = tx * P::PW;
+    } else {
+      const int tq = bid % d.ntt; bid /= d.ntt;
+      q0 = tq * 128;
+    }
+    const int b = bid;
+
+    // ---- stage dy tile [128 positions][32*CT co], scaled per frame
+    {
+      constexpr int PARTS = DYB / 16;
+      constexpr int TOT = 128 * PARTS;
+      constexpr int NI = TOT / 256;
+      uint4 v[NI];
+      float sc[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int row = e / PARTS, part = e % PARTS;
+        const int co = co0 + part * 8;
+        v[i] = make_uint4(0, 0, 0, 0);
+        sc[i] = 1.f;
+        int t; size_t pix; bool ok;
+        if constexpr (TAPS == 9) {
+          const int f_ = row / (P::PH * P::PW), py = (row / P::PW) % P::PH, px = row % P::PW;
+          t = t0 + f_; ok = t < T; pix = (size_t)t * HWp + (y0 + py) * W + x0 + px;
+        } else {
+          const int qq = q0 + row;
+          ok = qq < T * HWp; t = ok ? qq / HWp : 0; pix = (size_t)qq;
+        }
+        if (ok && co < a.Cout) {
+          v[i] = *(const uint4*)(dyg + ((size_t)b * T * HWp + pix) * a.Cout + co);
+          if (a.scale) sc[i] = a.scale[b * T + t];
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        const int row = e / PARTS, part = e % PARTS;
+        uint4 o = v[i];
+        if (a.scale) {
+          bf16x8 bv = __builtin_bit_cast(bf16x8, o);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) bv[k] = f2bf(bf2f(bv[k]) * sc[i]);
+          o = __builtin_bit_cast(uint4, bv);
+        }
+        *(uint4*)(dy_lds + row * DY_ROWB + part * 16) = o;
+      }
+    }
+    // ---- stage x halo [XROWS][32*IT ci]
+    {
+      constexpr int PARTS = XB / 16;
+      constexpr int TOT = XROWS * PARTS;
+      constexpr int NI = (TOT + 255) / 256;
+      const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.fill));
+      const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
+      uint4 v[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        v[i] = make_uint4(0, 0, 0, 0);
+        if (e < TOT) {
+          const int row = e / PARTS, part = e % PARTS;
+          const int ci = ci0 + part * 8;
+          int t, y, x; bool ok;
+          if constexpr (TAPS == 9) {
+            const int f_ = row / (P::HH * P::HW), rem = row % (P::HH * P::HW);
+            y = y0 + rem / P::HW - 1; x = x0 + rem % P::HW - 1; t = t0 + f_;
+            ok = t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+          } else {
+            const int qq = q0 + row;
+            ok = qq < T * HWp; t = ok ? qq / HWp : 0; const int pp = ok ? qq % HWp : 0; y = pp / W; x = pp % W;
+          }
+          if (ok && ci < a.Cin) {
+            const int f = t + a.coff;
+            if (f >= 0 && f < a.x_T)
+              v[i] = *(const uint4*)(xg + ((size_t)(b * a.xb_stride + f) * HWp + y * W + x) * a.Cin + ci);
+            else
+              v[i] = make_uint4(fill2, fill2, fill2, fill2);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int e = tid + i * 256;
+        if (e < TOT) *(uint4*)(x_lds + (e / PARTS) * X_ROWB + (e % PARTS) * 16) = v[i];
+      }
+    }
+    __syncthreads();
+    // ---- MFMA: k = 16 positions per step
+#pragma unroll
+    for (int ksi = 0; ksi < 8 / NKS; ++ksi) {
+      const int ks = ksi * NKS + my_ks;
+      // rows (positions) this lane addresses for the two transposing reads
+      const int p0 = ks * 16 + 8 * hh + q, p1 = p0 + 4;
+      const bf16x8 af = tr_frag(dy_lds + p0 * DY_ROWB + (ct * 32 + pcol) * 2, dy_lds + p1 * DY_ROWB + (ct * 32 + pcol) * 2);
+      int r0 = p0, r1 = p1;
+      if constexpr (TAPS == 9) {
+        r0 = ((p0 / (P::PH * P::PW)) * P::HH + (p0 / P::PW) % P::PH) * P::HW + p0 % P::PW;
+        r1 = ((p1 / (P::PH * P::PW)) * P::HH + (p1 / P::PW) % P::PH) * P::HW + p1 % P::PW;
+      }
+#pragma unroll
+      for (int tap = 0; tap < TAPS; ++tap) {
+        const int off = (TAPS == 9) ? ((tap / 3) * P::HW + (tap % 3)) : 0;
+        const bf16x8 bfm = tr_frag(x_lds + (r0 + off) * X_ROWB + (it * 32 + pcol) * 2,
+                                   x_lds + (r1 + off) * X_ROWB + (it * 32 + pcol) * 2);
+        acc[tap] = mfma32(af, bfm, acc[tap]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- accumulate into the packed fp32 gradient  dwp[tap][co][ci]
+  const int cj = ci0 + it * 32 + (lane & 31);
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    float* base = a.dwp + (size_t)tap * a.CoutP * a.CinP;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int co = co0 + ct * 32 + mfma_row(rr, lane);
+      if (co < a.CoutP && cj < a.CinP) atomicAdd(base + (size_t)co * a.CinP + cj, acc[tap][rr]);
+    }
+  }
+}
+
+template <int TAPS, int PW, int CT, int IT>
+static int launch_wgrad(const OnirisWgradArgs& a, hipStream_t stream) {
+  using P = Patch<PW>;
+  WgradDev d;
+  d.a = a;
+  if (TAPS == 9) {
+    d.ntx = a.W / P::PW; d.nty = a.H / P::PH; d.ntt = cdiv(a.T, P::FT);
+  } else {
+    d.ntx = 1; d.nty = 1; d.ntt = cdiv(a.T * a.H * a.W, 128);
+  }
+  d.ntiles = d.ntx * d.nty * d.ntt * a.B;
+  d.ncib = cdiv(a.Cin, 32 * IT);
+  const int ncob = cdiv(a.Cout, 32 * CT);
+  const int gy = d.ncib * ncob;
+  int gx = 1024 / gy;
+  if (gx < 1) gx = 1;
+  if (gx > d.ntiles) gx = d.ntiles;
+  constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
+  constexpr int LDS = 128 * ((CT == 1) ? 64 : 192) + XROWS * ((IT == 1) ? 64 : 192);
+  auto kern = conv_wgrad_kernel<TAPS, PW, CT, IT>;
+  if (LDS > 64 * 1024) {
+    static bool attr_done = false;
+    if (!attr_done) {
+      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
+        oniris_set_error("conv_wgrad: cannot raise dynamic LDS to %d", LDS);
+        return ONIRIS_ELAUNCH;
+      }
+      attr_done = true;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), LDS, stream, d);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+template <int TAPS, int PW>
+static int wgrad_pick_tile(const OnirisWgradArgs& a, hipStream_t stream) {
+  if (a.Cin > 32 && a.Cout > 32) return launch_wgrad<TAPS, PW, 2, 2>(a, stream);
+  return launch_wgrad<TAPS, PW, 1, 1>(a, stream);
+}
+
+extern "C" int oniris_conv_wgrad(const OnirisWgradArgs* args, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(args && args->x && args->dy && args->dwp, "conv_wgrad: null pointer");
+  const OnirisWgradArgs& a = *args;
+  ONIRIS_CHECK_ARG(a.taps == 9 || a.taps == 1, "conv_wgrad: taps must be 1 or 9 (got %d)", a.taps);
+  ONIRIS_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv_wgrad: Cin/Cout must be multiples of 8");
+  ONIRIS_CHECK_ARG(a.CoutP % 32 == 0 && a.CinP % 64 == 0 && a.CoutP >= a.Cout && a.CinP >= a.Cin,
+                   "conv_wgrad: bad padded sizes");
+  if (a.taps == 1) return wgrad_pick_tile<1, 16>(a, stream);
+  const int W = a.W, H = a.H;
+  if (W >= 16 && W % 16 == 0 && H % 8 == 0) return wgrad_pick_tile<9, 16>(a, stream);
+  if (W == 8 && H % 8 == 0) return wgrad_pick_tile<9, 8>(a, stream);
+  if (W == 4 && H % 4 == 0) return wgrad_pick_tile<9, 4>(a, stream);
+  if (W == 2 && H % 2 == 0) return wgrad_pick_tile<9, 2>(a, stream);
+  oniris_set_error("conv_wgrad: unsupported image size %dx%d", H, W);
+  return ONIRIS_EUNSUPPORTED;
+}

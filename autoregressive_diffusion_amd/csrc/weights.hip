@@ -1,0 +1,166 @@
+// Forced weight normalisation + bf16 packing for every weight of the net in ONE launch, and its backward.
+// Replaces NormalizedWeight.forward (reference edm2/conv.py:14-21) + the per-call `.to(x.dtype)` of MPConv
+// (edm2/conv.py:37,63).  HBM-bound row reductions: one 256-thread workgroup per output-channel row,
+// wave-shuffle + LDS reduce, fp32 math, coalesced row reads.
+#include "common.h"
+#include "../../include/oniris.h"
+
+#define W_EPS 1e-4f
+
+__device__ __forceinline__ const OnirisWeightDesc* find_desc(const OnirisWeightDesc* d, int n, int row) {
+  int lo = 0, hi = n - 1;                     // last desc with row_start <= row
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (d[mid].row_start <= row) lo = mid; else hi = mid - 1;
+  }
+  return d + lo;
+}
+
+// packed row index of original output channel `co`  (qkv: (m c s) -> (s m c), see attention_modules.py:48)
+__device__ __forceinline__ int perm_row(const OnirisWeightDesc* d, int co) {
+  if (!d->perm3) return co;
+  const int C = d->cout / 3;
+  return (co % 3) * C + co / 3;
+}
+
+__global__ __launch_bounds__(256) void weight_prep_kernel(const OnirisWeightDesc* descs, int ndesc, int training) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const OnirisWeightDesc* d = find_desc(descs, ndesc, row);
+  const int co = row - d->row_start;
+  const int taps = d->taps, cin = d->cin;
+  const int fan = cin * taps;
+  float* w = d->w + (size_t)co * fan;
+  const float rs = rsqrtf((float)fan);
+
+  float ss = 0.f;
+  for (int e = threadIdx.x; e < fan; e += 256) { float v = w[e]; ss += v * v; }
+  ss = block_sum(ss, red);
+  float inv1 = 1.f;
+  if (training) inv1 = 1.f / (W_EPS + sqrtf(ss) * rs);          // forced normalisation (stored back)
+  float ss2 = 0.f;
+  for (int e = threadIdx.x; e < fan; e += 256) {
+    float v = w[e] * inv1;
+    if (training) w[e] = v;
+    ss2 += v * v;
+  }
+  ss2 = block_sum(ss2, red);
+  const float scale = d->gain * rs / (W_EPS + sqrtf(ss2) * rs);   // second normalise * gain/sqrt(fan_in)
+
+  const int cop = perm_row(d, co);
+  bf16* wf = (bf16*)d->wf;
+  bf16* wb = (bf16*)d->wb;
+  const int per_t = d->kt > 0 ? taps / d->kt : taps;              // spatial taps per temporal slice (9 or 1)
+  for (int e = threadIdx.x; e < fan; e += 256) {
+    const int ci = e / taps, tap = e - ci * taps;
+    const float v = w[e] * (training ? 1.f : inv1) * scale;       // w already overwritten when training
+    const bf16 b = f2bf(v);
+    if (wf) wf[((size_t)tap * d->CoutP + cop) * d->CinP + ci] = b;
+    if (wb) {
+      const int j = tap / per_t, k = tap - j * per_t;
+      const int tb = j * per_t + (per_t - 1 - k);                 // spatially flipped tap, same temporal slice
+      wb[((size_t)tb * d->CoutPb + ci) * d->CinPb + cop] = b;
+    }
+  }
+}
+
+// grad(w_hat) of   W = gain/sqrt(f) * w_hat / (eps + |w_hat|/sqrt(f))   given dW (packed fp32, from wgrad)
+__global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc* descs, int ndesc) {
+  __shared__ float red[16];
+  const int row = blockIdx.x;
+  const OnirisWeightDesc* d = find_desc(descs, ndesc, row);
+  if (d->dwp == nullptr || d->grad == nullptr) return;
+  const int co = row - d->row_start;
+  const int taps = d->taps, cin = d->cin;
+  const int fan = cin * taps;
+  const float* w = d->w + (size_t)co * fan;
+  float* g = d->grad + (size_t)co * fan;
+  const int cop = perm_row(d, co);
+  float* dwp = d->dwp;
+  const float rs = rsqrtf((float)fan);
+
+  float dot = 0.f, nn = 0.f;
+  for (int e = threadIdx.x; e < fan; e += 256) {
+    const int ci = e / taps, tap = e - ci * taps;
+    const float G = dwp[((size_t)tap * d->CoutP + cop) * d->CinP + ci];
+    const float v = w[e];
+    dot += G * v; nn += v * v;
+  }
+  dot = block_sum(dot, red);
+  nn = block_sum(nn, red);
+  const float n = sqrtf(nn);
+  const float s = W_EPS + n * rs;
+  const float c = d->gain * rs;
+  const float k1 = c / s;
+  const float k2 = (n > 0.f) ? c * dot * rs / (s * s * n) : 0.f;
+  for (int e = threadIdx.x; e < fan; e += 256) {
+    const int ci = e / taps, tap = e - ci * taps;
+    const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
+    const float G = dwp[pi];
+    dwp[pi] = 0.f;                                                // leave the accumulator clean for the next step
+    g[e] += k1 * G - k2 * w[e];
+  }
+}
+
+extern "C" int oniris_weight_prep(const OnirisWeightDesc* descs_dev, int ndesc, int total_rows, int training,
+                                  oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(descs_dev && ndesc > 0 && total_rows > 0, "weight_prep: bad arguments");
+  hipLaunchKernelGGL(weight_prep_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc, training);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_weight_bwd(const OnirisWeightDesc* descs_dev, int ndesc, int total_rows, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(descs_dev && ndesc > 0 && total_rows > 0, "weight_bwd: bad arguments");
+  hipLaunchKernelGGL(weight_bwd_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// fused multi-tensor AdamW over the flat fp32 parameter / gradient buffers (gym_train.py:61,105-106 uses
+// torch.optim.AdamW; here one elementwise pass: 16 B/lane loads, 4 buffers)
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                             float bc1, float bc2, float gscale) {
+  size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+  for (; i + 3 < n; i += stride) {
+    float4 P = *(float4*)(p + i), G = *(const float4*)(g + i), M = *(float4*)(m + i), V = *(float4*)(v + i);
+    float* pp = (float*)&P; float* gg = (float*)&G; float* mm = (float*)&M; float* vv = (float*)&V;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * gscale;
+      mm[k] = b1 * mm[k] + (1.f - b1) * gr;
+      vv[k] = b2 * vv[k] + (1.f - b2) * gr * gr;
+      const float mh = mm[k] / bc1, vh = vv[k] / bc2;
+      pp[k] = pp[k] * (1.f - lr * wd) - lr * mh / (sqrtf(vh) + eps);
+    }
+    *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
+  }
+  if (i < n && i + 3 >= n) {
+    for (size_t k = i; k < n; ++k) {
+      const float gr = g[k] * gscale;
+      m[k] = b1 * m[k] + (1.f - b1) * gr;
+      v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
+      p[k] = p[k] * (1.f - lr * wd) - lr * (m[k] / bc1) / (sqrtf(v[k] / bc2) + eps);
+    }
+  }
+}
+
+extern "C" int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(p && g && m && v && step >= 1, "adamw: bad arguments");
+  if (n == 0) return ONIRIS_OK;
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  size_t nb = (n / 4 + 255) / 256;
+  if (nb > 4096) nb = 4096;
+  if (nb == 0) nb = 1;
+  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2, grad_scale);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}

@@ -1,0 +1,188 @@
+/* liboniris_hip.so -- C ABI of the MI355X-native Oniris denoiser-step kernels (gfx950 only).
+ *
+ * The reference (Francesco215/autoregressive_diffusion) has no FFI layer: its hot path is PyTorch dispatch from
+ * edm2/networks_edm2.py, edm2/conv.py and edm2/attention/.  Each entry point below names the reference call
+ * site(s) it replaces (file:line relative to the reference root).  Conventions:
+ *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked [host];
+ *   - the caller allocates every buffer; no hidden allocation, no stream synchronisation, no global state;
+ *   - returns 0 (ONIRIS_OK) or a negative code; oniris_last_error() gives a thread-local message;
+ *   - activations are channels-last bf16: a frame-slot tensor is [N][H][W][C] (C % 16 == 0 except outputs);
+ *     frame-slot index n = b*(S*T) + s*T + t  (S = 2 clean|noised in training -- the reference's '(b s t)'
+ *     order, edm2/conv.py:79 -- S = 1 in eval);
+ *   - `stream` is a hipStream_t passed as void*.
+ */
+#ifndef ONIRIS_H
+#define ONIRIS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* oniris_stream_t;
+
+const char* oniris_last_error(void);
+int oniris_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Mask tables [host, int32] -- bit-exact replacement of make_train_mask / make_infer_mask
+ * (edm2/attention/attention_masking.py:27-53, 64-90).
+ * oniris_train_mask: writes kv_num_blocks[2*nb] and kv_indices[2*nb][2*nb] for ONE (batch, head) (the reference
+ * repeats the same table over b,h).  Returns the number of row blocks 2*nb (>0), 0 when the reference returns
+ * None (T*P % 128 != 0 with P < 128), <0 on error.  Pass NULL outputs to query the size.  *block_size receives
+ * the BlockMask BLOCK_SIZE (P if P >= 128 else 128).
+ * oniris_infer_mask: same for the causal prefill mask; returns nb, 0 for the 'score_mod'/'dense' fall-backs
+ * (pure frame-causal mask_mod, no table).
+ * oniris_mask_transpose: inverts a kv table into the q table used by the dK/dV kernel (for each kv block: the
+ * q blocks that list it, ascending).
+ */
+int oniris_train_mask(int n_frames, int image_size, int32_t* kv_num_blocks, int32_t* kv_indices, int* block_size);
+int oniris_infer_mask(int n_frames, int image_size, int32_t* kv_num_blocks, int32_t* kv_indices, int* block_size);
+int oniris_mask_transpose(int n_rows, int n_cols, const int32_t* kv_num_blocks, const int32_t* kv_indices,
+                          int32_t* q_num_blocks, int32_t* q_indices);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Weights: forced normalisation + bf16 packing of ALL weights in one launch, and the backward through the
+ * normalisation.  Replaces NormalizedWeight.forward (edm2/conv.py:14-21) and the weight casts in
+ * MPConv.forward / MPCausal3DGatedConv.forward (edm2/conv.py:37,63).
+ * Descriptor table (device array, built once by the host):                                                     */
+typedef struct OnirisWeightDesc {
+  float* w;        /* fp32 parameter (cout, cin, taps) row-major == the reference (O,I[,kt],kh,kw) tensor        */
+  float* grad;     /* fp32 gradient, same shape; oniris_weight_bwd ACCUMULATES into it                           */
+  void* wf;        /* bf16 packed forward weight  [taps][CoutP][CinP]   (ci contiguous)                          */
+  void* wb;        /* bf16 packed dgrad weight    [taps][CoutPb][CinPb] = flipped/transposed copy (may be NULL)  */
+  float* dwp;      /* fp32 packed weight gradient [taps][CoutP][CinP] written by oniris_conv_wgrad (atomics);    *
+                    * consumed AND re-zeroed by oniris_weight_bwd                                                */
+  int32_t cout, cin, taps, kt;     /* taps = kt*kh*kw (1, 9 or 18); kt = temporal taps (1 or 2)                  */
+  int32_t CoutP, CinP;             /* CoutP = roundup(cout,32), CinP = roundup(cin,64)                           */
+  int32_t CoutPb, CinPb;           /* CoutPb = roundup(cin,32), CinPb = roundup(cout,64)                         */
+  int32_t row_start;               /* prefix sum of cout over the table                                          */
+  int32_t perm3;                   /* 1: attn_qkv rows (m c s) are packed as (s m c) (attention_modules.py:48)   */
+  float gain;                      /* static gain folded into the packed weight                                  */
+  int32_t pad_;
+} OnirisWeightDesc;
+
+int oniris_weight_prep(const OnirisWeightDesc* descs, int ndesc, int total_rows, int training, oniris_stream_t stream);
+int oniris_weight_bwd(const OnirisWeightDesc* descs, int ndesc, int total_rows, oniris_stream_t stream);
+
+/* Fused AdamW over flat fp32 buffers (the optimizer step of gym_train.py:105-106 / cs_train.py:117-118).       */
+int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                 float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Gated causal 3-D convolution as ONE implicit GEMM (MFMA bf16 -> fp32), forward and data-gradient.
+ * Replaces F.conv2d (edm2/conv.py:41,74) + F.conv3d over two previous clean frames (edm2/conv.py:86) + the gated
+ * mp_sum (edm2/conv.py:95) + the cat/stack/rearrange copies (edm2/conv.py:79-91); with taps == 1 it is the 1x1
+ * conv / linear of MPConv.forward (edm2/conv.py:39-41).
+ *   out[n] = coef_own[n] * conv(x[n], w_own) + coef_ctx[n] * sum_j conv(ctxframe(b, t + coff[j]), w_ctx[j])
+ * ctxframe(b,f) = ctx[b*ctx_bstride + f] if 0 <= f < ctx_T else a frame filled with ctx_fill (zero outside the
+ * image).  Forward (train): ctx = x, coff = {-2,-1}, ctx_fill = 1 (edm2/conv.py:68).  Data-gradient: x = dout,
+ * ctx = dy3, coff = {+2,+1}, ctx_fill = 0, packed weights = desc.wb.
+ * Epilogues (fused magnitude-preserving blocks, edm2/networks_edm2.py:73-93):
+ *   ONIRIS_EPI_NONE      out = v
+ *   ONIRIS_EPI_EMB_SILU  out = v ; out2 = silu(v * (1 + emb_gain * escale[n][co])) / 0.596
+ *   ONIRIS_EPI_MPSUM     out = clip( ta * res[n][p][co] + tb * v , +-clip )     (clip <= 0: no clipping)
+ */
+enum { ONIRIS_EPI_NONE = 0, ONIRIS_EPI_EMB_SILU = 1, ONIRIS_EPI_MPSUM = 2 };
+
+typedef struct OnirisConvArgs {
+  const void* x;          /* bf16 [B*S*T][H][W][Cin]                                                              */
+  const void* ctx;        /* bf16 [B*ctx_bstride][H][W][Cin] or NULL (no context path)                            */
+  const void* w_own;      /* bf16 packed [taps][CoutP][CinP]                                                      */
+  const void* w_ctx;      /* bf16 packed [2*taps][CoutP][CinP] or NULL                                            */
+  void* out;              /* bf16 [B*S*T][H][W][Cout]                                                             */
+  const float* coef_own;  /* [B*S*T] or NULL (= 1)                                                                */
+  const float* coef_ctx;  /* [B*S*T] or NULL (= 1)                                                                */
+  int32_t B, S, T, H, W;
+  int32_t Cin, CinP, Cout, CoutP;
+  int32_t taps;           /* 9 (3x3, zero padding 1) or 1                                                         */
+  int32_t ctx_bstride, ctx_T, coff0, coff1;
+  float ctx_fill;
+  int32_t epi;
+  const void* res;        /* bf16 [B*S*T][H][W][Cout]   (EPI_MPSUM)                                               */
+  const void* escale;     /* bf16 [B*S*T][Cout]         (EPI_EMB_SILU): emb_linear(emb)                           */
+  const float* emb_gain;  /* device scalar              (EPI_EMB_SILU)                                            */
+  void* out2;             /* bf16 like out              (EPI_EMB_SILU)                                            */
+  float ta, tb, clip;
+} OnirisConvArgs;
+
+int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);
+
+/* Weight gradient of the same operator (replaces the autograd of F.conv2d / F.conv3d wrt the weight):
+ *   dwp[tap][co][ci] += sum_{n,p} scale[n] * dy[n][p][co] * xframe(n)[p + tap][ci]           (fp32 atomics)
+ * path 0: xframe(n) = x[n] for all B*S*T frames.  path 1+j: frames n = (b,t), xframe = ctxframe(b, t+coff[j]),
+ * dy = dy3 [B*T], accumulated into dwp + (j*taps) slices.                                                        */
+typedef struct OnirisWgradArgs {
+  const void* x;          /* bf16 input frames   [B*xb_stride][H][W][Cin]                                         */
+  const void* dy;         /* bf16 output grads   [B*T][H][W][Cout]                                                */
+  float* dwp;             /* fp32 packed [taps][CoutP][CinP] (pre-zeroed / accumulated)                           */
+  const float* scale;     /* [B*T] or NULL                                                                        */
+  int32_t B, T, H, W, Cin, CinP, Cout, CoutP, taps;
+  int32_t xb_stride, x_T, coff;   /* xframe(b,t) = x[b*xb_stride + t + coff] if 0 <= t+coff < x_T else fill       */
+  float fill;
+} OnirisWgradArgs;
+
+int oniris_conv_wgrad(const OnirisWgradArgs* args /* [host] */, oniris_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * VideoAttention / FrameAttention (edm2/attention/attention_modules.py:30-82, 105-119; RoPe.py:43-68).
+ *
+ * oniris_qkv_norm: splits the 1x1-conv output qkv [N][P][3C] (channel = s*C + head*64 + c, see perm3) into
+ * q,k,v [N][P][C], each normalised per token and head over its 64 channels (normalize(dim=-1),
+ * attention_modules.py:38,49).  oniris_qkv_norm_bwd: the adjoint (dq,dk,dv -> dqkv).
+ * oniris_rope: rotates q (mode 1: * scale) or k (mode 2: / scale) over the FRAME index with host-built fp32
+ * tables cos/sin/scale [n_pos][64] (built from fp16-rounded angles exactly like RoPe.py:21-32), position of
+ * frame f = pos_offset + (f % pos_mod); writes the rotated tensor [B][L][C] and/or the transposed copy
+ * [B][heads][64][L] (the k-contiguous operand layout of the PV / dK / dQ MFMA products).  mode 0: copy only.
+ * mode 3/4: adjoint of mode 1/2 (backward).
+ */
+int oniris_qkv_norm(const void* qkv, void* q, void* k, void* v, int64_t n_tokens, int C, oniris_stream_t stream);
+int oniris_qkv_norm_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv,
+                        int64_t n_tokens, int C, oniris_stream_t stream);
+int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const float* sin_t, const float* scale_t,
+                int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod, oniris_stream_t stream);
+
+/* Block-sparse flash attention forward (replaces compiled_flex_attention / F.scaled_dot_product_attention,
+ * attention_modules.py:41,66,70,75,115).  q [B][Lq][C], k,v [B][Lk][C] bf16 (head h = channels 64h..64h+63),
+ * vt [B][heads][64][Lk].  softmax scale 1/sqrt(64).
+ *   mask_mode 0: dense;  1: frame-causal (key frame <= query frame, frames of P tokens; query frames are the
+ *   LAST Lq/P frames of the key sequence);  2: DART training mask (mask_mod of TrainingMask, T frames per half).
+ *   kv_num/kv_idx: device int32 table of 128-token blocks for one (b,h) ([nrows], [nrows][ncols]); NULL = every
+ *   block (then mask_mode alone decides).  The kernel visits exactly the listed blocks and applies mask_mod per
+ *   element -- the semantics of the compiled FlexAttention kernel.
+ * out [B][Lq][C] bf16, lse [B][heads][Lq] fp32 (log2-domain, for the backward).                                 */
+typedef struct OnirisAttnArgs {
+  const void *q, *k, *v, *qt, *kt, *vt;   /* qt/kt only needed by the backward                                    */
+  void* out;
+  float* lse;
+  const int32_t *kv_num, *kv_idx;         /* forward / dQ table (rows = q blocks)                                 */
+  const int32_t *q_num, *q_idx;           /* transposed table (rows = kv blocks), backward only                   */
+  int32_t tab_cols, qtab_cols;            /* row pitch of kv_idx / q_idx                                          */
+  int32_t B, heads, Lq, Lk, C;
+  int32_t mask_mode, P, T;
+  /* backward */
+  const void *dout, *doutt;               /* bf16 [B][Lq][C], [B][heads][64][Lq]                                  */
+  const float* delta;                     /* [B][heads][Lq]                                                       */
+  void *dq, *dk, *dv;                     /* bf16 [B][L][C]                                                       */
+} OnirisAttnArgs;
+
+int oniris_attn_fwd(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
+/* delta[b][h][q] = sum_c dout*out ; doutt = transposed dout                                                      */
+int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* doutt, int B, int heads, int L, int C,
+                         oniris_stream_t stream);
+int oniris_attn_bwd_dq(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
+int oniris_attn_bwd_dkv(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * RCCL helpers (cs_train.py:53-54,108-114,168): thin wrappers so a non-torch host can drive the same
+ * gradient all-reduce; the Python host uses torch.distributed ("nccl" == RCCL) over the same library.           */
+int oniris_comm_unique_id(void* id128 /* [host] 128 bytes */);
+int oniris_comm_init(void** comm, int rank, int world, const void* id128 /* [host] */);
+int oniris_comm_allreduce_sum_f32(void* comm, float* buf, size_t count, oniris_stream_t stream);
+int oniris_comm_destroy(void* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
