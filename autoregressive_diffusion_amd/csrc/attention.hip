@@ -23,6 +23,7 @@ struct AttnDev {
   OnirisAttnArgs a;
   int pshift;     // log2(P)
   int qf_off;     // (Lk - Lq) / P  (frame offset of the queries inside the key sequence, mask_mode 1)
+  int tshift;     // log2(table block / 128): the BlockMask BLOCK_SIZE is P when P >= 128
 };
 
 // ---- mask_mod on token indices ---------------------------------------------------------------------------------
@@ -131,9 +132,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; }
   float m = NEG_BIG, l = 0.f;
 
-  const int nkv = a.kv_num ? a.kv_num[qb] : (Lk + 127) / 128;
+  const int trow = qb >> d.tshift, tmask = (1 << d.tshift) - 1;
+  const int nkv = a.kv_num ? (a.kv_num[trow] << d.tshift) : (Lk + 127) / 128;
   for (int j = 0; j < nkv; ++j) {
-    const int kb = a.kv_idx ? a.kv_idx[(size_t)qb * a.tab_cols + j] : j;
+    const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
     for (int sub = 0; sub < 2; ++sub) {
       const int key0 = kb * 128 + sub * 64;
       if (key0 >= Lk) break;
@@ -258,9 +260,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
 
-  const int nkv = a.kv_num ? a.kv_num[qb] : (Lk + 127) / 128;
+  const int trow = qb >> d.tshift, tmask = (1 << d.tshift) - 1;
+  const int nkv = a.kv_num ? (a.kv_num[trow] << d.tshift) : (Lk + 127) / 128;
   for (int j = 0; j < nkv; ++j) {
-    const int kb = a.kv_idx ? a.kv_idx[(size_t)qb * a.tab_cols + j] : j;
+    const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
     for (int sub = 0; sub < 2; ++sub) {
       const int key0 = kb * 128 + sub * 64;
       if (key0 >= Lk) break;
@@ -360,9 +363,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
-  const int nq = a.q_num ? a.q_num[kb] : (Lq + 127) / 128;
+  const int trow = kb >> d.tshift, tmask = (1 << d.tshift) - 1;
+  const int nq = a.q_num ? (a.q_num[trow] << d.tshift) : (Lq + 127) / 128;
   for (int j = 0; j < nq; ++j) {
-    const int qblk = a.q_idx ? a.q_idx[(size_t)kb * a.qtab_cols + j] : j;
+    const int qblk = a.q_idx ? ((a.q_idx[(size_t)trow * a.qtab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
     for (int sub = 0; sub < 2; ++sub) {
       const int q0 = qblk * 128 + sub * 64;
       if (q0 >= Lq) break;
@@ -604,7 +608,12 @@ static int attn_prepare(const OnirisAttnArgs* args, AttnDev& d, const char* who)
     oniris_set_error("%s: bad sizes (C must be heads*64)", who); return ONIRIS_EINVAL;
   }
   if (a.Lk % 8 != 0 || a.Lq % 8 != 0) { oniris_set_error("%s: Lq, Lk must be multiples of 8", who); return ONIRIS_EINVAL; }
-  d.pshift = 0; d.qf_off = 0;
+  d.pshift = 0; d.qf_off = 0; d.tshift = 0;
+  if (a.kv_num || a.q_num) {
+    const int tb = a.tab_block > 0 ? a.tab_block : 128;
+    d.tshift = (tb % 128 == 0) ? ilog2_exact(tb / 128) : -1;
+    if (d.tshift < 0) { oniris_set_error("%s: table block %d must be 128 * 2^k", who, tb); return ONIRIS_EUNSUPPORTED; }
+  }
   if (a.mask_mode != 0) {
     d.pshift = ilog2_exact(a.P);
     if (d.pshift < 0) { oniris_set_error("%s: P=%d must be a power of two", who, a.P); return ONIRIS_EUNSUPPORTED; }

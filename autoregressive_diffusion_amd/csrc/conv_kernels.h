@@ -260,6 +260,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) ov[k] = f2bf(v[k]);
         *(bf16x4*)(og + obase + co) = ov;
+        if constexpr (HAS_CTX) {
+          if (a.ctx_out && s == 0) {        // unscaled context product y3 (shared by both slots), kept for d(gate)
+            bf16x4 cv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) cv[k] = f2bf(accc[nt][4 * g + k]);
+            *(bf16x4*)((bf16*)a.ctx_out + ((size_t)b * T * HWp + pix) * a.Cout + co) = cv;
+          }
+        }
         if (a.epi == ONIRIS_EPI_EMB_SILU) {
           const bf16x4 ev = *(const bf16x4*)((const bf16*)a.escale + (size_t)n * a.Cout + co);
           bf16x4 uv;

@@ -109,3 +109,11 @@ extern "C" int oniris_comm_destroy(void* comm) {
   if (comm) ncclCommDestroy((ncclComm_t)comm);
   return ONIRIS_OK;
 }
+
+// sizes of the argument structs, so a binding (ctypes, cgo, JNI ...) can verify its mirror of include/oniris.h
+extern "C" int oniris_struct_sizes(int32_t* out4) {
+  ONIRIS_CHECK_ARG(out4, "struct_sizes: null");
+  out4[0] = (int32_t)sizeof(OnirisWeightDesc); out4[1] = (int32_t)sizeof(OnirisConvArgs);
+  out4[2] = (int32_t)sizeof(OnirisWgradArgs);  out4[3] = (int32_t)sizeof(OnirisAttnArgs);
+  return ONIRIS_OK;
+}

@@ -164,3 +164,60 @@ extern "C" int oniris_adamw(float* p, const float* g, float* m, float* v, size_t
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward pre-pass of the gated conv (one pass over dout): per frame-slot n
+//   S1[n] = sum dout*out, S2[n] = sum dout*y3   (-> d gate),   dy3[b,t] = cb[b,0,t]*dout[b,0,t] + cb[b,1,t]*dout[b,1,t]
+// dout/out [B][S][T][PC], y3/dy3 [B][T][PC].  grid = B*T frames, HBM-bound, 16 B/lane loads.
+__global__ __launch_bounds__(256) void gconv_bwd_prep_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
+                                                             const bf16* __restrict__ y3, const float* __restrict__ cb,
+                                                             float* __restrict__ S1, float* __restrict__ S2,
+                                                             bf16* __restrict__ dy3, int S, int T, size_t PC) {
+  __shared__ float red[16];
+  const int bt = blockIdx.x, b = bt / T, t = bt % T;
+  const bf16* y3f = y3 + (size_t)bt * PC;
+  bf16* dy3f = dy3 + (size_t)bt * PC;
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  float c[2];
+  const bf16* df[2];
+  const bf16* of[2];
+  for (int s = 0; s < S; ++s) {
+    const size_t n = (size_t)(b * S + s) * T + t;
+    c[s] = cb[n]; df[s] = dout + n * PC; of[s] = out + n * PC;
+  }
+  for (size_t e = (size_t)threadIdx.x * 8; e < PC; e += 256 * 8) {
+    const bf16x8 yv = *(const bf16x8*)(y3f + e);
+    float acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const bf16x8 dv = *(const bf16x8*)(df[s] + e);
+      const bf16x8 ov = *(const bf16x8*)(of[s] + e);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float dd = bf2f(dv[i]);
+        s1[s] += dd * bf2f(ov[i]); s2[s] += dd * bf2f(yv[i]); acc[i] += c[s] * dd;
+      }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(acc[i]);
+    *(bf16x8*)(dy3f + e) = o;
+  }
+  for (int s = 0; s < S; ++s) {
+    const float a = block_sum(s1[s], red), bsum = block_sum(s2[s], red);
+    if (threadIdx.x == 0) { const size_t n = (size_t)(b * S + s) * T + t; S1[n] = a; S2[n] = bsum; }
+  }
+}
+
+extern "C" int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_ctx,
+                                     float* S1, float* S2, void* dy3, int B, int S, int T, int64_t frame_elems,
+                                     oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(dout && out && y3 && coef_ctx && S1 && S2 && dy3 && B > 0 && T > 0 && (S == 1 || S == 2) &&
+                   frame_elems > 0 && frame_elems % 8 == 0, "gconv_bwd_prep: bad arguments");
+  hipLaunchKernelGGL(gconv_bwd_prep_kernel, dim3(B * T), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)out,
+                     (const bf16*)y3, coef_ctx, S1, S2, (bf16*)dy3, S, T, (size_t)frame_elems);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}

@@ -1,0 +1,479 @@
+"""Tensor-level wrappers over the C-ABI (include/oniris.h): torch only provides device memory, the current HIP
+stream and autograd bookkeeping.  Activations are channels-last bf16: (N, H, W, C) with N = B*S*T frame-slots.
+
+No CPU / PyTorch fallback exists for these ops: they raise if the tensors are not on a HIP device.
+"""
+import ctypes
+import math
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check
+
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("oniris ops need HIP device tensors (there is no CPU fallback in the product path)")
+
+
+def roundup(a, b):
+    return (a + b - 1) // b * b
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# mask tables (host, int32) -- the reference's make_train_mask / make_infer_mask (attention_masking.py:27-90)
+
+def train_mask_table(n_frames, image_size):
+    """(kv_num_blocks (2nb,), kv_indices (2nb,2nb), block_size) as int32 numpy arrays, or None (reference: None)."""
+    blk = ctypes.c_int(0)
+    n = lib.oniris_train_mask(n_frames, image_size, None, None, ctypes.byref(blk))
+    if n < 0:
+        check(n, "train_mask")
+    if n == 0:
+        return None
+    num = np.zeros(n, dtype=np.int32)
+    idx = np.zeros((n, n), dtype=np.int32)
+    lib.oniris_train_mask(n_frames, image_size, num.ctypes.data_as(ctypes.c_void_p),
+                          idx.ctypes.data_as(ctypes.c_void_p), ctypes.byref(blk))
+    return num, idx, blk.value
+
+
+def infer_mask_table(n_frames, image_size):
+    blk = ctypes.c_int(0)
+    n = lib.oniris_infer_mask(n_frames, image_size, None, None, ctypes.byref(blk))
+    if n < 0:
+        check(n, "infer_mask")
+    if n == 0:
+        return None
+    num = np.zeros(n, dtype=np.int32)
+    idx = np.zeros((n, n), dtype=np.int32)
+    lib.oniris_infer_mask(n_frames, image_size, num.ctypes.data_as(ctypes.c_void_p),
+                          idx.ctypes.data_as(ctypes.c_void_p), ctypes.byref(blk))
+    return num, idx, blk.value
+
+
+def mask_transpose(num, idx):
+    n_rows, n_cols = idx.shape
+    qn = np.zeros(n_cols, dtype=np.int32)
+    qi = np.zeros((n_cols, n_rows), dtype=np.int32)
+    check(lib.oniris_mask_transpose(n_rows, n_cols, num.ctypes.data_as(ctypes.c_void_p),
+                                    idx.ctypes.data_as(ctypes.c_void_p), qn.ctypes.data_as(ctypes.c_void_p),
+                                    qi.ctypes.data_as(ctypes.c_void_p)), "mask_transpose")
+    return qn, qi
+
+
+_table_cache = {}
+
+
+def device_tables(kind, n_frames, image_size, device):
+    """Device copies of the (kv, q) tables for the kernels; cached per (kind, T, P, device)."""
+    key = (kind, n_frames, image_size, str(device))
+    if key not in _table_cache:
+        tab = train_mask_table(n_frames, image_size) if kind == "train" else infer_mask_table(n_frames, image_size)
+        if tab is None:
+            _table_cache[key] = None
+        else:
+            num, idx, _ = tab
+            qn, qi = mask_transpose(num, idx)
+            _table_cache[key] = tuple(torch.from_numpy(a).to(device) for a in (num, idx, qn, qi)) + (tab[2],)
+    return _table_cache[key]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# weight bank: descriptor table + packed buffers for every NormalizedWeight of a model
+
+class PackedWeight:
+    """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
+    __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
+                 "wf", "wb", "dwp")
+
+
+class WeightBank:
+    def __init__(self):
+        self.items = []
+        self._dev_table = None
+        self._sig = None
+        self.total_rows = 0
+
+    def add(self, param, perm3=False, gain=1.0, need_dgrad=True):
+        w = PackedWeight()
+        w.param = param
+        shp = tuple(param.shape)
+        w.cout, w.cin = shp[0], shp[1]
+        w.taps = int(np.prod(shp[2:])) if len(shp) > 2 else 1
+        w.kt = shp[2] if len(shp) == 5 else 1
+        w.CoutP, w.CinP = roundup(w.cout, 32), roundup(w.cin, 64)
+        w.CoutPb, w.CinPb = roundup(w.cin, 32), roundup(w.cout, 64)
+        w.perm3, w.gain = bool(perm3), float(gain)
+        w.wf = w.wb = w.dwp = None
+        self.items.append((w, need_dgrad))
+        return w
+
+    def _signature(self):
+        return tuple((w.param.data_ptr(), w.param.grad.data_ptr() if w.param.grad is not None else 0)
+                     for w, _ in self.items)
+
+    def _build(self, device):
+        descs = (_lib.WeightDesc * len(self.items))()
+        row = 0
+        for i, (w, need_dgrad) in enumerate(self.items):
+            p = w.param
+            if p.dtype != torch.float32 or not p.is_contiguous():
+                raise RuntimeError("weights must be contiguous fp32")
+            if w.wf is None or w.wf.device != p.device:
+                w.wf = torch.zeros(w.taps * w.CoutP * w.CinP, dtype=BF16, device=device)
+                w.wb = torch.zeros(w.taps * w.CoutPb * w.CinPb, dtype=BF16, device=device) if need_dgrad else None
+                w.dwp = torch.zeros(w.taps * w.CoutP * w.CinP, dtype=torch.float32, device=device)
+            if p.requires_grad and p.grad is None:
+                p.grad = torch.zeros_like(p)
+            d = descs[i]
+            d.w = p.data_ptr()
+            d.grad = p.grad.data_ptr() if p.grad is not None else None
+            d.wf = w.wf.data_ptr()
+            d.wb = w.wb.data_ptr() if w.wb is not None else None
+            d.dwp = w.dwp.data_ptr()
+            d.cout, d.cin, d.taps, d.kt = w.cout, w.cin, w.taps, w.kt
+            d.CoutP, d.CinP, d.CoutPb, d.CinPb = w.CoutP, w.CinP, w.CoutPb, w.CinPb
+            d.row_start, d.perm3, d.gain = row, int(w.perm3), w.gain
+            row += w.cout
+        self.total_rows = row
+        raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
+        self._dev_table = torch.from_numpy(raw).to(device)
+        self._sig = self._signature()
+
+    def _ensure(self):
+        device = self.items[0][0].param.device
+        _need_gpu(self.items[0][0].param)
+        for w, _ in self.items:
+            if w.param.requires_grad and w.param.grad is None:
+                self._sig = None
+        if self._dev_table is None or self._sig != self._signature():
+            self._build(device)
+
+    def prepare(self, training):
+        """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
+        self._ensure()
+        check(lib.oniris_weight_prep(_p(self._dev_table), len(self.items), self.total_rows, int(training), _stream()),
+              "weight_prep")
+
+    def backward(self):
+        """Packed fp32 weight gradients (from the wgrad kernels) -> parameter .grad (accumulated); one launch."""
+        self._ensure()
+        check(lib.oniris_weight_bwd(_p(self._dev_table), len(self.items), self.total_rows, _stream()), "weight_bwd")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# convolution
+
+def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP, Cout, CoutP, taps,
+                 ctx_bstride=0, ctx_T=0, coff=(0, 0), ctx_fill=0.0, epi=0, res=None, escale=None, emb_gain=None,
+                 out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None):
+    a = _lib.ConvArgs()
+    a.x, a.ctx, a.w_own, a.w_ctx, a.out = _p(x), _p(ctx), _p(w_own), _p(w_ctx), _p(out)
+    a.coef_own, a.coef_ctx = _p(coef_own), _p(coef_ctx)
+    a.B, a.S, a.T, a.H, a.W = B, S, T, H, W
+    a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = Cin, CinP, Cout, CoutP, taps
+    a.ctx_bstride, a.ctx_T, a.coff0, a.coff1, a.ctx_fill = ctx_bstride, ctx_T, coff[0], coff[1], ctx_fill
+    a.epi, a.res, a.escale, a.emb_gain, a.out2 = epi, _p(res), _p(escale), _p(emb_gain), _p(out2)
+    a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
+    check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
+
+
+def _wgrad_launch(x, dy, dwp, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill):
+    a = _lib.WgradArgs()
+    a.x, a.dy, a.dwp, a.scale = _p(x), _p(dy), _p(dwp), _p(scale)
+    a.B, a.T, a.H, a.W, a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = B, T, H, W, Cin, CinP, Cout, CoutP, taps
+    a.xb_stride, a.x_T, a.coff, a.fill = xb_stride, x_T, coff, fill
+    check(lib.oniris_conv_wgrad(ctypes.byref(a), _stream()), "conv_wgrad")
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = conv(x, W) for a 1x1 / 3x3 MPConv (no context path).  x (N,H,W,Cin) bf16.  The weight gradient is
+    accumulated into the bank's packed fp32 buffer (side effect); WeightBank.backward() finishes it."""
+
+    @staticmethod
+    def forward(ctx, x, pw, epi_res, ta, tb, clip):
+        _need_gpu(x)
+        N, H, W, Cin = x.shape
+        assert Cin == pw.cin or (Cin >= pw.cin and Cin % 8 == 0), (Cin, pw.cin)
+        taps = pw.taps
+        out = torch.empty((N, H, W, pw.cout), dtype=BF16, device=x.device)
+        if epi_res is not None:
+            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, pw.cout, pw.CoutP, taps,
+                         epi=_lib.EPI_MPSUM, res=epi_res, ta=ta, tb=tb, clip=clip)
+        else:
+            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, pw.cout, pw.CoutP, taps)
+        ctx.pw, ctx.scal = pw, (ta, tb, clip, epi_res is not None)
+        ctx.save_for_backward(x, out if (epi_res is not None and clip > 0) else None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out = ctx.saved_tensors
+        pw = ctx.pw
+        ta, tb, clip, has_res = ctx.scal
+        dout = dout.contiguous()
+        dres = None
+        if has_res:
+            if clip > 0:
+                dout = dout * (out.abs() < clip)      # clamp passes the gradient strictly inside the range
+            dres = dout * ta
+            dout = dout * tb
+        N, H, W, Cin = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            _conv_launch(dout, None, pw.wb, None, dx, None, None, 1, 1, N, H, W, pw.cout, pw.CinPb, Cin, pw.CoutPb,
+                         pw.taps)
+        if pw.param.requires_grad:
+            _wgrad_launch(x, dout, pw.dwp, None, 1, N, H, W, Cin, pw.CinP, pw.cout, pw.CoutP, pw.taps, N, N, 0, 0.0)
+        return dx, None, dres, None, None, None
+
+
+def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0):
+    """MPConv forward on packed weights; optional fused epilogue out = clip(ta*res + tb*conv(x))."""
+    return _ConvFn.apply(x, pw, res, ta, tb, clip)
+
+
+class _GatedConvFn(torch.autograd.Function):
+    """Training-mode MPCausal3DGatedConv (edm2/conv.py:59-95) on the DART layout: x (B*2*T,H,W,Cin), slot order
+    (b s t).  out = ca[n]*conv2d(x[n]) + cb[n]*(conv(clean[t-2]) + conv(clean[t-1])), ones-padded in time."""
+
+    @staticmethod
+    def forward(ctx, x, ca, cb, pw2, pw3, B, T, need_grad):
+        _need_gpu(x, ca, cb)
+        N, H, W, Cin = x.shape
+        assert N == B * 2 * T
+        out = torch.empty((N, H, W, pw2.cout), dtype=BF16, device=x.device)
+        y3 = torch.empty((B * T, H, W, pw2.cout), dtype=BF16, device=x.device) if need_grad else None
+        ca32, cb32 = ca.detach().float().contiguous(), cb.detach().float().contiguous()
+        _conv_launch(x, x, pw2.wf, pw3.wf, out, ca32, cb32, B, 2, T, H, W, Cin, pw2.CinP, pw2.cout, pw2.CoutP, 9,
+                     ctx_bstride=2 * T, ctx_T=T, coff=(-2, -1), ctx_fill=1.0, ctx_out=y3)
+        ctx.pws, ctx.dims = (pw2, pw3), (B, T)
+        ctx.save_for_backward(x, out, y3, ca32, cb32)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, out, y3, ca, cb = ctx.saved_tensors
+        pw2, pw3 = ctx.pws
+        B, T = ctx.dims
+        N, H, W, Cin = x.shape
+        Cout = pw2.cout
+        dout = dout.contiguous()
+        dev = x.device
+        S1 = torch.empty(N, dtype=torch.float32, device=dev)
+        S2 = torch.empty(N, dtype=torch.float32, device=dev)
+        dy3 = torch.empty_like(y3)
+        check(lib.oniris_gconv_bwd_prep(_p(dout), _p(out), _p(y3), _p(cb), _p(S1), _p(S2), _p(dy3), B, 2, T,
+                                        H * W * Cout, _stream()), "gconv_bwd_prep")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            sel = torch.zeros(B, 2, T, dtype=torch.float32, device=dev)
+            sel[:, 0] = 1.0                                    # the context gradient only reaches the clean slot
+            _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca, sel.reshape(-1), B, 2, T, H, W, Cout, pw2.CinPb, Cin,
+                         pw2.CoutPb, 9, ctx_bstride=T, ctx_T=T, coff=(2, 1), ctx_fill=0.0)
+        if pw2.param.requires_grad:
+            _wgrad_launch(x, dout, pw2.dwp, ca, 1, N, H, W, Cin, pw2.CinP, Cout, pw2.CoutP, 9, N, N, 0, 0.0)
+        if pw3.param.requires_grad:
+            per = 9 * pw3.CoutP * pw3.CinP
+            for j, coff in enumerate((-2, -1)):
+                _wgrad_launch(x, dy3, pw3.dwp[j * per:], None, B, T, H, W, Cin, pw3.CinP, Cout, pw3.CoutP, 9, 2 * T, T,
+                              coff, 1.0)
+        # out = ca*y2 + cb*y3  ->  d ca = sum(dout*y2) = (S1 - cb*S2)/ca ,  d cb = S2
+        dca = (S1 - cb * S2) / ca
+        return dx, dca, S2, None, None, None, None, None
+
+
+def gated_conv_train(x, gate, pw2, pw3, B, T):
+    """gate: (B*2*T,) fp32 (autograd tensor from Gating).  mp_sum(y2, y3, g) coefficients in torch (tiny)."""
+    den = torch.rsqrt((1 - gate) ** 2 + gate ** 2)
+    return _GatedConvFn.apply(x, (1 - gate) * den, gate * den, pw2, pw3, B, T, torch.is_grad_enabled())
+
+
+@torch.no_grad()
+def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames):
+    """Eval-mode gated conv: x (B*t,H,W,C); ctx_frames (B, t+2, H, W, C) = [2 cached frames, x frames]."""
+    N, H, W, Cin = x.shape
+    out = torch.empty((N, H, W, pw2.cout), dtype=BF16, device=x.device)
+    den = torch.rsqrt((1 - gate) ** 2 + gate ** 2)
+    ca, cb = ((1 - gate) * den).float().contiguous(), (gate * den).float().contiguous()
+    _conv_launch(x, ctx_frames, pw2.wf, pw3.wf, out, ca, cb, B, 1, t, H, W, Cin, pw2.CinP, pw2.cout, pw2.CoutP, 9,
+                 ctx_bstride=t + 2, ctx_T=t + 2, coff=(0, 1), ctx_fill=0.0)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# attention
+
+_rope_cache = {}
+
+
+def rope_tables(inv_freq, scale_vec, n_pos, device, scale_base=64):
+    """fp32 cos/sin/scale tables (n_pos, 64) built from fp16-ROUNDED angles and scales exactly like
+    RotaryEmbedding.make_rotary_embedding (RoPe.py:21-32: the fp16 rounding is part of the numerical spec)."""
+    key = (n_pos, str(device), inv_freq.data_ptr(), scale_vec.data_ptr())
+    if key not in _rope_cache:
+        inv, sv = inv_freq.detach().float().cpu(), scale_vec.detach().float().cpu()
+        t = torch.arange(n_pos, dtype=torch.float32)
+        ang = torch.outer(t, inv)
+        ang = torch.cat([ang, ang], -1).to(torch.float16)
+        power = (t - (n_pos // 2)) / scale_base
+        sc = sv[None, :] ** power[:, None]
+        sc = torch.cat([sc, sc], -1).to(torch.float16)
+        _rope_cache[key] = tuple(z.float().contiguous().to(device) for z in (ang.cos(), ang.sin(), sc))
+    return _rope_cache[key]
+
+
+def _rope(x, xr, xt, tabs, mode, B, frames, P, C, pos_offset, pos_mod):
+    cs, sn, sc = tabs if tabs is not None else (None, None, None)
+    check(lib.oniris_rope(_p(x), _p(xr), _p(xt), _p(cs), _p(sn), _p(sc), mode, B, frames, P, C, pos_offset, pos_mod,
+                          _stream()), "rope")
+
+
+def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mode, P, T):
+    a = _lib.AttnArgs()
+    a.q, a.k, a.v, a.qt, a.kt, a.vt, a.out, a.lse = _p(q), _p(k), _p(v), _p(qt), _p(kt), _p(vt), _p(out), _p(lse)
+    if tabs is not None:
+        num, idx, qn, qi, a.tab_block = tabs
+        a.kv_num, a.kv_idx, a.q_num, a.q_idx = _p(num), _p(idx), _p(qn), _p(qi)
+        a.tab_cols, a.qtab_cols = idx.shape[1], qi.shape[1]
+    a.B, a.heads, a.Lq, a.Lk, a.C = B, heads, Lq, Lk, C
+    a.mask_mode, a.P, a.T = mask_mode, P, T
+    return a
+
+
+class _AttentionFn(torch.autograd.Function):
+    """qkv (N, P, 3C) bf16 (channel = s*C + head*64 + c)  ->  attention output (N, P, C).
+    kind: 'video' (DART training mask + RoPE over frames, B sequences of 2T frames) or 'frame' (dense per frame)."""
+
+    @staticmethod
+    def forward(ctx, qkv, kind, B, T, heads, rope_bufs, need_grad):
+        _need_gpu(qkv)
+        N, P, C3 = qkv.shape
+        C = C3 // 3
+        dev = qkv.device
+        q = torch.empty((N, P, C), dtype=BF16, device=dev)
+        k, v = torch.empty_like(q), torch.empty_like(q)
+        check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, _stream()), "qkv_norm")
+        if kind == "video":
+            frames = N // B
+            Bq, L = B, frames * P
+            tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], T, dev)
+            mask_mode = 2
+            tabs = device_tables("train", T, P, dev)
+            if tabs is None:
+                raise RuntimeError(f"make_train_mask returns None for T={T}, P={P} (T*P must be a multiple of 128)")
+        else:
+            frames, Bq, L = 1, N, P
+            tabs_r, mask_mode, tabs = None, 0, None
+        qt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev) if need_grad else None
+        kt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev) if need_grad else None
+        vt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev)
+        if kind == "video":
+            qr, kr = torch.empty_like(q), torch.empty_like(k)
+            _rope(q, qr, qt, tabs_r, 1, Bq, frames, P, C, 0, T)
+            _rope(k, kr, kt, tabs_r, 2, Bq, frames, P, C, 0, T)
+        else:
+            qr, kr = q, k
+            if need_grad:
+                _rope(q, None, qt, None, 0, Bq, L, 1, C, 0, 1)
+                _rope(k, None, kt, None, 0, Bq, L, 1, C, 0, 1)
+        _rope(v, None, vt, None, 0, Bq, L, 1, C, 0, 1)
+        out = torch.empty((N, P, C), dtype=BF16, device=dev)
+        lse = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
+        a = _attn_args(qr, kr, v, qt, kt, vt, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
+        check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+        ctx.meta = (kind, B, T, heads, Bq, L, frames, P, C, mask_mode)
+        ctx.tabs, ctx.tabs_r = tabs, tabs_r
+        ctx.save_for_backward(qkv, qr, kr, v, qt, kt, vt, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, qr, kr, v, qt, kt, vt, out, lse = ctx.saved_tensors
+        kind, B, T, heads, Bq, L, frames, P, C, mask_mode = ctx.meta
+        dev = qkv.device
+        dout = dout.contiguous()
+        delta = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
+        doutt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev)
+        check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), _p(doutt), Bq, heads, L, C, _stream()),
+              "attn_bwd_prep")
+        dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
+        a = _attn_args(qr, kr, v, qt, kt, vt, out, lse, ctx.tabs, Bq, heads, L, L, C, mask_mode, P, T)
+        a.dout, a.doutt, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(doutt), _p(delta), _p(dq), _p(dk), _p(dv)
+        check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq")
+        check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv")
+        if kind == "video":
+            dqn, dkn = torch.empty_like(dq), torch.empty_like(dk)
+            _rope(dq, dqn, None, ctx.tabs_r, 3, Bq, frames, P, C, 0, T)
+            _rope(dk, dkn, None, ctx.tabs_r, 4, Bq, frames, P, C, 0, T)
+        else:
+            dqn, dkn = dq, dk
+        dqkv = torch.empty_like(qkv)
+        N = qkv.shape[0]
+        check(lib.oniris_qkv_norm_bwd(_p(qkv), _p(dqn), _p(dkn), _p(dv), _p(dqkv), N * P, C, _stream()), "qkv_norm_bwd")
+        return dqkv, None, None, None, None, None, None
+
+
+def attention_train(qkv, kind, B, T, heads, rope_bufs=None):
+    return _AttentionFn.apply(qkv, kind, B, T, heads, rope_bufs, torch.is_grad_enabled())
+
+
+@torch.no_grad()
+def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
+    """Eval-mode VideoAttention core (attention_modules.py:51-77): qkv (B*t, P, 3C) of the NEW frames.
+    kv_cache: (K, V) normalised, un-rotated, (B, t_cached*P, C) or None.  Returns out (B*t,P,C), new cache."""
+    N, P_, C3 = qkv.shape
+    C = C3 // 3
+    dev = qkv.device
+    t = N // B
+    q = torch.empty((N, P, C), dtype=BF16, device=dev)
+    k, v = torch.empty_like(q), torch.empty_like(q)
+    check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, _stream()), "qkv_norm")
+    k, v = k.reshape(B, t * P, C), v.reshape(B, t * P, C)
+    if kv_cache is not None:
+        k = torch.cat([kv_cache[0], k], dim=1)
+        v = torch.cat([kv_cache[1], v], dim=1)
+    new_cache = (k, v) if update_cache else kv_cache
+    nk = k.shape[1] // P
+    Lq, Lk = t * P, nk * P
+    tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], nk, dev)
+    qr, kr = torch.empty_like(q), torch.empty_like(k)
+    vt = torch.empty((B, heads, 64, Lk), dtype=BF16, device=dev)
+    _rope(q, qr, None, tabs_r, 1, B, t, P, C, nk - t, nk)
+    _rope(k, kr, None, tabs_r, 2, B, nk, P, C, 0, nk)
+    _rope(v, None, vt, None, 0, B, Lk, 1, C, 0, 1)
+    out = torch.empty((N, P, C), dtype=BF16, device=dev)
+    if t == 1:
+        mask_mode, tabs = 0, None                               # one new frame: dense SDPA over all keys (:69-70)
+    elif Lq == Lk:
+        mask_mode = 1                                           # causal prefill (:72-75)
+        tabs = device_tables("infer", t, P, dev)
+    else:
+        raise NotImplementedError("The inference mask is not implemented for this case")
+    a = _attn_args(qr, kr, v, None, None, vt, out, None, tabs, B, heads, Lq, Lk, C, mask_mode, P, 0)
+    check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+    return out, new_cache
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# optimizer
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+    _need_gpu(p, g, m, v)
+    check(lib.oniris_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
+                           _stream()), "adamw")

@@ -24,6 +24,8 @@ typedef void* oniris_stream_t;
 
 const char* oniris_last_error(void);
 int oniris_abi_version(void);
+/* sizeof(OnirisWeightDesc, OnirisConvArgs, OnirisWgradArgs, OnirisAttnArgs) for binding self-checks */
+int oniris_struct_sizes(int32_t* out4 /* [host] */);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Mask tables [host, int32] -- bit-exact replacement of make_train_mask / make_infer_mask
@@ -105,6 +107,7 @@ typedef struct OnirisConvArgs {
   const float* emb_gain;  /* device scalar              (EPI_EMB_SILU)                                            */
   void* out2;             /* bf16 like out              (EPI_EMB_SILU)                                            */
   float ta, tb, clip;
+  void* ctx_out;          /* optional bf16 [B*T][H][W][Cout]: the un-gated context product y3 (for d gate)        */
 } OnirisConvArgs;
 
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);
@@ -124,6 +127,12 @@ typedef struct OnirisWgradArgs {
 } OnirisWgradArgs;
 
 int oniris_conv_wgrad(const OnirisWgradArgs* args /* [host] */, oniris_stream_t stream);
+
+/* Backward pre-pass of the gated conv (autograd of edm2/conv.py:90-95): one pass over dout computing, per
+ * frame-slot n, S1[n] = sum(dout*out), S2[n] = sum(dout*y3) (gate gradient) and the context-path gradient
+ * dy3[b,t] = sum_s coef_ctx[b,s,t] * dout[b,s,t].  dout/out bf16 [B][S][T][frame_elems], y3/dy3 [B][T][frame_elems]. */
+int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_ctx, float* S1,
+                          float* S2, void* dy3, int B, int S, int T, int64_t frame_elems, oniris_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * VideoAttention / FrameAttention (edm2/attention/attention_modules.py:30-82, 105-119; RoPe.py:43-68).
@@ -161,6 +170,7 @@ typedef struct OnirisAttnArgs {
   int32_t tab_cols, qtab_cols;            /* row pitch of kv_idx / q_idx                                          */
   int32_t B, heads, Lq, Lk, C;
   int32_t mask_mode, P, T;
+  int32_t tab_block;                      /* tokens per table block (BlockMask BLOCK_SIZE: 128, or P if P >= 128)   */
   /* backward */
   const void *dout, *doutt;               /* bf16 [B][Lq][C], [B][heads][64][Lq]                                  */
   const float* delta;                     /* [B][heads][Lq]                                                       */

@@ -1,0 +1,300 @@
+"""GPU parity of every HIP op (called through the C-ABI wrappers) against the fp32 CPU oracle.
+Tolerance: bf16 operands / fp32 accumulation vs fp32 oracle -> relative L2 <= 1e-2 forward, 2e-2 gradients
+(stated per assert).  Mask tables are bit-exact."""
+import math
+import numpy as np
+import pytest
+import torch
+
+from oracle import oniris_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def nhwc(x):   # (N,C,H,W) fp32 -> (N,H,W,C) bf16 on device
+    return x.permute(0, 2, 3, 1).contiguous().to(DEV, torch.bfloat16)
+
+
+def nchw(x):   # (N,H,W,C) bf16 device -> (N,C,H,W) fp32 cpu
+    return x.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def bfr(x):    # round to bf16 and back (so both paths see identical inputs)
+    return x.to(torch.bfloat16).float()
+
+
+def make_bank(params, **kw):
+    from autoregressive_diffusion_amd import ops
+    bank = ops.WeightBank()
+    pws = [bank.add(p, **kw) for p in params]
+    return bank, pws
+
+
+def test_mask_tables_bit_exact():
+    from autoregressive_diffusion_amd import ops
+    for (T, P) in [(64, 64), (32, 16), (64, 16), (8, 64), (4, 256), (3, 128)]:
+        num, idx, blk = ops.train_mask_table(T, P)
+        rn, ri, rb = O.train_table(T, P)
+        assert np.array_equal(num, rn) and np.array_equal(idx, ri) and blk == rb
+    assert ops.train_mask_table(3, 64) is None
+
+
+@pytest.mark.parametrize("shape", [(24, 16, ()), (40, 24, (1, 1)), (16, 8, (3, 3)), (64, 32, (2, 3, 3))])
+def test_weight_prep_and_bwd(shape):
+    from autoregressive_diffusion_amd import ops
+    cout, cin, k = shape
+    torch.manual_seed(0)
+    w0 = torch.randn(cout, cin, *k) * 1.7
+    p = torch.nn.Parameter(w0.clone().to(DEV))
+    bank, (pw,) = make_bank([p], gain=0.8)
+    bank.prepare(training=True)
+    w_ref = w0.clone().requires_grad_(True)
+    w_eff, w_new = O.weight_effective(w_ref, 0.8, training=True)
+    assert rel(p.data, w_new) < 1e-5, "forced normalisation written back"
+    taps = pw.taps
+    wf = pw.wf.float().cpu().reshape(taps, pw.CoutP, pw.CinP)[:, :cout, :cin]          # [tap][co][ci]
+    ref = w_eff.detach().reshape(cout, cin, taps).permute(2, 0, 1)
+    assert rel(wf, ref) < 5e-3, "packed forward weight"
+    wb = pw.wb.float().cpu().reshape(taps, pw.CoutPb, pw.CinPb)[:, :cin, :cout]        # [tapflip][ci][co]
+    per = taps // pw.kt
+    refb = w_eff.detach().reshape(cout, cin, pw.kt, per).flip(-1).reshape(cout, cin, taps).permute(2, 1, 0)
+    assert rel(wb, refb) < 5e-3, "packed dgrad weight (flipped, transposed)"
+    # backward: random packed gradient
+    G = torch.randn(cout, cin, taps)
+    pw.dwp.zero_()
+    dwp = torch.zeros(taps, pw.CoutP, pw.CinP)
+    dwp[:, :cout, :cin] = G.permute(2, 0, 1)
+    pw.dwp.copy_(dwp.reshape(-1))
+    p.grad.zero_()
+    bank.backward()
+    (w_eff * G.reshape(w_eff.shape)).sum().backward()
+    assert rel(p.grad, w_ref.grad) < 1e-4, "gradient through the normalisation"
+    assert float(pw.dwp.abs().max()) == 0.0, "dwp re-zeroed"
+
+
+def test_weight_perm3():
+    from autoregressive_diffusion_amd import ops
+    C = 64
+    torch.manual_seed(1)
+    w0 = torch.randn(3 * C, C, 1, 1)
+    p = torch.nn.Parameter(w0.clone().to(DEV))
+    bank, (pw,) = make_bank([p], perm3=True)
+    bank.prepare(training=False)
+    w_eff, _ = O.weight_effective(w0, 1.0, training=False)
+    wf = pw.wf.float().cpu().reshape(pw.CoutP, pw.CinP)[:3 * C, :C]
+    ref = w_eff.reshape(C, 3, C).permute(1, 0, 2).reshape(3 * C, C)      # rows (m c s) -> (s m c)
+    assert rel(wf, ref) < 5e-3
+
+
+@pytest.mark.parametrize("N,H,cin,cout,k", [(6, 16, 32, 64, 3), (5, 8, 96, 32, 3), (16, 4, 64, 64, 3), (3, 32, 16, 40, 3),
+                                            (7, 8, 64, 192, 1), (3, 16, 48, 32, 1), (130, 1, 64, 96, 1)])
+def test_conv_plain(N, H, cin, cout, k):
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(2)
+    kk = (k, k) if k == 3 else ((1, 1) if H > 1 else ())
+    w0 = O.normalize(O.normalize(torch.randn(cout, cin, *kk)))
+    p = torch.nn.Parameter(w0.clone().to(DEV))
+    bank, (pw,) = make_bank([p])
+    bank.prepare(training=True)
+    x0 = bfr(torch.randn(N, cin, H, H))
+    x = nhwc(x0).requires_grad_(True)
+    y = ops.conv(x, pw)
+    gy0 = bfr(torch.randn(N, cout, H, H))
+    y.backward(nhwc(gy0))
+    bank.backward()
+    wr = w0.clone().requires_grad_(True)
+    xr = x0.clone().requires_grad_(True)
+    w_eff, _ = O.weight_effective(wr, 1.0, training=True)
+    yr = torch.nn.functional.conv2d(xr, w_eff.reshape(cout, cin, k, k), padding=k // 2)
+    (yr * gy0).sum().backward()
+    e = (rel(nchw(y), yr), rel(nchw(x.grad), xr.grad), rel(p.grad, wr.grad))
+    print("conv_plain", (N, H, cin, cout, k), "rel err y/dx/dw", e)
+    assert e[0] < 1e-2 and e[1] < 1e-2 and e[2] < 2e-2
+
+
+@pytest.mark.parametrize("B,T,H,cin,cout", [(2, 4, 8, 32, 32), (1, 2, 16, 64, 64), (1, 8, 4, 32, 64), (2, 3, 8, 96, 32),
+                                            (1, 2, 32, 16, 32)])
+def test_gated_conv_train(B, T, H, cin, cout):
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(3)
+    w2 = O.normalize(O.normalize(torch.randn(cout, cin, 3, 3)))
+    w3 = O.normalize(O.normalize(torch.randn(cout, cin, 2, 3, 3)))
+    p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=True)
+    N = B * 2 * T
+    x0 = bfr(torch.randn(N, cin, H, H))
+    g0 = torch.rand(N) * 0.6 + 0.05
+    gy0 = bfr(torch.randn(N, cout, H, H))
+    x = nhwc(x0).requires_grad_(True)
+    g = g0.clone().to(DEV).requires_grad_(True)
+    y = ops.gated_conv_train(x, g, pw2, pw3, B, T)
+    y.backward(nhwc(gy0))
+    bank.backward()
+    # oracle (fused algebraic form, fp32)
+    xr, gr = x0.clone().requires_grad_(True), g0.clone().requires_grad_(True)
+    w2r, w3r = w2.clone().requires_grad_(True), w3.clone().requires_grad_(True)
+    e2, _ = O.weight_effective(w2r, 1.0, True)
+    e3, _ = O.weight_effective(w3r, 1.0, True)
+    F = torch.nn.functional
+    y2 = F.conv2d(xr, e2, padding=1)
+    clean = xr.reshape(B, 2, T, cin, H, H)[:, 0]
+    ctx = torch.cat([torch.ones(B, 2, cin, H, H), clean], 1)
+    y3 = F.conv2d(ctx[:, 0:T].reshape(B * T, cin, H, H), e3[:, :, 0], padding=1) + \
+        F.conv2d(ctx[:, 1:T + 1].reshape(B * T, cin, H, H), e3[:, :, 1], padding=1)
+    y3 = y3.reshape(B, 1, T, cout, H, H).expand(B, 2, T, cout, H, H).reshape(N, cout, H, H)
+    yr = O.mp_sum(y2, y3, gr)
+    (yr * gy0).sum().backward()
+    e = dict(y=rel(nchw(y), yr), dx=rel(nchw(x.grad), xr.grad), dw2=rel(p2.grad, w2r.grad), dw3=rel(p3.grad, w3r.grad),
+             dg=rel(g.grad, gr.grad))
+    print("gated_conv", (B, T, H, cin, cout), e)
+    assert e["y"] < 1e-2 and e["dx"] < 1e-2 and e["dw2"] < 2e-2 and e["dw3"] < 2e-2 and e["dg"] < 3e-2
+
+
+def test_gated_conv_eval_matches_oracle():
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(4)
+    B, t, H, cin, cout = 2, 3, 8, 32, 32
+    w2 = torch.randn(cout, cin, 3, 3)
+    w3 = torch.randn(cout, cin, 2, 3, 3)
+    p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=False)
+    x0 = bfr(torch.randn(B * t, cin, H, H))
+    cache0 = bfr(torch.randn(B, cin, 2, H, H))
+    g0 = torch.rand(B * t) * 0.6 + 0.05
+    x = nhwc(x0)
+    ctxf = torch.cat([cache0.permute(0, 2, 3, 4, 1).to(DEV, torch.bfloat16), x.reshape(B, t, H, H, cin)], 1).contiguous()
+    y = ops.gated_conv_eval(x, g0.to(DEV), pw2, pw3, B, t, ctxf)
+    e2, _ = O.weight_effective(w2, 1.0, False)
+    e3, _ = O.weight_effective(w3, 1.0, False)
+    F = torch.nn.functional
+    ctx = torch.cat([cache0.permute(0, 2, 1, 3, 4), x0.reshape(B, t, cin, H, H)], 1)
+    y3 = F.conv2d(ctx[:, 0:t].reshape(B * t, cin, H, H), e3[:, :, 0], padding=1) + \
+        F.conv2d(ctx[:, 1:t + 1].reshape(B * t, cin, H, H), e3[:, :, 1], padding=1)
+    yr = O.mp_sum(F.conv2d(x0, e2, padding=1), y3, g0)
+    e = rel(nchw(y), yr)
+    print("gated_conv_eval", e)
+    assert e < 1e-2
+
+
+def _attn_ref(x0, wq, wp, B, m, training, just_2d=False, rope=True):
+    p = {"a.attn_qkv.weight.weight": wq, "a.attn_proj.weight.weight": wp,
+         "a.rope.inv_freq": 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)),
+         "a.rope.scale": (torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)}
+    return p
+
+
+@pytest.mark.parametrize("B,T,H,m", [(2, 4, 8, 1), (1, 8, 4, 2), (1, 2, 16, 1), (1, 16, 8, 2)])
+def test_video_attention_core_train(B, T, H, m):
+    """qkv -> attention output (the part between the qkv conv and the proj conv), forward + backward."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(5)
+    C, P, N = 64 * m, H * H, B * 2 * T
+    qkv0 = bfr(torch.randn(N, 3 * C, H, H))            # reference channel order (m c s)
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    sc = (torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)
+    go0 = bfr(torch.randn(N, C, H, H))
+    # oracle
+    qr_in = qkv0.clone().requires_grad_(True)
+    q, k, v = O._split_qkv(qr_in, m)
+    q, k, v = (z.reshape(B, 2 * T, m, P, 64).permute(0, 2, 1, 3, 4) for z in (q, k, v))
+    q, k = O.rope_apply(q, k, inv, sc, True)
+    q, k, v = (z.reshape(B, m, -1, 64) for z in (q, k, v))
+    allowed = torch.from_numpy(O.train_allowed_tokens(T, P))
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
+    o = o.reshape(B, m, 2 * T, P, 64).permute(0, 2, 1, 4, 3).reshape(N, C, H, H)
+    (o * go0).sum().backward()
+    # HIP: channel order (s m c)
+    perm = qkv0.reshape(N, m * 64, 3, H, H).permute(0, 2, 1, 3, 4).reshape(N, 3 * C, H, H)
+    x = nhwc(perm).reshape(N, P, 3 * C).requires_grad_(True)
+    out = ops.attention_train(x, "video", B, T, m, (inv.to(DEV), sc.to(DEV)))
+    out.backward(nhwc(go0).reshape(N, P, C))
+    dqkv = x.grad.reshape(N, H, H, 3, m * 64).permute(0, 4, 3, 1, 2).reshape(N, 3 * C, H, H).float().cpu()
+    e = (rel(nchw(out.reshape(N, H, H, C)), o), rel(dqkv, qr_in.grad))
+    print("video_attention", (B, T, H, m), "rel err out/dqkv", e)
+    assert e[0] < 1e-2 and e[1] < 2.5e-2
+
+
+def test_frame_attention_core_train():
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(6)
+    N, H, m = 5, 16, 2
+    C, P = 64 * m, H * H
+    qkv0 = bfr(torch.randn(N, 3 * C, H, H))
+    go0 = bfr(torch.randn(N, C, H, H))
+    qr_in = qkv0.clone().requires_grad_(True)
+    q, k, v = O._split_qkv(qr_in, m)
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 1, 3, 2).reshape(N, C, H, H)
+    (o * go0).sum().backward()
+    perm = qkv0.reshape(N, m * 64, 3, H, H).permute(0, 2, 1, 3, 4).reshape(N, 3 * C, H, H)
+    x = nhwc(perm).reshape(N, P, 3 * C).requires_grad_(True)
+    out = ops.attention_train(x, "frame", N, 1, m)
+    out.backward(nhwc(go0).reshape(N, P, C))
+    dqkv = x.grad.reshape(N, H, H, 3, m * 64).permute(0, 4, 3, 1, 2).reshape(N, 3 * C, H, H).float().cpu()
+    e = (rel(nchw(out.reshape(N, H, H, C)), o), rel(dqkv, qr_in.grad))
+    print("frame_attention rel err out/dqkv", e)
+    assert e[0] < 1e-2 and e[1] < 2.5e-2
+
+
+def test_attention_eval_prefill_and_decode():
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(7)
+    B, H, m = 2, 8, 1
+    C, P = 64 * m, H * H
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    sc = (torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)
+    rb = (inv.to(DEV), sc.to(DEV))
+
+    def hip(qkv0, t, cache, upd):
+        N = B * t
+        perm = qkv0.reshape(N, m * 64, 3, H, H).permute(0, 2, 1, 3, 4).reshape(N, 3 * C, H, H)
+        out, cache = ops.attention_eval(nhwc(perm).reshape(N, P, 3 * C), B, m, rb, cache, upd, P)
+        return nchw(out.reshape(N, H, H, C)), cache
+
+    def ref(qkv0, t, cache, upd):
+        q, k, v = O._split_qkv(qkv0, m)
+        q, k, v = (z.reshape(B, t, m, P, 64).permute(0, 2, 1, 3, 4) for z in (q, k, v))
+        if cache is not None:
+            k, v = torch.cat([cache[0], k], 2), torch.cat([cache[1], v], 2)
+        if upd:
+            cache = (k, v)
+        nk = k.shape[2]
+        q, k = O.rope_apply(q, k, inv, sc, False)
+        q, k, v = (z.reshape(B, m, -1, 64) for z in (q, k, v))
+        allowed = None if t == 1 else torch.from_numpy(O.infer_allowed_tokens(t, P))
+        o = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
+        return o.reshape(B, m, t, P, 64).permute(0, 2, 1, 4, 3).reshape(B * t, C, H, H), cache
+
+    for t0 in (4, 5, 1):      # table path, dense-fallback path (t*P % 128 != 0), score_mod path
+        a0 = bfr(torch.randn(B * t0, 3 * C, H, H))
+        o1, c1 = hip(a0, t0, None, True)
+        r1, rc1 = ref(a0, t0, None, True)
+        a1 = bfr(torch.randn(B, 3 * C, H, H))
+        o2, c2 = hip(a1, 1, c1, True)
+        r2, rc2 = ref(a1, 1, rc1, True)
+        e = (rel(o1, r1), rel(o2, r2))
+        print("attention_eval t0 =", t0, e)
+        assert e[0] < 1e-2 and e[1] < 1e-2
+        assert c2[0].shape[1] == (t0 + 1) * P
+
+
+def test_adamw():
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(8)
+    n = 100003
+    p0, g0 = torch.randn(n), torch.randn(n)
+    pr = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([pr], lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.01)
+    p, m, v = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in (1, 2, 3):
+        pr.grad = g0 * step
+        opt.step()
+        ops.adamw_(p, (g0 * step).to(DEV), m, v, 1e-2, 0.9, 0.99, 1e-8, 0.01, step)
+    assert rel(p, pr.data) < 1e-5
