@@ -6,6 +6,8 @@ this module raises.  Build it with `make -j8` at the repo root (or `python -c "i
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- MUST come first: binds liboniris_hip.so to the HIP/RCCL runtime torch already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liboniris_hip.so")
 

@@ -1,0 +1,80 @@
+"""VideoAttention / FrameAttention with the reference's signatures (edm2/attention/attention_modules.py:15-119).
+qkv 1x1 conv -> per-head pixel norm -> RoPE over the frame index -> block-sparse DART attention (train) /
+causal prefill / KV-cached decode (eval) -> proj 1x1 conv fused with mp_sum(x, y, attn_balance)."""
+import math
+import torch
+from torch import nn
+
+from ... import ops
+from ..conv import MPConv, weights_ready
+from ..utils import to_cl, from_cl
+from .RoPe import RotaryEmbedding
+
+
+class _AttentionBase(nn.Module):
+    def __init__(self, channels, num_heads, attn_balance=0.3):
+        super().__init__()
+        self.channels, self.num_heads, self.attn_balance = channels, num_heads, attn_balance
+        if num_heads == 0:
+            return
+        self.attn_qkv = MPConv(channels, channels * 3, kernel=[1, 1])
+        self.attn_qkv.weight.perm3 = True          # packed rows (m c s) -> (s m c): q | k | v contiguous
+        self.attn_proj = MPConv(channels, channels, kernel=[1, 1])
+
+    def _proj(self, x, o, clip):
+        t = self.attn_balance
+        den = 1.0 / math.sqrt((1 - t) ** 2 + t ** 2)
+        # proj conv with fused epilogue  out = clip((1-t)/den' * x + t/den' * conv(o))
+        return self.attn_proj._cl(o, res=x, ta=(1 - t) * den, tb=t * den, clip=clip)
+
+    def _frame_cl(self, x, clip):
+        N, H, W, C = x.shape
+        qkv = self.attn_qkv._cl(x).reshape(N, H * W, 3 * C)
+        o = ops.attention_train(qkv, "frame", N, 1, self.num_heads)
+        return self._proj(x, o.reshape(N, H, W, C), clip)
+
+
+class VideoAttention(_AttentionBase):
+    def __init__(self, channels, num_heads, attn_balance=0.3):
+        super().__init__(channels, num_heads, attn_balance)
+        if num_heads == 0:
+            return
+        self.rope = RotaryEmbedding(channels // num_heads)
+        self.train_mask = None
+
+    def _cl(self, x, batch_size, cache=None, update_cache=False, just_2d=False, clip=0.0):
+        """x (B*t, H, W, C) bf16 -> (mp_sum(x, attention(x)) [clipped], cache)."""
+        if self.num_heads == 0:
+            return (x.clamp(-clip, clip) if clip > 0 else x), None
+        if just_2d:
+            return self._frame_cl(x, clip), cache
+        N, H, W, C = x.shape
+        P = H * W
+        qkv = self.attn_qkv._cl(x).reshape(N, P, 3 * C)
+        rope_bufs = (self.rope.inv_freq, self.rope.scale)
+        if self.training:
+            T = N // (2 * batch_size)
+            o = ops.attention_train(qkv, "video", batch_size, T, self.num_heads, rope_bufs)
+        else:
+            o, cache = ops.attention_eval(qkv, batch_size, self.num_heads, rope_bufs, cache, update_cache, P)
+        return self._proj(x, o.reshape(N, H, W, C), clip), cache
+
+    def forward(self, x, batch_size, cache=None, update_cache=False, just_2d=False):
+        if self.num_heads == 0:
+            return x, None
+        with weights_ready(self):
+            y, cache = self._cl(to_cl(x), batch_size, cache, update_cache, just_2d)
+            return from_cl(y, x.dtype), cache
+
+
+class FrameAttention(_AttentionBase):
+    def _cl(self, x, batch_size=None, cache=None, update_cache=False, just_2d=True, clip=0.0):
+        if self.num_heads == 0:
+            return (x.clamp(-clip, clip) if clip > 0 else x), None
+        return self._frame_cl(x, clip), None
+
+    def forward(self, x, batch_size=None, cache=None, update_cache=False, just_2d=True):
+        if self.num_heads == 0:
+            return x, None
+        with weights_ready(self):
+            return from_cl(self._frame_cl(to_cl(x), 0.0), x.dtype), None

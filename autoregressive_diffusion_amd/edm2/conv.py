@@ -1,0 +1,150 @@
+"""MPConv / MPCausal3DGatedConv / Gating / NormalizedWeight with the reference's module tree, parameter names and
+call signatures (edm2/conv.py:8-127), computing through the HIP implicit-GEMM kernels.
+
+Public `forward`s take/return NCHW tensors like the reference; `_cl` variants work on channels-last bf16 and are
+what UNet uses internally.  Weights are normalised + packed ONCE per top-level forward by the WeightBank of the
+outermost module (see `weights_ready`)."""
+import threading
+import torch
+from torch import nn
+
+from .. import ops
+from .utils import to_cl, from_cl, BF16
+
+_tls = threading.local()
+
+
+def _bank_of(root):
+    bank = root.__dict__.get("_oniris_bank")
+    mods = [m for m in root.modules() if isinstance(m, NormalizedWeight)]
+    if bank is None or bank._n_mods != len(mods) or any(m.pw is None or m.pw.param is not m.weight for m in mods):
+        bank = ops.WeightBank()
+        for m in mods:
+            m.pw = bank.add(m.weight, perm3=m.perm3)
+            m.pw.bank = bank
+        bank._n_mods = len(mods)
+        root.__dict__["_oniris_bank"] = bank
+    return bank
+
+
+class weights_ready:
+    """Context manager: the OUTERMOST module forward normalises+packs all of its weights (one kernel launch);
+    nested forwards reuse them.  Mirrors 'NormalizedWeight.forward runs on every use' (conv.py:14-21) at the
+    granularity the fixed point of the forced normalisation allows (once per step)."""
+
+    def __init__(self, module):
+        self.module = module
+
+    def __enter__(self):
+        depth = getattr(_tls, "depth", 0)
+        if depth == 0:
+            _bank_of(self.module).prepare(self.module.training)
+        _tls.depth = depth + 1
+
+    def __exit__(self, *exc):
+        _tls.depth -= 1
+        return False
+
+
+class NormalizedWeight(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels, *kernel))
+        self.perm3 = False
+        self.pw = None
+
+
+class MPConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel, dilation=1):
+        super().__init__()
+        self.out_channels = out_channels
+        self.weight = NormalizedWeight(in_channels, out_channels, kernel)
+        assert dilation == 1
+
+    def _cl(self, x, res=None, ta=0.0, tb=0.0, clip=0.0):
+        return ops.conv(x, self.weight.pw, res, ta, tb, clip)
+
+    def forward(self, x, gain=1):
+        with weights_ready(self):
+            if x.ndim == 2:                                     # linear (conv.py:38-39)
+                pad = (-x.shape[1]) % 8
+                xin = torch.nn.functional.pad(x, (0, pad)).to(BF16)[:, None, None, :].contiguous()
+                y = self._cl(xin)[:, 0, 0, :].to(x.dtype)
+            else:
+                y = from_cl(self._cl(to_cl(x, pad_to=-(-x.shape[1] // 8) * 8)), x.dtype)
+            return y * gain
+
+    @torch.no_grad()
+    def load_from_2d(self, state_dict):
+        self.weight.weight.copy_(state_dict)
+
+
+class Gating(nn.Module):
+    """edm2/conv.py:104-127 (tiny, fp32, stays in torch autograd)."""
+
+    def __init__(self):
+        super().__init__()
+        self.offset = nn.Parameter(torch.tensor([0., 0.]))
+        self.mult = nn.Parameter(torch.tensor([1.5, -0.5]))
+        self.max_gating = nn.Parameter(torch.tensor(-5.))
+        self.min_gating = nn.Parameter(torch.tensor(-5.))
+
+    def forward(self, c_noise, n_context_frames=0, just_2d=False):
+        B, tt = c_noise.shape
+        T = tt // 2 if self.training else tt
+        if just_2d:
+            pos = torch.zeros_like(c_noise)
+        else:
+            pos = (torch.arange(B * tt, device=c_noise.device) % T).reshape(B, tt) + n_context_frames
+            pos = pos.to(c_noise.dtype).log1p()
+        sv = c_noise * self.mult[0] + self.offset[0] + pos * self.mult[1] + self.offset[1]
+        lo, hi = torch.sigmoid(self.min_gating), torch.sigmoid(self.max_gating)
+        return lo + (1 - lo) * hi * torch.sigmoid(sv), n_context_frames + T
+
+
+class MPCausal3DGatedConv(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel):
+        super().__init__()
+        assert len(kernel) == 3
+        self.out_channels = out_channels
+        self.in_channels = in_channels
+        self.last_frame_conv = MPConv(in_channels, out_channels, kernel[1:])
+        self.weight = NormalizedWeight(in_channels, out_channels, (kernel[0] - 1, kernel[1], kernel[2]))
+        self.gating = Gating()
+
+    def _cl(self, x, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
+        """x (B*t, H, W, C) bf16 -> (y, cache).  cache['activations'] is (B, 2, H, W, C) bf16."""
+        if just_2d:
+            return self.last_frame_conv._cl(x), cache
+        if cache is None:
+            cache = {}
+        gate, n_new = self.gating(c_noise.float(), cache.get("n_context_frames", 0))
+        if update_cache:
+            cache["n_context_frames"] = n_new
+        N, H, W, C = x.shape
+        pw2, pw3 = self.last_frame_conv.weight.pw, self.weight.pw
+        if self.training:
+            T = N // (2 * batch_size)
+            return ops.gated_conv_train(x, gate.reshape(-1), pw2, pw3, batch_size, T), cache
+        t = N // batch_size
+        pad = cache.get("activations")
+        if pad is None:
+            pad = torch.ones(batch_size, 2, H, W, C, dtype=BF16, device=x.device)
+        ctx = torch.cat([pad, x.reshape(batch_size, t, H, W, C)], dim=1).contiguous()
+        if update_cache:
+            cache["activations"] = ctx[:, -2:].clone()
+        return ops.gated_conv_eval(x, gate.reshape(-1), pw2, pw3, batch_size, t, ctx), cache
+
+    def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
+        with weights_ready(self):
+            cl = to_cl(x, pad_to=-(-x.shape[1] // 8) * 8)
+            if cache is not None and "activations" in cache and cache["activations"].shape[-1] != cl.shape[-1]:
+                raise ValueError("cache does not belong to this layer")
+            y, cache = self._cl(cl, batch_size, c_noise, cache, update_cache, just_2d)
+            return from_cl(y, x.dtype), cache
+
+    @torch.no_grad()
+    def load_from_2d(self, weight):
+        if isinstance(weight, dict):
+            weight = weight["weight"]
+        self.last_frame_conv.load_from_2d(weight)

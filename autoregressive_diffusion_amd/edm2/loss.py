@@ -1,0 +1,47 @@
+"""EDM2 loss with DART duplication (reference edm2/loss.py:9-69): builds x = cat(images, images) + sigma*eps,
+calls net(x, sigma, conditioning, just_2d=...), weights the per-frame MSE of the noised half by lambda(sigma) and
+divides by the fitted mean loss."""
+import numpy as np
+import torch
+
+
+class EDM2Loss:
+    def __init__(self, P_mean=0.5, P_std=2., sigma_data=1., context_noise_reduction=0.1):
+        assert 0 <= context_noise_reduction <= 1
+        self.P_mean, self.P_std, self.sigma_data = P_mean, P_std, sigma_data
+        self.context_noise_reduction = context_noise_reduction
+
+    def __call__(self, net, images, conditioning=None, sigma=None, just_2d=False, noise=None, sync=True):
+        """`noise` (optional): the standard-normal draw to use (fixtures); `sync=False` skips the host round trips
+        (returns the un-weighted loss as a device tensor and does not log to net.noise_weight)."""
+        B, T = images.shape[:2]
+        assert net.training, "The model should be in training mode"
+        cat_images = images if just_2d else torch.cat((images, images), dim=1)
+        if conditioning is not None and not just_2d:
+            conditioning = torch.cat((conditioning, conditioning), dim=1)
+        if sigma is None:
+            sigma = (torch.randn(B, T, device=images.device) * self.P_std + self.P_mean).exp()
+            if not just_2d:
+                ctx = torch.rand(B, 1, device=images.device).expand(-1, T) * self.context_noise_reduction
+                sigma = torch.cat((ctx, sigma), dim=1)
+        if noise is None:
+            noise = torch.randn_like(cat_images)
+        out, _ = net(cat_images + sigma[:, :, None, None, None] * noise, sigma, conditioning, just_2d=just_2d)
+        losses = ((out[:, -T:] - images) ** 2).mean(dim=(-1, -2, -3))
+        sg = sigma[:, -T:]
+        losses = losses * (sg ** 2 + self.sigma_data ** 2) / (sg * self.sigma_data) ** 2
+        unweighted = losses.mean().detach()
+        if sync:
+            unweighted = unweighted.cpu().item()
+            net.noise_weight.add_data(sg, losses)
+        mean_loss = net.noise_weight.calculate_mean_loss(sg)
+        return (losses / mean_loss).mean(), unweighted
+
+
+def learning_rate_schedule(current_step, ref_lr=1e-2, ref_step=7e4, rampup_steps=1e3):
+    lr = ref_lr
+    if ref_step > 0:
+        lr /= np.sqrt(max(current_step / ref_step, 1))
+    if rampup_steps > 0:
+        lr *= min(current_step / rampup_steps, 1)
+    return lr

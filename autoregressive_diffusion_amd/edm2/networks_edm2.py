@@ -1,0 +1,187 @@
+"""Block / UNet / Precond with the reference's constructor arguments, forward signatures, module tree and
+state_dict keys (edm2/networks_edm2.py:19-297), running on the MI355X kernels: activations stay channels-last
+bf16 between layers, every conv / attention is a HIP kernel behind the C-ABI, weights are normalised and packed
+once per forward."""
+import inspect
+import math
+from contextlib import nullcontext
+import torch
+from torch import nn
+import torch.nn.functional as F
+
+from .loss_weight import MultiNoiseLoss
+from .utils import (BetterModule, MPFourier, mp_silu, mp_sum, mp_cat_cl, normalize_cl, resample_cl, to_cl, from_cl, BF16)
+from .conv import MPConv, MPCausal3DGatedConv, Gating, weights_ready
+from .attention import FrameAttention, VideoAttention
+
+
+class Block(nn.Module):
+    def __init__(self, in_channels, out_channels, emb_channels, flavor="enc", resample_mode="keep",
+                 resample_filter=[1, 1], attention=False, channels_per_head=64, dropout=0, res_balance=0.3,
+                 attn_balance=0.3, clip_act=256):
+        super().__init__()
+        assert list(resample_filter) == [1, 1], "only the [1,1] resampling filter of the reference configs"
+        self.out_channels, self.in_channels = out_channels, in_channels
+        self.flavor, self.resample_filter, self.resample_mode = flavor, resample_filter, resample_mode
+        self.num_heads = out_channels // channels_per_head if attention else 0
+        self.dropout, self.res_balance, self.attn_balance, self.clip_act = dropout, res_balance, attn_balance, clip_act
+        self.emb_gain = nn.Parameter(torch.zeros([]))
+        self.emb_linear = MPConv(emb_channels, out_channels, kernel=[])
+        self.conv_res0 = MPCausal3DGatedConv(out_channels if flavor == "enc" else in_channels, out_channels, [3, 3, 3])
+        self.conv_res1 = MPCausal3DGatedConv(out_channels, out_channels, [3, 3, 3])
+        self.conv_skip = MPConv(in_channels, out_channels, kernel=[1, 1]) if in_channels != out_channels else None
+        if attention == "video":
+            self.attn = VideoAttention(out_channels, self.num_heads, attn_balance)
+        else:
+            self.attn = FrameAttention(out_channels, self.num_heads, attn_balance)
+
+    def _cl(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
+        """x (N,H,W,C) bf16, emb (N,1,1,cemb) bf16."""
+        if cache is None:
+            cache = {}
+        x = resample_cl(x, self.resample_mode)
+        if self.flavor == "enc":
+            if self.conv_skip is not None:
+                x = self.conv_skip._cl(x)
+            x = normalize_cl(x)
+        y, cache["conv_res0"] = self.conv_res0._cl(mp_silu(x), batch_size, c_noise, cache.get("conv_res0"),
+                                                   update_cache, just_2d)
+        c = self.emb_linear._cl(emb) * self.emb_gain.to(BF16) + 1            # (N,1,1,Cout)
+        y = mp_silu(y * c)
+        if self.training and self.dropout != 0:
+            y = F.dropout(y, p=self.dropout)
+        y, cache["conv_res1"] = self.conv_res1._cl(y, batch_size, c_noise, cache.get("conv_res1"), update_cache, just_2d)
+        if self.flavor == "dec" and self.conv_skip is not None:
+            x = self.conv_skip._cl(x)
+        x = mp_sum(x, y, self.res_balance)
+        clip = float(self.clip_act) if self.clip_act is not None else 0.0
+        x, cache["attn"] = self.attn._cl(x, batch_size, cache.get("attn"), update_cache, just_2d, clip=clip)
+        return x, cache
+
+    def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
+        with weights_ready(self):
+            pad = (-emb.shape[1]) % 8
+            e = F.pad(emb, (0, pad)).to(BF16)[:, None, None, :].contiguous()
+            y, cache = self._cl(to_cl(x), e, batch_size, c_noise, cache, update_cache, just_2d)
+            return from_cl(y, x.dtype), cache
+
+
+class UNet(BetterModule):
+    def __init__(self, img_resolution, img_channels, label_dim, model_channels, channel_mult=[1, 2, 2, 4],
+                 channel_mult_noise=None, channel_mult_emb=None, num_blocks=3, video_attn_resolutions=[8],
+                 frame_attn_resolutions=[16], label_balance=0.5, concat_balance=0.5, **block_kwargs):
+        super().__init__()
+        self.img_resolution, self.img_channels, self.label_dim = img_resolution, img_channels, label_dim
+        cblock = [model_channels * x for x in channel_mult]
+        cnoise = model_channels * channel_mult_noise if channel_mult_noise is not None else cblock[0]
+        cemb = model_channels * channel_mult_emb if channel_mult_emb is not None else max(cblock)
+        self.label_balance, self.concat_balance = label_balance, concat_balance
+        self.out_res = Gating()
+        self.out_gain = nn.Parameter(torch.zeros([]))
+        self.emb_fourier_sigma = MPFourier(cnoise)
+        self.emb_noise = MPConv(cnoise, cemb, kernel=[])
+        self.emb_fourier_time = MPFourier(cnoise)
+        self.emb_time = MPConv(cnoise, cemb, kernel=[])
+        self.emb_label = MPConv(label_dim, cemb, kernel=[]) if label_dim != 0 else None
+
+        def attn_kind(res):
+            return "video" if res in video_attn_resolutions else "frame" if res in frame_attn_resolutions else False
+
+        self.enc = nn.ModuleDict()
+        cout = img_channels + 1
+        for level, channels in enumerate(cblock):
+            res = img_resolution >> level
+            if level == 0:
+                cin, cout = cout, channels
+                self.enc[f"{res}x{res}_conv"] = MPCausal3DGatedConv(cin, cout, kernel=[3, 3, 3])
+            else:
+                self.enc[f"{res}x{res}_down"] = Block(cout, cout, cemb, flavor="enc", resample_mode="down", **block_kwargs)
+            for idx in range(num_blocks):
+                cin, cout = cout, channels
+                self.enc[f"{res}x{res}_block{idx}"] = Block(cin, cout, cemb, flavor="enc", attention=attn_kind(res),
+                                                            **block_kwargs)
+        self.dec = nn.ModuleDict()
+        skips = [block.out_channels for block in self.enc.values()]
+        for level, channels in reversed(list(enumerate(cblock))):
+            res = img_resolution >> level
+            if level == len(cblock) - 1:
+                self.dec[f"{res}x{res}_in0"] = Block(cout, cout, cemb, flavor="dec", attention="video", **block_kwargs)
+                self.dec[f"{res}x{res}_in1"] = Block(cout, cout, cemb, flavor="dec", **block_kwargs)
+            else:
+                self.dec[f"{res}x{res}_up"] = Block(cout, cout, cemb, flavor="dec", resample_mode="up", **block_kwargs)
+            for idx in range(num_blocks + 1):
+                cin = cout + skips.pop()
+                cout = channels
+                self.dec[f"{res}x{res}_block{idx}"] = Block(cin, cout, cemb, flavor="dec", attention=attn_kind(res),
+                                                            **block_kwargs)
+        self.out_conv = MPCausal3DGatedConv(cout, img_channels, kernel=[3, 3, 3])
+        frame = inspect.currentframe()
+        args, _, _, values = inspect.getargvalues(frame)
+        self.kwargs = {arg: values[arg] for arg in args if arg != "self"}
+
+    def forward(self, x, c_noise, conditioning=None, cache=None, update_cache=False, just_2d=False):
+        if cache is None:
+            cache = {}
+        with weights_ready(self):
+            B, tt = x.shape[:2]
+            n_ctx = cache.get("n_context_frames", 0)
+            _, n_new = self.out_res(c_noise, n_ctx, just_2d)              # frame counter (value unused, :197)
+            if update_cache:
+                cache["n_context_frames"] = n_new
+            c_noise = c_noise.float()
+            cn = c_noise.reshape(-1)
+            # embedding (fp32 in torch for the tiny Fourier features, bf16 through the linear kernels)
+            emb = self.emb_noise.forward(self.emb_fourier_sigma(cn))
+            if self.emb_label is not None and conditioning is not None:
+                oh = F.one_hot(conditioning.reshape(-1), num_classes=self.label_dim).to(cn.dtype) * math.sqrt(self.label_dim)
+                emb = mp_sum(emb, self.emb_label.forward(oh), t=1 / 3)
+            emb = mp_silu(emb)
+            emb = emb.to(BF16)[:, None, None, :].contiguous()
+            # input: (B,t,C,H,W) -> channels-last with the extra all-ones channel (:221), padded to 16 channels
+            N = B * tt
+            xc = x.reshape(N, *x.shape[2:])
+            xc = torch.cat([xc, torch.ones_like(xc[:, :1])], dim=1)
+            xcl = to_cl(xc, pad_to=-(-xc.shape[1] // 16) * 16)
+            skips = []
+            for name, block in self.enc.items():
+                if isinstance(block, Block):
+                    xcl, cache["enc", name] = block._cl(xcl, emb, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
+                else:
+                    xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
+                skips.append(xcl)
+            for name, block in self.dec.items():
+                if "block" in name:
+                    xcl = mp_cat_cl(xcl, skips.pop(), t=self.concat_balance)
+                xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d)
+            xcl, cache["out_conv"] = self.out_conv._cl(xcl, B, c_noise, cache.get("out_conv"), update_cache, just_2d)
+            out = from_cl(xcl[..., :self.img_channels], torch.float32)
+            out = out.reshape(B, tt, *out.shape[1:]) * self.out_gain
+            return out, cache
+
+    def no_sync(self):
+        return nullcontext()
+
+    @torch.no_grad()
+    def load_from_2d(self, unet):
+        raise NotImplementedError("importing NVIDIA EDM2 2-D checkpoints is listed under SURVEY 8(f), not built yet")
+
+
+class Precond(BetterModule):
+    def __init__(self, unet, use_fp16=True, sigma_data=0.5):
+        super().__init__()
+        self.unet, self.use_fp16, self.sigma_data = unet, use_fp16, sigma_data
+        self.noise_weight = MultiNoiseLoss()
+
+    def forward(self, x, sigma, conditioning=None, force_fp32=False, cache=None, update_cache=False, just_2d=False):
+        if cache is None:
+            cache = {}
+        cache["shape"] = x.shape
+        x = x.to(torch.float32)
+        sigma = sigma.to(torch.float32)[:, :, None, None, None]
+        sd = self.sigma_data
+        c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
+        c_out = sigma * sd / (sigma ** 2 + sd ** 2).sqrt()
+        c_in = 1 / (sd ** 2 + sigma ** 2).sqrt()
+        c_noise = sigma.reshape(sigma.shape[:2]).log() / 4
+        F_x, cache = self.unet.forward(c_in * x, c_noise, conditioning, cache, update_cache, just_2d)
+        return c_skip * x + c_out * F_x.to(torch.float32), cache

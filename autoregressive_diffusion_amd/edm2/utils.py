@@ -1,0 +1,97 @@
+"""Magnitude-preserving primitives on channels-last bf16 tensors + BetterModule (checkpoint helpers).
+
+Mirrors the interface of the reference's edm2/utils.py (normalize :83-88, resample :94-107, mp_silu :112,
+mp_sum :118-123, mp_cat :128-134, MPFourier :139-150, BetterModule :13-72) -- written from scratch.  These are the
+HBM-bound glue ops between the HIP kernels; they run as device elementwise ops on (N, H, W, C) bf16 tensors.
+"""
+import math
+import numpy as np
+import torch
+from torch import nn
+
+EPS = 1e-4
+SILU_SCALE = 1.0 / 0.596
+BF16 = torch.bfloat16
+
+
+def to_cl(x, pad_to=None):
+    """(N, C, H, W) any float dtype -> (N, H, W, C[padded]) bf16 contiguous."""
+    x = x.permute(0, 2, 3, 1)
+    if pad_to is not None and x.shape[-1] < pad_to:
+        x = torch.nn.functional.pad(x, (0, pad_to - x.shape[-1]))
+    return x.to(BF16).contiguous()
+
+
+def from_cl(x, dtype=torch.float32):
+    return x.permute(0, 3, 1, 2).to(dtype).contiguous()
+
+
+def normalize_cl(x):
+    """pixel norm over the channel (last) dim: x / (eps + |x| / sqrt(C))   (utils.py:83-88 with dim=1)."""
+    n = torch.linalg.vector_norm(x.float(), dim=-1, keepdim=True)
+    return (x.float() / (EPS + n * (1.0 / math.sqrt(x.shape[-1])))).to(x.dtype)
+
+
+def mp_silu(x):
+    return torch.nn.functional.silu(x) * SILU_SCALE
+
+
+def mp_sum(a, b, t=0.5):
+    return (a + (b - a) * t) * (1.0 / math.sqrt((1 - t) ** 2 + t ** 2))
+
+
+def mp_cat_cl(a, b, t=0.5):
+    Na, Nb = a.shape[-1], b.shape[-1]
+    C = math.sqrt((Na + Nb) / ((1 - t) ** 2 + t ** 2))
+    return torch.cat([a * (C / math.sqrt(Na) * (1 - t)), b * (C / math.sqrt(Nb) * t)], dim=-1)
+
+
+def resample_cl(x, mode="keep"):
+    """f = [1,1]: 'down' = 2x2 mean, 'up' = nearest x2 (utils.py:94-107)."""
+    if mode == "keep":
+        return x
+    N, H, W, C = x.shape
+    if mode == "down":
+        return x.reshape(N, H // 2, 2, W // 2, 2, C).float().mean(dim=(2, 4)).to(x.dtype)
+    assert mode == "up"
+    return x[:, :, None, :, None, :].expand(N, H, 2, W, 2, C).reshape(N, 2 * H, 2 * W, C)
+
+
+class MPFourier(nn.Module):
+    def __init__(self, num_channels, bandwidth=1):
+        super().__init__()
+        self.register_buffer("freqs", 2 * np.pi * torch.randn(num_channels) * bandwidth)
+        self.register_buffer("phases", 2 * np.pi * torch.rand(num_channels))
+
+    def forward(self, x):
+        y = torch.outer(x.float(), self.freqs.float()) + self.phases.float()
+        return (y.cos() * math.sqrt(2)).to(x.dtype)
+
+
+class BetterModule(nn.Module):
+    """save_to_state_dict / from_pretrained with the reference's {"state_dict", "kwargs"} file format (local paths;
+    s3:// URLs need boto3 exactly like the reference and are not part of the hot path)."""
+
+    def save_to_state_dict(self, path):
+        data = {"state_dict": self.state_dict(), "kwargs": self.kwargs}
+        if str(path).startswith("s3://"):
+            raise NotImplementedError("s3:// checkpoints are outside the MI355X hot path; save locally")
+        torch.save(data, path)
+
+    @classmethod
+    def from_pretrained(cls, checkpoint):
+        if isinstance(checkpoint, str):
+            if checkpoint.startswith("s3://"):
+                raise NotImplementedError("s3:// checkpoints are outside the MI355X hot path; download first")
+            checkpoint = torch.load(checkpoint, weights_only=False)
+        model = cls(**checkpoint["kwargs"])
+        model.load_state_dict(checkpoint["state_dict"])
+        return model
+
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    @property
+    def n_params(self):
+        return sum(p.numel() for p in self.parameters())

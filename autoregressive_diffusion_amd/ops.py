@@ -97,7 +97,7 @@ def device_tables(kind, n_frames, image_size, device):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp")
+                 "wf", "wb", "dwp", "bank")
 
 
 class WeightBank:
@@ -106,6 +106,8 @@ class WeightBank:
         self._dev_table = None
         self._sig = None
         self.total_rows = 0
+        self._finish_queued = False
+        self.post_backward_hooks = []      # callables run after the weight gradients are final (DDP all-reduce)
 
     def add(self, param, perm3=False, gain=1.0, need_dgrad=True):
         w = PackedWeight()
@@ -118,6 +120,7 @@ class WeightBank:
         w.CoutPb, w.CinPb = roundup(w.cin, 32), roundup(w.cout, 64)
         w.perm3, w.gain = bool(perm3), float(gain)
         w.wf = w.wb = w.dwp = None
+        w.bank = self
         self.items.append((w, need_dgrad))
         return w
 
@@ -173,6 +176,19 @@ class WeightBank:
         self._ensure()
         check(lib.oniris_weight_bwd(_p(self._dev_table), len(self.items), self.total_rows, _stream()), "weight_bwd")
 
+    def request_finish(self):
+        """Called from inside a conv backward: run `backward()` once, after the autograd engine has finished the
+        whole pass (all wgrad kernels enqueued), then the post-backward hooks."""
+        if not self._finish_queued:
+            self._finish_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._finish)
+
+    def _finish(self):
+        self._finish_queued = False
+        self.backward()
+        for h in self.post_backward_hooks:
+            h()
+
 
 # ------------------------------------------------------------------------------------------------------------------
 # convolution
@@ -204,17 +220,20 @@ class _ConvFn(torch.autograd.Function):
     accumulated into the bank's packed fp32 buffer (side effect); WeightBank.backward() finishes it."""
 
     @staticmethod
-    def forward(ctx, x, pw, epi_res, ta, tb, clip):
+    def forward(ctx, x, wparam, pw, epi_res, ta, tb, clip):
+        # `wparam` (the fp32 Parameter) is an input only so that autograd schedules this node even when x needs
+        # no gradient; its gradient is accumulated out-of-band (packed dwp buffer -> WeightBank.backward()).
         _need_gpu(x)
         N, H, W, Cin = x.shape
         assert Cin == pw.cin or (Cin >= pw.cin and Cin % 8 == 0), (Cin, pw.cin)
         taps = pw.taps
-        out = torch.empty((N, H, W, pw.cout), dtype=BF16, device=x.device)
+        Co = roundup(pw.cout, 8)                      # channel counts in HBM are multiples of 8 (16-byte vectors)
+        out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
         if epi_res is not None:
-            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, pw.cout, pw.CoutP, taps,
+            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, Co, pw.CoutP, taps,
                          epi=_lib.EPI_MPSUM, res=epi_res, ta=ta, tb=tb, clip=clip)
         else:
-            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, pw.cout, pw.CoutP, taps)
+            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, Co, pw.CoutP, taps)
         ctx.pw, ctx.scal = pw, (ta, tb, clip, epi_res is not None)
         ctx.save_for_backward(x, out if (epi_res is not None and clip > 0) else None)
         return out
@@ -232,19 +251,21 @@ class _ConvFn(torch.autograd.Function):
             dres = dout * ta
             dout = dout * tb
         N, H, W, Cin = x.shape
+        Co = dout.shape[-1]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-            _conv_launch(dout, None, pw.wb, None, dx, None, None, 1, 1, N, H, W, pw.cout, pw.CinPb, Cin, pw.CoutPb,
+            _conv_launch(dout, None, pw.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw.CinPb, Cin, pw.CoutPb,
                          pw.taps)
         if pw.param.requires_grad:
-            _wgrad_launch(x, dout, pw.dwp, None, 1, N, H, W, Cin, pw.CinP, pw.cout, pw.CoutP, pw.taps, N, N, 0, 0.0)
-        return dx, None, dres, None, None, None
+            _wgrad_launch(x, dout, pw.dwp, None, 1, N, H, W, Cin, pw.CinP, Co, pw.CoutP, pw.taps, N, N, 0, 0.0)
+            pw.bank.request_finish()
+        return dx, None, None, dres, None, None, None
 
 
 def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0):
     """MPConv forward on packed weights; optional fused epilogue out = clip(ta*res + tb*conv(x))."""
-    return _ConvFn.apply(x, pw, res, ta, tb, clip)
+    return _ConvFn.apply(x, pw.param, pw, res, ta, tb, clip)
 
 
 class _GatedConvFn(torch.autograd.Function):
@@ -252,14 +273,15 @@ class _GatedConvFn(torch.autograd.Function):
     (b s t).  out = ca[n]*conv2d(x[n]) + cb[n]*(conv(clean[t-2]) + conv(clean[t-1])), ones-padded in time."""
 
     @staticmethod
-    def forward(ctx, x, ca, cb, pw2, pw3, B, T, need_grad):
+    def forward(ctx, x, ca, cb, w2param, w3param, pw2, pw3, B, T, need_grad):
         _need_gpu(x, ca, cb)
         N, H, W, Cin = x.shape
         assert N == B * 2 * T
-        out = torch.empty((N, H, W, pw2.cout), dtype=BF16, device=x.device)
-        y3 = torch.empty((B * T, H, W, pw2.cout), dtype=BF16, device=x.device) if need_grad else None
+        Co = roundup(pw2.cout, 8)
+        out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
+        y3 = torch.empty((B * T, H, W, Co), dtype=BF16, device=x.device) if need_grad else None
         ca32, cb32 = ca.detach().float().contiguous(), cb.detach().float().contiguous()
-        _conv_launch(x, x, pw2.wf, pw3.wf, out, ca32, cb32, B, 2, T, H, W, Cin, pw2.CinP, pw2.cout, pw2.CoutP, 9,
+        _conv_launch(x, x, pw2.wf, pw3.wf, out, ca32, cb32, B, 2, T, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
                      ctx_bstride=2 * T, ctx_T=T, coff=(-2, -1), ctx_fill=1.0, ctx_out=y3)
         ctx.pws, ctx.dims = (pw2, pw3), (B, T)
         ctx.save_for_backward(x, out, y3, ca32, cb32)
@@ -271,7 +293,7 @@ class _GatedConvFn(torch.autograd.Function):
         pw2, pw3 = ctx.pws
         B, T = ctx.dims
         N, H, W, Cin = x.shape
-        Cout = pw2.cout
+        Cout = out.shape[-1]
         dout = dout.contiguous()
         dev = x.device
         S1 = torch.empty(N, dtype=torch.float32, device=dev)
@@ -293,25 +315,29 @@ class _GatedConvFn(torch.autograd.Function):
             for j, coff in enumerate((-2, -1)):
                 _wgrad_launch(x, dy3, pw3.dwp[j * per:], None, B, T, H, W, Cin, pw3.CinP, Cout, pw3.CoutP, 9, 2 * T, T,
                               coff, 1.0)
+        if pw2.param.requires_grad or pw3.param.requires_grad:
+            pw2.bank.request_finish()
         # out = ca*y2 + cb*y3  ->  d ca = sum(dout*y2) = (S1 - cb*S2)/ca ,  d cb = S2
         dca = (S1 - cb * S2) / ca
-        return dx, dca, S2, None, None, None, None, None
+        return dx, dca, S2, None, None, None, None, None, None, None
 
 
 def gated_conv_train(x, gate, pw2, pw3, B, T):
     """gate: (B*2*T,) fp32 (autograd tensor from Gating).  mp_sum(y2, y3, g) coefficients in torch (tiny)."""
     den = torch.rsqrt((1 - gate) ** 2 + gate ** 2)
-    return _GatedConvFn.apply(x, (1 - gate) * den, gate * den, pw2, pw3, B, T, torch.is_grad_enabled())
+    return _GatedConvFn.apply(x, (1 - gate) * den, gate * den, pw2.param, pw3.param, pw2, pw3, B, T,
+                              torch.is_grad_enabled())
 
 
 @torch.no_grad()
 def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames):
     """Eval-mode gated conv: x (B*t,H,W,C); ctx_frames (B, t+2, H, W, C) = [2 cached frames, x frames]."""
     N, H, W, Cin = x.shape
-    out = torch.empty((N, H, W, pw2.cout), dtype=BF16, device=x.device)
+    Co = roundup(pw2.cout, 8)
+    out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
     den = torch.rsqrt((1 - gate) ** 2 + gate ** 2)
     ca, cb = ((1 - gate) * den).float().contiguous(), (gate * den).float().contiguous()
-    _conv_launch(x, ctx_frames, pw2.wf, pw3.wf, out, ca, cb, B, 1, t, H, W, Cin, pw2.CinP, pw2.cout, pw2.CoutP, 9,
+    _conv_launch(x, ctx_frames, pw2.wf, pw3.wf, out, ca, cb, B, 1, t, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
                  ctx_bstride=t + 2, ctx_T=t + 2, coff=(0, 1), ctx_fill=0.0)
     return out
 

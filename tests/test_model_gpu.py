@@ -1,0 +1,220 @@
+"""GPU parity of the edm2-compatible modules (HIP kernels behind the C-ABI) against the golden vectors captured
+from the reference (tests/golden/*.npz).  bf16 operands / fp32 accumulation vs the reference's fp32:
+tolerances are relative L2 per tensor, stated at each assert (<= 1e-2 per op; deeper stacks looser)."""
+import os
+import numpy as np
+import pytest
+import torch
+
+import paramgen
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"), allow_pickle=False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def rel(a, b):
+    a, b = torch.as_tensor(a).detach().float().cpu(), torch.as_tensor(b).detach().float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def load_params(mod, params):
+    sd = {k: v.clone() for k, v in params.items()}
+    mod.load_state_dict(sd, strict=True)
+    return mod.to(DEV)
+
+
+def test_g3_gated_conv_module():
+    from edm2.conv import MPCausal3DGatedConv
+    z = load("g3_gated_conv")
+    conv = load_params(MPCausal3DGatedConv(8, 8, [3, 3, 3]), {k[2:]: T(z[k]) for k in z.files if k.startswith("p_")})
+    B = 2
+    conv.train()
+    x = T(z["train_x"]).to(DEV).requires_grad_(True)
+    y, _ = conv(x, None, B, T(z["train_cn"]).to(DEV))
+    y.backward(T(z["train_gy"]).to(DEV))
+    errs = {"y": rel(y, z["train_y"]), "gx": rel(x.grad, z["train_gx"])}
+    for n, p in conv.named_parameters():
+        errs["g_" + n] = rel(p.grad, z["train_g_" + n])
+    print("g3 train", errs)
+    assert errs["y"] < 1e-2 and errs["gx"] < 1.5e-2
+    assert all(v < 3e-2 for k, v in errs.items() if k.startswith("g_")), errs
+    y2, _ = conv(x.detach(), None, B, T(z["train_cn"]).to(DEV), just_2d=True)
+    assert rel(y2, z["train_y_just2d"]) < 1e-2
+    conv.eval()
+    with torch.no_grad():
+        xe, cn = T(z["eval_x"]).to(DEV), T(z["eval_cn"]).to(DEV)
+        ye, _ = conv(xe, None, B, cn)
+        xs = xe.reshape(B, 6, *xe.shape[1:])
+        y4, c = conv(xs[:, :4].reshape(-1, *xe.shape[1:]), None, B, cn[:, :4], cache=None, update_cache=True)
+        assert c["n_context_frames"] == int(z["eval_cache_n4"])
+        y5, c = conv(xs[:, 4:5].reshape(-1, *xe.shape[1:]), None, B, cn[:, 4:5], cache=c, update_cache=True)
+        assert c["n_context_frames"] == int(z["eval_cache_n5"])
+        y6, c = conv(xs[:, 5:6].reshape(-1, *xe.shape[1:]), None, B, cn[:, 5:6], cache=c, update_cache=False)
+    e = (rel(ye, z["eval_y"]), rel(y4, z["eval_y4"]), rel(y5, z["eval_y5"]), rel(y6, z["eval_y6"]))
+    print("g3 eval", e)
+    assert max(e) < 1e-2
+    # cached == uncached (reference property consistency_test.py:261-307), same kernels both ways -> tight
+    cat = torch.cat([y4.reshape(B, 4, -1), y5.reshape(B, 1, -1), y6.reshape(B, 1, -1)], 1).reshape(ye.shape)
+    assert rel(cat, ye) < 1e-6
+
+
+def test_g6_attention_modules():
+    from edm2.attention import VideoAttention, FrameAttention
+    z = load("g6_attention")
+    for tag, C, m, B in [("a", 64, 1, 2), ("b", 64, 1, 1), ("c", 128, 2, 1)]:
+        att = load_params(VideoAttention(C, m), {k[len(tag) + 3:]: T(z[k]) for k in z.files if k.startswith(tag + "_p_")})
+        att.train()
+        x = T(z[tag + "_x"]).to(DEV).requires_grad_(True)
+        y, _ = att(x, B)
+        y.backward(T(z[tag + "_gy"]).to(DEV))
+        e = dict(y=rel(y, z[tag + "_y"]), gx=rel(x.grad, z[tag + "_gx"]),
+                 g_qkv=rel(att.attn_qkv.weight.weight.grad, z[tag + "_g_qkv"]),
+                 g_proj=rel(att.attn_proj.weight.weight.grad, z[tag + "_g_proj"]))
+        print("g6", tag, e)
+        assert e["y"] < 1e-2 and e["gx"] < 2e-2 and e["g_qkv"] < 3e-2 and e["g_proj"] < 3e-2
+        y2, _ = att(x.detach(), B, just_2d=True)
+        assert rel(y2, z[tag + "_y_just2d"]) < 1e-2
+        if tag == "a":
+            att.eval()
+            with torch.no_grad():
+                xe = T(z["a_eval_x"]).to(DEV)
+                ye, _ = att(xe, B)
+                xs = xe.reshape(B, 6, *xe.shape[1:])
+                y4, c = att(xs[:, :4].reshape(-1, *xe.shape[1:]), B, None, update_cache=True)
+                y5, c = att(xs[:, 4:5].reshape(-1, *xe.shape[1:]), B, c, update_cache=True)
+                y6, _ = att(xs[:, 5:6].reshape(-1, *xe.shape[1:]), B, c, update_cache=False)
+            e = (rel(ye, z["a_eval_y"]), rel(y4, z["a_eval_y4"]), rel(y5, z["a_eval_y5"]), rel(y6, z["a_eval_y6"]))
+            print("g6 eval", e)
+            assert max(e) < 1e-2
+    fa = load_params(FrameAttention(64, 1), {k[4:]: T(z[k]) for k in z.files if k.startswith("f_p_")})
+    fa.train()
+    x = T(z["f_x"]).to(DEV).requires_grad_(True)
+    y, _ = fa(x)
+    y.backward(T(z["f_gy"]).to(DEV))
+    e = (rel(y, z["f_y"]), rel(x.grad, z["f_gx"]), rel(fa.attn_qkv.weight.weight.grad, z["f_g_qkv"]))
+    print("g6 frame", e)
+    assert e[0] < 1e-2 and e[1] < 2e-2 and e[2] < 3e-2
+
+
+def test_g7_blocks():
+    from edm2.networks_edm2 import Block
+    from test_oracle_golden import _block_params
+    z = load("g7_blocks")
+    for tag, kw, cin, cout in [("enc", dict(flavor="enc", resample_mode="down", attention="frame"), 32, 64),
+                               ("dec", dict(flavor="dec", resample_mode="up", attention="video"), 96, 64)]:
+        p, _ = _block_params(tag, z)
+        blk = load_params(Block(cin, cout, 32, **kw), p)
+        blk.train()
+        x = T(z[tag + "_x"]).to(DEV).requires_grad_(True)
+        emb = T(z[tag + "_emb"]).to(DEV).requires_grad_(True)
+        y, _ = blk(x, emb, 1, T(z[tag + "_cn"]).to(DEV))
+        y.backward(T(z[tag + "_gy"]).to(DEV))
+        e = dict(y=rel(y, z[tag + "_y"]), gx=rel(x.grad, z[tag + "_gx"]), gemb=rel(emb.grad, z[tag + "_gemb"]))
+        gn = {}
+        for n, prm in blk.named_parameters():
+            k = f"{tag}_gn_{n}"
+            if k in z.files and prm.grad is not None:
+                gn[n] = abs(prm.grad.norm().item() - float(z[k])) / (float(z[k]) + 1e-12)
+        print("g7", tag, e, "max gradnorm rel err", max(gn.values()), max(gn, key=gn.get))
+        assert e["y"] < 1.5e-2 and e["gx"] < 3e-2 and e["gemb"] < 3e-2
+        # weights: 5e-2.  gate scalars: d(gate) is a reduction of bf16-stored activations whose true value can be far
+        # below the magnitude of its terms (scale-invariant layers downstream) -> absolute noise floor, see GATE_TOL
+        assert max(v for k, v in gn.items() if "gating" not in k) < 5e-2, gn
+        assert max(v for k, v in gn.items() if "gating" in k) < 0.15, gn
+
+
+SMALL_CFG = dict(img_resolution=32, img_channels=4, label_dim=4, model_channels=16, channel_mult=[1, 4, 4],
+                 num_blocks=1, video_attn_resolutions=[8], frame_attn_resolutions=[16])
+C1_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=16, channel_mult=[1, 2, 4, 8],
+              num_blocks=1, video_attn_resolutions=[8], frame_attn_resolutions=[16])
+
+
+def build_precond(cfg, seed, sigma_data):
+    from edm2.networks_edm2 import UNet, Precond
+    p = paramgen.prenormalise(paramgen.precond_params(cfg, seed))
+    net = Precond(UNet(**cfg), use_fp16=True, sigma_data=sigma_data)
+    return load_params(net, p)
+
+
+@pytest.mark.parametrize("tag,cfg", [("small", SMALL_CFG), ("c1", C1_CFG)])
+def test_g8_unet_loss(tag, cfg):
+    from edm2.loss import EDM2Loss
+    z = load("g8_unet")
+    images, labels = T(z[tag + "_images"]).to(DEV), T(z[tag + "_labels"]).to(DEV)
+    for mode in ("3d", "2d"):
+        net = build_precond(cfg, int(z[tag + "_seed"]), 1.0)
+        net.train()
+        sigma, eps = T(z[f"{tag}_{mode}_sigma"]).to(DEV), T(z[f"{tag}_{mode}_eps"]).to(DEV)
+        loss_fn = EDM2Loss(sigma_data=1.0)
+        loss, unw = loss_fn(net, images, labels, sigma=sigma, just_2d=(mode == "2d"), noise=eps)
+        loss.backward()
+        with torch.no_grad():
+            cat = images if mode == "2d" else torch.cat([images, images], 1)
+            cond = labels if mode == "2d" else torch.cat([labels, labels], 1)
+            net2 = build_precond(cfg, int(z[tag + "_seed"]), 1.0).train()
+            Dx, _ = net2(cat + sigma[:, :, None, None, None] * eps, sigma, cond, just_2d=(mode == "2d"))
+        e = dict(Dx=rel(Dx, z[f"{tag}_{mode}_Dx"]), loss=abs(loss.item() - float(z[f"{tag}_{mode}_loss"])) / float(z[f"{tag}_{mode}_loss"]),
+                 unw=abs(unw - float(z[f"{tag}_{mode}_unweighted"])) / float(z[f"{tag}_{mode}_unweighted"]))
+        names = [str(s) for s in z[f"{tag}_{mode}_gradnorm_names"]]
+        vals = z[f"{tag}_{mode}_gradnorm_vals"]
+        prm = dict(net.named_parameters())
+        gerr = {}
+        for n, v in zip(names, vals):
+            g = prm[n].grad
+            assert g is not None, n
+            gerr[n] = abs(g.norm().item() - v) / (v + 1e-12)
+        worst = sorted(gerr, key=gerr.get)[-3:]
+        full = {}
+        for k in z.files:
+            pre = f"{tag}_{mode}_g_"
+            if k.startswith(pre):
+                full[k[len(pre):]] = rel(prm[k[len(pre):]].grad, z[k])
+        for k in sorted(full):
+            if "gating" in k and full[k] > 0.05:
+                print("   gate grad", k, prm[k].grad.flatten().tolist(), "ref", z[f"{tag}_{mode}_g_{k}"].flatten().tolist())
+        print("g8", tag, mode, e, "worst gradnorm", [(w, round(gerr[w], 4)) for w in worst],
+              "worst full grad", max(full.values()) if full else None)
+        assert e["Dx"] < 2e-2 and e["loss"] < 2e-2 and e["unw"] < 2e-2
+        wg = {k: v for k, v in gerr.items() if "gating" not in k}
+        assert np.median(list(wg.values())) < 2e-2 and max(wg.values()) < 0.1, sorted(wg.items(), key=lambda kv: kv[1])[-3:]
+        # gate scalars: |err| <= 3% of the value + 0.3% of the largest gate gradient in the net (bf16 noise floor of
+        # the sum(dout*out) / sum(dout*y3) reductions; measured floor ~5e-5 absolute on this fixture)
+        refs = {n: v for n, v in zip(names, vals) if "gating" in n}
+        gmax = max(refs.values())
+        for n, v in refs.items():
+            assert abs(prm[n].grad.norm().item() - v) <= 3e-2 * v + 3e-3 * gmax, (n, prm[n].grad.norm().item(), v)
+        unused = set(str(s) for s in z[f"{tag}_{mode}_unused"])
+        for n in unused:       # parameters the reference leaves without gradient must not get one here either
+            g = prm[n].grad
+            assert g is None or float(g.abs().max()) == 0.0, n
+
+
+def test_g9_sampler_rollout():
+    from edm2.sampler import edm_sampler_with_mse
+    z = load("g9_sampler")
+    net = build_precond(SMALL_CFG, int(z["seed"]), 0.5)
+    net.eval()
+    with torch.no_grad():
+        D, cache = net(T(z["ctx"]).to(DEV), torch.ones(1, 4, device=DEV) * 0.05, T(z["ctx_labels"]).to(DEV), update_cache=True)
+        e0 = rel(D, z["prefill_D"])
+        errs = []
+        for step in range(2):
+            x, _, _, cache = edm_sampler_with_mse(net, cache, conditioning=torch.full((1, 1), 1 + step, device=DEV),
+                                                  num_steps=4, sigma_min=0.01, sigma_max=80, rho=2, guidance=1, S_churn=0,
+                                                  noise=T(z["noise"][step]).to(DEV))
+            errs.append(rel(x, z["frames"][step]))
+    print("g9 prefill", e0, "frames", errs)
+    assert cache["n_context_frames"] == int(z["cache_n_ctx"])
+    blk = cache[("enc", "8x8_block0")]
+    assert blk["conv_res0"]["n_context_frames"] == int(z["cache_conv0_n"])
+    assert blk["attn"][0].shape[1] == z["cache_attn_k"].shape[2] * z["cache_attn_k"].shape[3]
+    assert e0 < 2e-2 and max(errs) < 5e-2
