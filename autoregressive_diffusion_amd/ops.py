@@ -184,6 +184,8 @@ class WeightBank:
             torch.autograd.Variable._execution_engine.queue_callback(self._finish)
 
     def _finish(self):
+        if not self._finish_queued:        # already finished early (e.g. by the DDP end-of-backward callback)
+            return
         self._finish_queued = False
         self.backward()
         for h in self.post_backward_hooks:

@@ -1,0 +1,148 @@
+"""Batch-sharded data parallelism for the denoiser step: one process per GPU, gradients summed with RCCL
+(torch.distributed backend "nccl" == RCCL on ROCm) over the xGMI mesh.
+
+Replaces `DDP(unet, device_ids=[local_rank], find_unused_parameters=True)` + `unet.no_sync()` of the reference
+(cs_train.py:53-54,108).  Design for MI355X: parameters and gradients live in ONE flat fp32 buffer each
+(FlatParams), so the gradient exchange is a handful of large all-reduces on contiguous memory (xGMI ring
+collectives are per-link bound: few large messages beat many 25 MB buckets), parameters that received no gradient
+(2-D steps, `out_res.*`, `emb_time`) are simply zeros in the flat buffer (no unused-parameter bookkeeping, no
+deadlock), and the optimizer is a single fused kernel over the same buffers.
+"""
+import contextlib
+import torch
+import torch.distributed as dist
+from torch import nn
+
+
+class FlatParams:
+    """Re-homes every trainable parameter of `module` (and its .grad) as a view into one flat fp32 buffer."""
+
+    def __init__(self, module):
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        assert self.params, "no trainable parameters"
+        dev, dt = self.params[0].device, self.params[0].dtype
+        assert all(p.dtype == dt and p.device == dev for p in self.params)
+        sizes = [p.numel() for p in self.params]
+        self.offsets, off = [], 0
+        for n in sizes:
+            self.offsets.append(off)
+            off += (n + 3) // 4 * 4                      # 16-byte aligned slices
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=dt, device=dev)
+        self.grad = torch.zeros(off, dtype=dt, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                v = self.flat[o:o + p.numel()].view_as(p)
+                v.copy_(p.data)
+                p.data = v
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def check(self):
+        """True while every parameter still aliases the flat buffers (a .to()/deepcopy breaks the aliasing)."""
+        base = self.flat.data_ptr()
+        return all(p.data_ptr() == base + 4 * o and p.grad is not None and
+                   p.grad.data_ptr() == self.grad.data_ptr() + 4 * o for p, o in zip(self.params, self.offsets))
+
+
+class OnirisDDP(nn.Module):
+    """Data-parallel wrapper: forward delegates to `module`; at the END of every backward pass (unless inside
+    `no_sync()`) the flat gradient buffer is averaged over the process group in `bucket_mb`-sized all-reduces."""
+
+    def __init__(self, module, process_group=None, bucket_mb=256, flat=None):
+        super().__init__()
+        self.module = module
+        self.process_group = process_group
+        self.flat = flat if flat is not None else FlatParams(module)
+        self.bucket_elems = max(1, int(bucket_mb * (1 << 20) // 4))
+        self._sync_enabled = True
+        self._queued = False
+        self._works = []
+        # every rank starts from rank 0's parameters (what torch DDP does at construction)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
+            dist.broadcast(self.flat.flat, src=0, group=self.process_group)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.module, name)
+
+    def forward(self, *args, **kwargs):
+        out = self.module(*args, **kwargs)
+        if torch.is_grad_enabled() and self._sync_enabled:
+            first = out[0] if isinstance(out, (tuple, list)) else out
+            if torch.is_tensor(first) and first.requires_grad:
+                first.register_hook(self._on_backward_start)
+        return out
+
+    def _on_backward_start(self, grad):
+        if not self._queued:
+            self._queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        return grad
+
+    def _end_of_backward(self):
+        self._queued = False
+        if not self._sync_enabled:
+            return
+        bank = self.module.__dict__.get("_oniris_bank")
+        if bank is not None:
+            bank._finish()                               # weight gradients must be final before the exchange
+        self.allreduce_grads()
+
+    def allreduce_grads(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return
+        world = dist.get_world_size(self.process_group)
+        if world == 1:
+            return
+        g = self.flat.grad
+        g.mul_(1.0 / world)
+        self._works = [dist.all_reduce(g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.process_group,
+                                       async_op=True) for s in range(0, g.numel(), self.bucket_elems)]
+
+    def wait(self):
+        """Block the current stream until the gradient exchange is done (call before the optimizer step)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        old, self._sync_enabled = self._sync_enabled, False
+        try:
+            yield
+        finally:
+            self._sync_enabled = old
+
+
+class FlatAdamW:
+    """AdamW on the flat buffers.  GPU: one fused HIP kernel (oniris_adamw); CPU tensors (tests): plain torch math."""
+
+    def __init__(self, flat, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(flat.flat)
+        self.v = torch.zeros_like(flat.flat)
+        self.steps = 0
+
+    @torch.no_grad()
+    def step(self, grad_scale=1.0):
+        self.steps += 1
+        f = self.flat
+        if f.flat.is_cuda:
+            from . import ops
+            ops.adamw_(f.flat, f.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
+                       self.weight_decay, self.steps, grad_scale)
+            return
+        b1, b2 = self.betas
+        g = f.grad * grad_scale
+        self.m.mul_(b1).add_(g, alpha=1 - b1)
+        self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        mh, vh = self.m / (1 - b1 ** self.steps), self.v / (1 - b2 ** self.steps)
+        f.flat.mul_(1 - self.lr * self.weight_decay).sub_(self.lr * mh / (vh.sqrt() + self.eps))
+
+    def zero_grad(self):
+        self.flat.zero_grad()
