@@ -195,9 +195,54 @@ class WeightBank:
 # ------------------------------------------------------------------------------------------------------------------
 # convolution
 
+class KernelProfile:
+    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg).  Events are recorded on
+    the stream the kernel is launched on (torch's current stream)."""
+    enabled = False
+    records = []          # (key, algorithmic flops, start_event, end_event)
+
+    @classmethod
+    def start(cls):
+        cls.records, cls.enabled = [], True
+
+    @classmethod
+    def stop(cls):
+        cls.enabled = False
+        torch.cuda.synchronize()
+        agg = {}
+        for key, flops, e0, e1 in cls.records:
+            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0))
+            a["launches"] += 1
+            a["flops"] += flops
+            a["ms"] += e0.elapsed_time(e1)
+        cls.records = []
+        return agg
+
+
+def _patch_w(W):
+    return 16 if W >= 16 else W
+
+
 def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP, Cout, CoutP, taps,
                  ctx_bstride=0, ctx_T=0, coff=(0, 0), ctx_fill=0.0, epi=0, res=None, escale=None, emb_gain=None,
                  out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None):
+    if KernelProfile.enabled:
+        flops = 2.0 * B * S * T * H * W * Cout * Cin * taps
+        if ctx is not None:
+            flops += 2.0 * B * T * H * W * Cout * Cin * 2 * taps
+        nt = 2 if CoutP % 64 == 0 else 1
+        key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        KernelProfile.enabled = False
+        try:
+            _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP, Cout, CoutP, taps,
+                         ctx_bstride, ctx_T, coff, ctx_fill, epi, res, escale, emb_gain, out2, ta, tb, clip, ctx_out)
+        finally:
+            KernelProfile.enabled = True
+        e1.record()
+        KernelProfile.records.append((key, flops, e0, e1))
+        return
     a = _lib.ConvArgs()
     a.x, a.ctx, a.w_own, a.w_ctx, a.out = _p(x), _p(ctx), _p(w_own), _p(w_ctx), _p(out)
     a.coef_own, a.coef_ctx = _p(coef_own), _p(coef_ctx)
@@ -210,6 +255,19 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
 
 
 def _wgrad_launch(x, dy, dwp, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill):
+    if KernelProfile.enabled:
+        tile = 2 if (Cin > 32 and Cout > 32) else 1
+        key = f"conv_wgrad_kernel<TAPS={taps},PW={_patch_w(W)},CT={tile},IT={tile}>"
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        KernelProfile.enabled = False
+        try:
+            _wgrad_launch(x, dy, dwp, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill)
+        finally:
+            KernelProfile.enabled = True
+        e1.record()
+        KernelProfile.records.append((key, 2.0 * B * T * H * W * Cout * Cin * taps, e0, e1))
+        return
     a = _lib.WgradArgs()
     a.x, a.dy, a.dwp, a.scale = _p(x), _p(dy), _p(dwp), _p(scale)
     a.B, a.T, a.H, a.W, a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = B, T, H, W, Cin, CinP, Cout, CoutP, taps

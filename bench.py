@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Denoiser-step throughput of the MI355X-native Oniris implementation (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config.workload): the Lunar-Lander net of gym_train.py:37-47 (46.2 M parameters), 64-frame sequences of
+8x64x64 latents, B sequences per GPU, synthetic N(0,1) latents and random-init weights.  One step = the reference
+training micro-step: EDM2Loss forward (Precond -> UNet over clean|noised frame slots), backward, gradient
+all-reduce (N > 1), fused AdamW, with the reference's 3:1 mix of 3-D and 2-D steps (gym_train.py:96).
+value = latent frames / s over the whole job = N * B * T * K / wall time of the K timed steps (max over ranks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+GYM_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=32, channel_mult=[1, 2, 4, 8],
+               channel_mult_noise=None, channel_mult_emb=None, num_blocks=2, video_attn_resolutions=[8],
+               frame_attn_resolutions=[16])
+MFMA_BF16_PEAK = 2.5e15          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+# algorithmic forward FLOPs per sample of the 3-D step at T=64: 1.82 TFLOP; x3 fwd+bwd
+
+
+def cpu_baseline(frames):
+    """The CPU oracle (fp32 PyTorch restatement, pinned to the reference by tests/golden) on a bounded sample."""
+    import torch
+    import paramgen
+    from oracle import oniris_oracle as O
+    cfg = {k: v for k, v in GYM_CFG.items() if v is not None}
+    torch.manual_seed(0)
+    p = paramgen.precond_params(cfg, 0)
+    p = {k: v.clone().requires_grad_(v.is_floating_point() and "rope" not in k and "fourier" not in k) for k, v in p.items()}
+    images = torch.randn(1, frames, 8, 64, 64)
+    labels = torch.randint(0, 4, (1, frames))
+    sigma = (torch.randn(1, 2 * frames) * 1.0 + 1.2).exp()
+    eps = torch.randn(1, 2 * frames, 8, 64, 64)
+    t0 = time.time()
+    loss, _, _ = O.edm2_loss(p, cfg, images, sigma, eps, labels, sigma_data=1.0)
+    loss.backward()
+    dt = time.time() - t0
+    return dict(value=frames / dt, unit="latent-frames/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle (fp32 PyTorch CPU restatement), gym UNet 46.2M, B=1, T={frames}, one 3-D "
+                       f"forward+backward step, {dt:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--batch", type=int, default=2, help="sequences per GPU (weak scaling)")
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
+                         f"--nproc-per-node {args.gpus} bench.py ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+
+    from edm2.networks_edm2 import UNet, Precond
+    from edm2.loss import EDM2Loss
+    from autoregressive_diffusion_amd.parallel import FlatParams, OnirisDDP, FlatAdamW
+    from autoregressive_diffusion_amd import ops
+
+    torch.manual_seed(0)
+    unet = UNet(**GYM_CFG).to(dev)
+    for m in unet.modules():                      # give the zero-initialised gains a value so every branch carries signal
+        if hasattr(m, "emb_gain"):
+            torch.nn.init.constant_(m.emb_gain, 0.3)
+    torch.nn.init.constant_(unet.out_gain, 1.0)
+    flat = FlatParams(unet)
+    model = OnirisDDP(unet, flat=flat) if world > 1 else unet
+    net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
+    opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
+    loss_fn = EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5)   # gym_train.py:66-67
+
+    B, T = args.batch, args.frames
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    latents = torch.randn(B, T, 8, 64, 64, device=dev, generator=g)
+    actions = torch.randint(0, 4, (B, T), device=dev, generator=g)
+
+    def step(i):
+        just_2d = (i % 4 == 0)                                   # gym_train.py:96
+        opt.zero_grad()
+        loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
+        loss.backward()
+        if world > 1:
+            model.wait()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(last.item())
+
+    # per-mode step times (one 3-D and one 2-D step, timed separately, not part of `value`)
+    per_mode = {}
+    for name, i in (("ms_3d_step", 1), ("ms_2d_step", 0)):
+        fence(); t1 = time.perf_counter(); step(i); fence()
+        per_mode[name] = (time.perf_counter() - t1) * 1e3
+
+    roof, kernels = None, None
+    if rank == 0 and not args.no_profile:
+        ops.KernelProfile.start()
+        for i in range(4):                                        # one full 3:1 cycle, every MFMA conv launch bracketed
+            step(i)                                               # by HIP events on its own stream
+        agg = ops.KernelProfile.stop()
+        kernels = {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
+                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in
+                   sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:8]}
+        dom, v = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        achieved = v["flops"] / (v["ms"] * 1e-3)
+        roof = dict(bound="mfma", kernel=dom, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
+                    flops_per_launch=v["flops"] / v["launches"], achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12,
+                    unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=None)
+    elif world > 1:
+        for i in range(4):
+            step(i)                                               # keep collectives matched across ranks
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_frames > 0:
+        cpu = cpu_baseline(args.cpu_frames)
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        frames = world * B * T * args.steps
+        out = {"metric": "denoiser-step frames/sec at 1/2/4/8 MI355X; 64-frame Lunar-Lander seq",
+               "value": frames / dt, "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), "
+                                      f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + AdamW, 3:1 mix of "
+                                      f"3-D/2-D steps", "global_batch": world * B, "seq_len": T,
+                          "parallelism": f"dp{world}", **{k: round(v, 2) for k, v in per_mode.items()}},
+               "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
