@@ -72,8 +72,15 @@ _SIGS = {
                              c_float, c_int, c_float, c_void_p]),
     "oniris_conv_fwd": (c_int, [C.POINTER(ConvArgs), c_void_p]),
     "oniris_conv_wgrad": (c_int, [C.POINTER(WgradArgs), c_void_p]),
-    "oniris_gconv_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                      c_int, c_int64, c_void_p]),
+    "oniris_gconv_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                      c_int, c_int, c_int, c_int64, c_void_p]),
+    "oniris_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
+                               c_int, c_void_p]),
+    "oniris_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,
+                               c_float, c_int, c_void_p]),
+    "oniris_emb_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "oniris_mpsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p]),
+    "oniris_resample": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "oniris_qkv_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "oniris_qkv_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "oniris_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,

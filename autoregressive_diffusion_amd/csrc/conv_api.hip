@@ -11,7 +11,7 @@ extern "C" int oniris_conv_fwd(const OnirisConvArgs* args, oniris_stream_t strea
   ONIRIS_CHECK_ARG(a.CoutP % 32 == 0 && a.CinP % 64 == 0 && a.CoutP >= a.Cout && a.CinP >= a.Cin,
                    "conv_fwd: bad padded sizes CoutP=%d CinP=%d", a.CoutP, a.CinP);
   ONIRIS_CHECK_ARG(a.epi != ONIRIS_EPI_MPSUM || a.res, "conv_fwd: EPI_MPSUM needs res");
-  ONIRIS_CHECK_ARG(a.epi != ONIRIS_EPI_EMB_SILU || (a.escale && a.emb_gain && a.out2), "conv_fwd: EPI_EMB_SILU needs escale/emb_gain/out2");
+  ONIRIS_CHECK_ARG(a.epi != ONIRIS_EPI_EMB_SILU || (a.escale && a.out2), "conv_fwd: EPI_EMB_SILU needs escale/out2");
   const bool has_ctx = a.ctx != nullptr;
   ONIRIS_CHECK_ARG(!has_ctx || (a.w_ctx && a.taps == 9), "conv_fwd: context path needs w_ctx and taps == 9");
   if (a.taps == 1) {

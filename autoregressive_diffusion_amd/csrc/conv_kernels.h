@@ -227,7 +227,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   }
   if (!valid) return;
   bf16* og = (bf16*)a.out;
-  const float gain = (a.epi == ONIRIS_EPI_EMB_SILU) ? *a.emb_gain : 0.f;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int n = (b * S + s) * T + tloc;
@@ -248,6 +247,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
           if constexpr (HAS_CTX) v[k] += cctx * accc[nt][4 * g + k];
         }
         if (a.epi == ONIRIS_EPI_MPSUM) {
+          if (a.out2) {                                   // keep the raw conv output (needed for d gate)
+            bf16x4 rawv;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) rawv[k] = f2bf(v[k]);
+            *(bf16x4*)((bf16*)a.out2 + obase + co) = rawv;
+          }
           const bf16x4 rv = *(const bf16x4*)((const bf16*)a.res + obase + co);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
@@ -260,6 +265,17 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) ov[k] = f2bf(v[k]);
         *(bf16x4*)(og + obase + co) = ov;
+        if (a.epi == ONIRIS_EPI_EMB_SILU) {
+          const float4 ev = *(const float4*)((const float*)a.escale + (size_t)n * a.Cout + co);
+          const float cvv[4] = {ev.x, ev.y, ev.z, ev.w};
+          bf16x4 uv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float z = bf2f(ov[k]) * cvv[k];
+            uv[k] = f2bf(z / (1.f + __expf(-z)) * (1.f / 0.596f));
+          }
+          *(bf16x4*)((bf16*)a.out2 + obase + co) = uv;
+        }
         if constexpr (HAS_CTX) {
           if (a.ctx_out && s == 0) {        // unscaled context product y3 (shared by both slots), kept for d(gate)
             bf16x4 cv;
@@ -267,16 +283,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
             for (int k = 0; k < 4; ++k) cv[k] = f2bf(accc[nt][4 * g + k]);
             *(bf16x4*)((bf16*)a.ctx_out + ((size_t)b * T * HWp + pix) * a.Cout + co) = cv;
           }
-        }
-        if (a.epi == ONIRIS_EPI_EMB_SILU) {
-          const bf16x4 ev = *(const bf16x4*)((const bf16*)a.escale + (size_t)n * a.Cout + co);
-          bf16x4 uv;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const float z = bf2f(ov[k]) * (1.f + gain * bf2f(ev[k]));
-            uv[k] = f2bf(z / (1.f + __expf(-z)) * (1.f / 0.596f));
-          }
-          *(bf16x4*)((bf16*)a.out2 + obase + co) = uv;
         }
       }
     }

@@ -1,0 +1,293 @@
+// Fused magnitude-preserving glue kernels (HBM-bound; 16-byte vector loads/stores, one pass each).
+// They replace the chains of elementwise ops of Block.forward (reference edm2/networks_edm2.py:62-94):
+//   act_fwd / act_bwd     mp_cat (utils.py:128-134) and/or pixel norm (utils.py:83-88) followed by mp_silu (:112)
+//   emb_silu_bwd          backward of  u = mp_silu(y * c[n,co])  (networks_edm2.py:75-77) incl. the per-(frame,
+//                         channel) reduction for c; the forward lives in the conv epilogue (ONIRIS_EPI_EMB_SILU)
+//   mpsum_bwd             backward of  out = clip(ta*res + tb*v) (networks_edm2.py:86,93), forward = conv epilogue
+//   resample_down/up      2x2 mean / nearest x2 (utils.py:94-107 with f=[1,1]) and their adjoints
+#include "common.h"
+#include "../../include/oniris.h"
+
+#define SILU_SCALE (1.0f / 0.596f)
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float dsilu_f(float z) {
+  const float sg = 1.f / (1.f + __expf(-z));
+  return sg * (1.f + z * (1.f - sg));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// v = concat(w1 * x[C1], w2 * skip[C2]) ; NORM: v <- v / (eps + |v|/sqrt(C)) ; xo = v ; a = silu(v)/0.596
+// one thread = 8 channels of one pixel; G = C/8 threads per pixel (NORM needs G to be a power of two <= 64)
+template <bool NORM>
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ skip,
+                                                      bf16* __restrict__ xo, bf16* __restrict__ a,
+                                                      float* __restrict__ sden, long long npix, int C1, int C2, float w1,
+                                                      float w2) {
+  const int C = C1 + C2, G = C >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long pix = gid / G;
+  const int cg = (int)(gid % G);
+  const bool ok = pix < npix;
+  float v[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  if (ok) {
+    const int c = cg * 8;
+    bf16x8 in;
+    float w;
+    if (c < C1) { in = *(const bf16x8*)(x + pix * C1 + c); w = w1; }
+    else { in = *(const bf16x8*)(skip + pix * C2 + (c - C1)); w = w2; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = bf2f(in[i]) * w;
+  }
+  if (NORM) {
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ss += v[i] * v[i];
+    for (int o = 1; o < G; o <<= 1) ss += __shfl_xor(ss, o);
+    const float s = 1e-4f + sqrtf(ss) * rsqrtf((float)C);
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] *= inv;
+    if (ok && cg == 0 && sden) sden[pix] = s;
+  }
+  if (!ok) return;
+  bf16x8 o, av;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    o[i] = f2bf(v[i]);
+    av[i] = f2bf(silu_f(bf2f(o[i])) * SILU_SCALE);
+  }
+  if (xo) *(bf16x8*)(xo + pix * C + cg * 8) = o;
+  *(bf16x8*)(a + pix * C + cg * 8) = av;
+}
+
+// g = dxo + da * silu'(xo)/0.596 ; NORM: g <- (g - xo * sum(g*xo) * k) / s ; dx = w1*g[:C1], dskip = w2*g[C1:]
+template <bool NORM>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ da, const bf16* __restrict__ dxo,
+                                                      const bf16* __restrict__ xo, const float* __restrict__ sden,
+                                                      bf16* __restrict__ dx, bf16* __restrict__ dskip, long long npix,
+                                                      int C1, int C2, float w1, float w2) {
+  const int C = C1 + C2, G = C >> 3;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long pix = gid / G;
+  const int cg = (int)(gid % G);
+  const bool ok = pix < npix;
+  float g[8], xv[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { g[i] = 0.f; xv[i] = 0.f; }
+  if (ok) {
+    const bf16x8 xin = *(const bf16x8*)(xo + pix * C + cg * 8);
+    const bf16x8 dain = *(const bf16x8*)(da + pix * C + cg * 8);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { xv[i] = bf2f(xin[i]); g[i] = bf2f(dain[i]) * dsilu_f(xv[i]) * SILU_SCALE; }
+    if (dxo) {
+      const bf16x8 d2 = *(const bf16x8*)(dxo + pix * C + cg * 8);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[i] += bf2f(d2[i]);
+    }
+  }
+  if (NORM) {
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dot += g[i] * xv[i];
+    for (int o = 1; o < G; o <<= 1) dot += __shfl_xor(dot, o);
+    const float s = ok ? sden[pix] : 1.f;
+    // xn = x/s, s = eps + n/sqrt(C):  dx = (g - xn * sum(g*xn) * s / (n*sqrt(C))) / s,   n/sqrt(C) = s - eps,  n*sqrt(C) = C*(s-eps)
+    const float nsc = (s - 1e-4f) * (float)C;
+    const float k = (nsc > 0.f) ? dot * s / nsc : 0.f;
+    const float inv = 1.f / s;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) g[i] = (g[i] - xv[i] * k) * inv;
+  }
+  if (!ok) return;
+  const int c = cg * 8;
+  bf16x8 o;
+  if (c < C1) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w1);
+    *(bf16x8*)(dx + pix * C1 + c) = o;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w2);
+    *(bf16x8*)(dskip + pix * C2 + (c - C1)) = o;
+  }
+}
+
+extern "C" int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sden, int64_t npix, int C1,
+                              int C2, float w1, float w2, int norm, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int C = C1 + C2;
+  ONIRIS_CHECK_ARG(x && a && npix > 0 && C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || skip),
+                   "act_fwd: bad arguments");
+  ONIRIS_CHECK_ARG(!norm || ((C / 8) <= 64 && ((C / 8) & (C / 8 - 1)) == 0 && sden), "act_fwd: pixel norm needs C/8 = 2^k <= 64");
+  const long long nthr = npix * (C / 8);
+  const dim3 grid((unsigned)((nthr + 255) / 256));
+  if (norm) hipLaunchKernelGGL(act_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2);
+  else hipLaunchKernelGGL(act_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
+                              int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  const int C = C1 + C2;
+  ONIRIS_CHECK_ARG(da && xo && dx && npix > 0 && C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || dskip),
+                   "act_bwd: bad arguments");
+  ONIRIS_CHECK_ARG(!norm || ((C / 8) <= 64 && ((C / 8) & (C / 8 - 1)) == 0 && sden), "act_bwd: pixel norm needs C/8 = 2^k <= 64");
+  const long long nthr = npix * (C / 8);
+  const dim3 grid((unsigned)((nthr + 255) / 256));
+  if (norm) hipLaunchKernelGGL(act_bwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (long long)npix, C1, C2, w1, w2);
+  else hipLaunchKernelGGL(act_bwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (long long)npix, C1, C2, w1, w2);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// u = silu(y*c)/0.596:  dz = du*silu'(y*c)/0.596 ; dy = dz*c ; dc[n][co] += sum_pixels dz*y
+// grid = (frames, pixel slices); threads: channel group = tid % G, pixel lane = tid / G
+__global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restrict__ du, const bf16* __restrict__ y,
+                                                           const float* __restrict__ c, bf16* __restrict__ dy,
+                                                           float* __restrict__ dc, int P, int C, int pix_per_block) {
+  __shared__ float acc[512];
+  const int n = blockIdx.x, G = C >> 3;
+  const int cg = threadIdx.x % G, pl = threadIdx.x / G, npl = 256 / G;
+  for (int i = threadIdx.x; i < C; i += 256) acc[i] = 0.f;
+  __syncthreads();
+  float cv[8], part[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { cv[i] = 0.f; part[i] = 0.f; }
+  if (pl < npl) {
+    const float4 c0 = *(const float4*)(c + (size_t)n * C + cg * 8), c1 = *(const float4*)(c + (size_t)n * C + cg * 8 + 4);
+    cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
+    const int p0 = blockIdx.y * pix_per_block;
+    const int p1 = min(P, p0 + pix_per_block);
+    for (int p = p0 + pl; p < p1; p += npl) {
+      const size_t off = ((size_t)n * P + p) * C + cg * 8;
+      const bf16x8 duv = *(const bf16x8*)(du + off), yv = *(const bf16x8*)(y + off);
+      bf16x8 o;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const float yy = bf2f(yv[i]);
+        const float dz = bf2f(duv[i]) * dsilu_f(yy * cv[i]) * SILU_SCALE;
+        o[i] = f2bf(dz * cv[i]);
+        part[i] += dz * yy;
+      }
+      *(bf16x8*)(dy + off) = o;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) atomicAdd(&acc[cg * 8 + i], part[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) atomicAdd(dc + (size_t)n * C + i, acc[i]);
+}
+
+extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P,
+                                   int C, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(du && y && c && dy && dc && N > 0 && P > 0 && C > 0 && C % 8 == 0 && C <= 512,
+                   "emb_silu_bwd: bad arguments (C %% 8 == 0, C <= 512)");
+  int slices = 1;
+  const int npl = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
+  while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < 2048) slices *= 2;
+  const int ppb = cdiv(P, slices);
+  hipMemsetAsync(dc, 0, sizeof(float) * (size_t)N * C, stream);
+  hipLaunchKernelGGL(emb_silu_bwd_kernel, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
+                     (bf16*)dy, dc, P, C, ppb);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// out = clip(ta*res + tb*v): given g = d out  ->  dres = ta*g*[|out|<clip], dv = tb*g*[|out|<clip]
+__global__ void mpsum_bwd_kernel(const bf16* __restrict__ g, const bf16* __restrict__ out, bf16* __restrict__ dres,
+                                 bf16* __restrict__ dv, size_t n8, float ta, float tb, float clip) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    const bf16x8 gv = *(const bf16x8*)(g + i * 8);
+    bf16x8 a, b;
+    if (clip > 0.f) {
+      const bf16x8 ov = *(const bf16x8*)(out + i * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const float gg = (fabsf(bf2f(ov[k])) < clip) ? bf2f(gv[k]) : 0.f;
+        a[k] = f2bf(gg * ta); b[k] = f2bf(gg * tb);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float gg = bf2f(gv[k]); a[k] = f2bf(gg * ta); b[k] = f2bf(gg * tb); }
+    }
+    *(bf16x8*)(dres + i * 8) = a;
+    *(bf16x8*)(dv + i * 8) = b;
+  }
+}
+
+extern "C" int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv, int64_t numel, float ta, float tb,
+                                float clip, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(g && dres && dv && numel > 0 && numel % 8 == 0 && (clip <= 0.f || out), "mpsum_bwd: bad arguments");
+  const size_t n8 = (size_t)numel / 8;
+  size_t nb = (n8 + 255) / 256;
+  if (nb > 8192) nb = 8192;
+  hipLaunchKernelGGL(mpsum_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
+                     (bf16*)dres, (bf16*)dv, n8, ta, tb, clip);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// resample: mode 0: out[n][y][x] = mean of the 2x2 input block (H,W = INPUT size);  mode 1: nearest x2 (H,W = INPUT size)
+// `scale` multiplies the result (adjoints: down^T = 0.25 * up, up^T = 4 * down -> pass scale accordingly)
+__global__ void resample_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, long long nout8, int H, int W, int C,
+                                int mode, float scale) {
+  const int G = C >> 3;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nout8; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    long long p = i / G;
+    float v[8];
+    if (mode == 0) {
+      const int Wo = W >> 1, Ho = H >> 1;
+      const int xo = (int)(p % Wo); p /= Wo;
+      const int yo = (int)(p % Ho); const long long n = p / Ho;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = 0.f;
+#pragma unroll
+      for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+          const bf16x8 a = *(const bf16x8*)(in + ((n * H + 2 * yo + dy) * W + 2 * xo + dx) * C + cg * 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += bf2f(a[k]);
+        }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] *= 0.25f * scale;
+    } else {
+      const int Wo = W << 1, Ho = H << 1;
+      const int xo = (int)(p % Wo); p /= Wo;
+      const int yo = (int)(p % Ho); const long long n = p / Ho;
+      const bf16x8 a = *(const bf16x8*)(in + ((n * H + (yo >> 1)) * W + (xo >> 1)) * C + cg * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = bf2f(a[k]) * scale;
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
+    *(bf16x8*)(out + i * 8) = o;
+  }
+}
+
+extern "C" int oniris_resample(const void* in, void* out, int64_t N, int H, int W, int C, int mode, float scale,
+                               oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && C % 8 == 0 && (mode == 1 || (H % 2 == 0 && W % 2 == 0)),
+                   "resample: bad arguments");
+  const long long npix_out = (mode == 0) ? N * (H / 2) * (W / 2) : N * (H * 2LL) * (W * 2);
+  const long long n8 = npix_out * (C / 8);
+  long long nb = (n8 + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out, n8, H, W, C,
+                     mode, scale);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}

@@ -167,10 +167,12 @@ extern "C" int oniris_adamw(float* p, const float* g, float* m, float* v, size_t
 
 // ---------------------------------------------------------------------------------------------------------------
 // Backward pre-pass of the gated conv (one pass over dout): per frame-slot n
-//   S1[n] = sum dout*out, S2[n] = sum dout*y3   (-> d gate),   dy3[b,t] = cb[b,0,t]*dout[b,0,t] + cb[b,1,t]*dout[b,1,t]
+//   S1[n] = sum dout*out, S2[n] = sum dout*y3,  d ca[n] = (S1 - cb*S2)/ca  (= sum dout*y2),  d cb[n] = S2,
+//   dy3[b,t] = cb[b,0,t]*dout[b,0,t] + cb[b,1,t]*dout[b,1,t]
 // dout/out [B][S][T][PC], y3/dy3 [B][T][PC].  grid = B*T frames, HBM-bound, 16 B/lane loads.
 __global__ __launch_bounds__(256) void gconv_bwd_prep_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out,
-                                                             const bf16* __restrict__ y3, const float* __restrict__ cb,
+                                                             const bf16* __restrict__ y3, const float* __restrict__ ca,
+                                                             const float* __restrict__ cb,
                                                              float* __restrict__ S1, float* __restrict__ S2,
                                                              bf16* __restrict__ dy3, int S, int T, size_t PC) {
   __shared__ float red[16];
@@ -206,18 +208,19 @@ __global__ __launch_bounds__(256) void gconv_bwd_prep_kernel(const bf16* __restr
   }
   for (int s = 0; s < S; ++s) {
     const float a = block_sum(s1[s], red), bsum = block_sum(s2[s], red);
-    if (threadIdx.x == 0) { const size_t n = (size_t)(b * S + s) * T + t; S1[n] = a; S2[n] = bsum; }
+    if (threadIdx.x == 0) { const size_t n = (size_t)(b * S + s) * T + t; S1[n] = (a - cb[n] * bsum) / ca[n]; S2[n] = bsum; }
   }
 }
 
-extern "C" int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_ctx,
-                                     float* S1, float* S2, void* dy3, int B, int S, int T, int64_t frame_elems,
+extern "C" int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_own,
+                                     const float* coef_ctx, float* S1, float* S2, void* dy3, int B, int S, int T,
+                                     int64_t frame_elems,
                                      oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ONIRIS_CHECK_ARG(dout && out && y3 && coef_ctx && S1 && S2 && dy3 && B > 0 && T > 0 && (S == 1 || S == 2) &&
+  ONIRIS_CHECK_ARG(dout && out && y3 && coef_own && coef_ctx && S1 && S2 && dy3 && B > 0 && T > 0 && (S == 1 || S == 2) &&
                    frame_elems > 0 && frame_elems % 8 == 0, "gconv_bwd_prep: bad arguments");
   hipLaunchKernelGGL(gconv_bwd_prep_kernel, dim3(B * T), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)out,
-                     (const bf16*)y3, coef_ctx, S1, S2, (bf16*)dy3, S, T, (size_t)frame_elems);
+                     (const bf16*)y3, coef_own, coef_ctx, S1, S2, (bf16*)dy3, S, T, (size_t)frame_elems);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -102,6 +102,25 @@ class Gating(nn.Module):
         return lo + (1 - lo) * hi * torch.sigmoid(sv), n_context_frames + T
 
 
+def batched_gates(convs, c_noise, caches, training):
+    """All Gating modules of a net in ONE vectorised evaluation (identical math to Gating.forward, conv.py:113-127):
+    replaces ~60 x 20 tiny elementwise launches per step by ~20.  Returns per-layer (ca, cb, n_new)."""
+    B, tt = c_noise.shape
+    T = tt // 2 if training else tt
+    dev = c_noise.device
+    n_ctx = [int(c.get("n_context_frames", 0)) if c else 0 for c in caches]
+    mult = torch.stack([m.gating.mult for m in convs])            # (L,2)
+    off = torch.stack([m.gating.offset for m in convs])           # (L,2)
+    lo = torch.sigmoid(torch.stack([m.gating.min_gating for m in convs]))[:, None, None]
+    hi = torch.sigmoid(torch.stack([m.gating.max_gating for m in convs]))[:, None, None]
+    base = (torch.arange(B * tt, device=dev) % T).reshape(1, B, tt)
+    pos = (base + torch.tensor(n_ctx, device=dev).reshape(-1, 1, 1)).to(c_noise.dtype).log1p()
+    sv = c_noise[None] * mult[:, 0, None, None] + off[:, 0, None, None] + pos * mult[:, 1, None, None] + off[:, 1, None, None]
+    g = (lo + (1 - lo) * hi * torch.sigmoid(sv)).reshape(len(convs), -1)
+    ca, cb = ops.gate_coefs(g)
+    return [(a, b, n + T) for a, b, n in zip(ca.unbind(0), cb.unbind(0), n_ctx)]
+
+
 class MPCausal3DGatedConv(nn.Module):
     def __init__(self, in_channels, out_channels, kernel):
         super().__init__()
@@ -112,20 +131,27 @@ class MPCausal3DGatedConv(nn.Module):
         self.weight = NormalizedWeight(in_channels, out_channels, (kernel[0] - 1, kernel[1], kernel[2]))
         self.gating = Gating()
 
-    def _cl(self, x, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
-        """x (B*t, H, W, C) bf16 -> (y, cache).  cache['activations'] is (B, 2, H, W, C) bf16."""
+    def _cl(self, x, batch_size, c_noise, cache=None, update_cache=False, just_2d=False, **epi):
+        """x (B*t, H, W, C) bf16 -> (y, cache).  cache['activations'] is (B, 2, H, W, C) bf16.
+        **epi: fused epilogue, either cscale=(N,Cout) fp32 [silu(y*cscale)/0.596] or res/ta/tb/clip [mp_sum+clip]."""
         if just_2d:
-            return self.last_frame_conv._cl(x), cache
+            self.__dict__.pop("_gate_pre", None)
+            return ops.conv(x, self.last_frame_conv.weight.pw, **epi), cache
         if cache is None:
             cache = {}
-        gate, n_new = self.gating(c_noise.float(), cache.get("n_context_frames", 0))
+        pre = self.__dict__.pop("_gate_pre", None)            # (ca, cb, n_new) batched by UNet.forward for all layers
+        if pre is not None:
+            coefs, gate, n_new = (pre[0], pre[1]), None, pre[2]
+        else:
+            gate, n_new = self.gating(c_noise.float(), cache.get("n_context_frames", 0))
+            gate, coefs = gate.reshape(-1), None
         if update_cache:
             cache["n_context_frames"] = n_new
         N, H, W, C = x.shape
         pw2, pw3 = self.last_frame_conv.weight.pw, self.weight.pw
         if self.training:
             T = N // (2 * batch_size)
-            return ops.gated_conv_train(x, gate.reshape(-1), pw2, pw3, batch_size, T), cache
+            return ops.gated_conv_train(x, gate, pw2, pw3, batch_size, T, coefs, **epi), cache
         t = N // batch_size
         pad = cache.get("activations")
         if pad is None:
@@ -133,7 +159,7 @@ class MPCausal3DGatedConv(nn.Module):
         ctx = torch.cat([pad, x.reshape(batch_size, t, H, W, C)], dim=1).contiguous()
         if update_cache:
             cache["activations"] = ctx[:, -2:].clone()
-        return ops.gated_conv_eval(x, gate.reshape(-1), pw2, pw3, batch_size, t, ctx), cache
+        return ops.gated_conv_eval(x, gate, pw2, pw3, batch_size, t, ctx, coefs, **epi), cache
 
     def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
         with weights_ready(self):

@@ -9,9 +9,10 @@ import torch
 from torch import nn
 import torch.nn.functional as F
 
+from .. import ops
 from .loss_weight import MultiNoiseLoss
 from .utils import (BetterModule, MPFourier, mp_silu, mp_sum, mp_cat_cl, normalize_cl, resample_cl, to_cl, from_cl, BF16)
-from .conv import MPConv, MPCausal3DGatedConv, Gating, weights_ready
+from .conv import MPConv, MPCausal3DGatedConv, Gating, weights_ready, batched_gates
 from .attention import FrameAttention, VideoAttention
 
 
@@ -35,27 +36,40 @@ class Block(nn.Module):
         else:
             self.attn = FrameAttention(out_channels, self.num_heads, attn_balance)
 
-    def _cl(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
-        """x (N,H,W,C) bf16, emb (N,1,1,cemb) bf16."""
+    def _cl(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False, skip=None, cat_w=None):
+        """x (N,H,W,C) bf16, emb (N,1,1,cemb) bf16; skip/cat_w: the decoder's mp_cat operand, fused into the first
+        activation kernel.  Elementwise chains of the reference's Block.forward (:62-94) run as fused HIP kernels:
+        [mp_cat | pixel norm] + mp_silu -> act;  *c + mp_silu -> conv_res0 epilogue;  mp_sum (+clip) -> conv_res1 /
+        attn_proj epilogue."""
         if cache is None:
             cache = {}
-        x = resample_cl(x, self.resample_mode)
+        x = ops.resample(x, self.resample_mode)
         if self.flavor == "enc":
             if self.conv_skip is not None:
                 x = self.conv_skip._cl(x)
-            x = normalize_cl(x)
-        y, cache["conv_res0"] = self.conv_res0._cl(mp_silu(x), batch_size, c_noise, cache.get("conv_res0"),
-                                                   update_cache, just_2d)
-        c = self.emb_linear._cl(emb) * self.emb_gain.to(BF16) + 1            # (N,1,1,Cout)
-        y = mp_silu(y * c)
+            x, a = ops.act(x, norm=True)                                   # x <- pixel norm(x); a = mp_silu(x)
+        elif skip is not None:
+            x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True)      # x <- mp_cat(x, skip); a = mp_silu(x)
+        else:
+            a = ops.act(x)
+        N = x.shape[0]
+        c = (self.emb_linear._cl(emb).reshape(N, -1).float() * self.emb_gain + 1)      # (N, Cout) fp32
+        y, cache["conv_res0"] = self.conv_res0._cl(a, batch_size, c_noise, cache.get("conv_res0"), update_cache,
+                                                   just_2d, cscale=c)    # y = mp_silu(conv(a) * c)
         if self.training and self.dropout != 0:
             y = F.dropout(y, p=self.dropout)
-        y, cache["conv_res1"] = self.conv_res1._cl(y, batch_size, c_noise, cache.get("conv_res1"), update_cache, just_2d)
         if self.flavor == "dec" and self.conv_skip is not None:
             x = self.conv_skip._cl(x)
-        x = mp_sum(x, y, self.res_balance)
+        t = self.res_balance
+        den = 1.0 / math.sqrt((1 - t) ** 2 + t ** 2)
         clip = float(self.clip_act) if self.clip_act is not None else 0.0
-        x, cache["attn"] = self.attn._cl(x, batch_size, cache.get("attn"), update_cache, just_2d, clip=clip)
+        x, cache["conv_res1"] = self.conv_res1._cl(y, batch_size, c_noise, cache.get("conv_res1"), update_cache, just_2d,
+                                                   res=x, ta=(1 - t) * den, tb=t * den,
+                                                   clip=clip if self.num_heads == 0 else 0.0)
+        if self.num_heads > 0:
+            x, cache["attn"] = self.attn._cl(x, batch_size, cache.get("attn"), update_cache, just_2d, clip=clip)
+        else:
+            cache["attn"] = None
         return x, cache
 
     def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
@@ -142,6 +156,8 @@ class UNet(BetterModule):
             xc = x.reshape(N, *x.shape[2:])
             xc = torch.cat([xc, torch.ones_like(xc[:, :1])], dim=1)
             xcl = to_cl(xc, pad_to=-(-xc.shape[1] // 16) * 16)
+            if not just_2d:
+                self._prime_gates(c_noise, cache)
             skips = []
             for name, block in self.enc.items():
                 if isinstance(block, Block):
@@ -150,13 +166,36 @@ class UNet(BetterModule):
                     xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
                 skips.append(xcl)
             for name, block in self.dec.items():
-                if "block" in name:
-                    xcl = mp_cat_cl(xcl, skips.pop(), t=self.concat_balance)
-                xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d)
+                skip, cat_w = None, None
+                if "block" in name:                                   # mp_cat(x, skip, t) fused into the block's act kernel
+                    skip = skips.pop()
+                    Na, Nb, t = xcl.shape[-1], skip.shape[-1], self.concat_balance
+                    Cn = math.sqrt((Na + Nb) / ((1 - t) ** 2 + t ** 2))
+                    cat_w = (Cn / math.sqrt(Na) * (1 - t), Cn / math.sqrt(Nb) * t)
+                xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d,
+                                                    skip=skip, cat_w=cat_w)
             xcl, cache["out_conv"] = self.out_conv._cl(xcl, B, c_noise, cache.get("out_conv"), update_cache, just_2d)
             out = from_cl(xcl[..., :self.img_channels], torch.float32)
             out = out.reshape(B, tt, *out.shape[1:]) * self.out_gain
             return out, cache
+
+    def _prime_gates(self, c_noise, cache):
+        """Evaluate the gates of all gated convs at once and hand each layer its (ca, cb, counter)."""
+        convs, caches = [], []
+
+        def visit(mod, c):
+            if isinstance(mod, MPCausal3DGatedConv):
+                convs.append(mod); caches.append(c)
+            else:
+                c = c or {}
+                convs.extend([mod.conv_res0, mod.conv_res1]); caches.extend([c.get("conv_res0"), c.get("conv_res1")])
+        for name, block in self.enc.items():
+            visit(block, cache.get(("enc", name)))
+        for name, block in self.dec.items():
+            visit(block, cache.get(("dec", name)))
+        visit(self.out_conv, cache.get("out_conv"))
+        for m, pre in zip(convs, batched_gates(convs, c_noise, caches, self.training)):
+            m.__dict__["_gate_pre"] = pre
 
     def no_sync(self):
         return nullcontext()

@@ -275,131 +275,250 @@ def _wgrad_launch(x, dy, dwp, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, x
     check(lib.oniris_conv_wgrad(ctypes.byref(a), _stream()), "conv_wgrad")
 
 
-class _ConvFn(torch.autograd.Function):
-    """y = conv(x, W) for a 1x1 / 3x3 MPConv (no context path).  x (N,H,W,Cin) bf16.  The weight gradient is
-    accumulated into the bank's packed fp32 buffer (side effect); WeightBank.backward() finishes it."""
+class ConvCfg:
+    """Static configuration of one conv op (not a tensor: passed through autograd untouched)."""
+    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad")
+
+    def __init__(self, pw2, pw3=None, B=1, T=1, epi="none", ta=0.0, tb=0.0, clip=0.0, need_grad=True):
+        self.pw2, self.pw3, self.B, self.T = pw2, pw3, B, T
+        self.epi, self.ta, self.tb, self.clip, self.need_grad = epi, ta, tb, clip, need_grad
+
+
+class _ConvOp(torch.autograd.Function):
+    """One fused conv op on channels-last bf16 activations.
+
+    plain  (cfg.pw3 None):  v = conv(x, W2)                                      x (N,H,W,Cin)
+    gated  (training DART layout, slot order (b s t), N = B*2*T; edm2/conv.py:59-95):
+                            v = ca[n]*conv2d(x[n]) + cb[n]*(conv(clean[t-2]) + conv(clean[t-1])), ones-padded in time
+    epilogue 'none': returns v; 'emb_silu': returns silu(v*cscale[n,co])/0.596 (v kept for the backward);
+             'mpsum': returns clip(ta*res + tb*v).
+    The weight Parameters are inputs only so that autograd always schedules the node; their gradients are
+    accumulated into the bank's packed fp32 buffers (WeightBank.backward() finishes them)."""
 
     @staticmethod
-    def forward(ctx, x, wparam, pw, epi_res, ta, tb, clip):
-        # `wparam` (the fp32 Parameter) is an input only so that autograd schedules this node even when x needs
-        # no gradient; its gradient is accumulated out-of-band (packed dwp buffer -> WeightBank.backward()).
+    def forward(ctx, x, w2param, w3param, ca, cb, cscale, res, cfg):
         _need_gpu(x)
+        pw2, pw3 = cfg.pw2, cfg.pw3
+        gated = pw3 is not None
         N, H, W, Cin = x.shape
-        assert Cin == pw.cin or (Cin >= pw.cin and Cin % 8 == 0), (Cin, pw.cin)
-        taps = pw.taps
-        Co = roundup(pw.cout, 8)                      # channel counts in HBM are multiples of 8 (16-byte vectors)
-        out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
-        if epi_res is not None:
-            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, Co, pw.CoutP, taps,
-                         epi=_lib.EPI_MPSUM, res=epi_res, ta=ta, tb=tb, clip=clip)
-        else:
-            _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, Co, pw.CoutP, taps)
-        ctx.pw, ctx.scal = pw, (ta, tb, clip, epi_res is not None)
-        ctx.save_for_backward(x, out if (epi_res is not None and clip > 0) else None)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, out = ctx.saved_tensors
-        pw = ctx.pw
-        ta, tb, clip, has_res = ctx.scal
-        dout = dout.contiguous()
-        dres = None
-        if has_res:
-            if clip > 0:
-                dout = dout * (out.abs() < clip)      # clamp passes the gradient strictly inside the range
-            dres = dout * ta
-            dout = dout * tb
-        N, H, W, Cin = x.shape
-        Co = dout.shape[-1]
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            _conv_launch(dout, None, pw.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw.CinPb, Cin, pw.CoutPb,
-                         pw.taps)
-        if pw.param.requires_grad:
-            _wgrad_launch(x, dout, pw.dwp, None, 1, N, H, W, Cin, pw.CinP, Co, pw.CoutP, pw.taps, N, N, 0, 0.0)
-            pw.bank.request_finish()
-        return dx, None, None, dres, None, None, None
-
-
-def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0):
-    """MPConv forward on packed weights; optional fused epilogue out = clip(ta*res + tb*conv(x))."""
-    return _ConvFn.apply(x, pw.param, pw, res, ta, tb, clip)
-
-
-class _GatedConvFn(torch.autograd.Function):
-    """Training-mode MPCausal3DGatedConv (edm2/conv.py:59-95) on the DART layout: x (B*2*T,H,W,Cin), slot order
-    (b s t).  out = ca[n]*conv2d(x[n]) + cb[n]*(conv(clean[t-2]) + conv(clean[t-1])), ones-padded in time."""
-
-    @staticmethod
-    def forward(ctx, x, ca, cb, w2param, w3param, pw2, pw3, B, T, need_grad):
-        _need_gpu(x, ca, cb)
-        N, H, W, Cin = x.shape
-        assert N == B * 2 * T
-        Co = roundup(pw2.cout, 8)
-        out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
-        y3 = torch.empty((B * T, H, W, Co), dtype=BF16, device=x.device) if need_grad else None
-        ca32, cb32 = ca.detach().float().contiguous(), cb.detach().float().contiguous()
-        _conv_launch(x, x, pw2.wf, pw3.wf, out, ca32, cb32, B, 2, T, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
-                     ctx_bstride=2 * T, ctx_T=T, coff=(-2, -1), ctx_fill=1.0, ctx_out=y3)
-        ctx.pws, ctx.dims = (pw2, pw3), (B, T)
-        ctx.save_for_backward(x, out, y3, ca32, cb32)
-        return out
-
-    @staticmethod
-    def backward(ctx, dout):
-        x, out, y3, ca, cb = ctx.saved_tensors
-        pw2, pw3 = ctx.pws
-        B, T = ctx.dims
-        N, H, W, Cin = x.shape
-        Cout = out.shape[-1]
-        dout = dout.contiguous()
+        Co = roundup(pw2.cout, 8)                       # channel counts in HBM are multiples of 8 (16-byte vectors)
         dev = x.device
-        S1 = torch.empty(N, dtype=torch.float32, device=dev)
-        S2 = torch.empty(N, dtype=torch.float32, device=dev)
-        dy3 = torch.empty_like(y3)
-        check(lib.oniris_gconv_bwd_prep(_p(dout), _p(out), _p(y3), _p(cb), _p(S1), _p(S2), _p(dy3), B, 2, T,
-                                        H * W * Cout, _stream()), "gconv_bwd_prep")
-        dx = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            sel = torch.zeros(B, 2, T, dtype=torch.float32, device=dev)
-            sel[:, 0] = 1.0                                    # the context gradient only reaches the clean slot
-            _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca, sel.reshape(-1), B, 2, T, H, W, Cout, pw2.CinPb, Cin,
-                         pw2.CoutPb, 9, ctx_bstride=T, ctx_T=T, coff=(2, 1), ctx_fill=0.0)
-        if pw2.param.requires_grad:
-            _wgrad_launch(x, dout, pw2.dwp, ca, 1, N, H, W, Cin, pw2.CinP, Cout, pw2.CoutP, 9, N, N, 0, 0.0)
-        if pw3.param.requires_grad:
-            per = 9 * pw3.CoutP * pw3.CinP
-            for j, coff in enumerate((-2, -1)):
-                _wgrad_launch(x, dy3, pw3.dwp[j * per:], None, B, T, H, W, Cin, pw3.CinP, Cout, pw3.CoutP, 9, 2 * T, T,
-                              coff, 1.0)
-        if pw2.param.requires_grad or pw3.param.requires_grad:
+        kw = {}
+        raw = torch.empty((N, H, W, Co), dtype=BF16, device=dev)
+        ret = raw
+        if cfg.epi == "emb_silu":
+            cs = cscale.detach().float().contiguous()
+            assert tuple(cs.shape) == (N, Co), (cs.shape, N, Co)
+            ret = torch.empty_like(raw)
+            kw = dict(epi=_lib.EPI_EMB_SILU, escale=cs, out2=ret)
+        elif cfg.epi == "mpsum":
+            keep_raw = gated and cfg.need_grad
+            ret = torch.empty_like(raw)
+            kw = dict(epi=_lib.EPI_MPSUM, res=res, ta=cfg.ta, tb=cfg.tb, clip=cfg.clip, out2=raw if keep_raw else None)
+            if not keep_raw:
+                raw = None
+        y3 = ca32 = cb32 = None
+        first_out = ret if cfg.epi == "mpsum" else (raw if raw is not None else ret)
+        if gated:
+            B, T = cfg.B, cfg.T
+            assert N == B * 2 * T
+            y3 = torch.empty((B * T, H, W, Co), dtype=BF16, device=dev) if cfg.need_grad else None
+            ca32, cb32 = ca.detach().float().contiguous(), cb.detach().float().contiguous()
+            _conv_launch(x, x, pw2.wf, pw3.wf, first_out, ca32, cb32, B, 2, T, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
+                         ctx_bstride=2 * T, ctx_T=T, coff=(-2, -1), ctx_fill=1.0, ctx_out=y3, **kw)
+        else:
+            _conv_launch(x, None, pw2.wf, None, first_out, None, None, 1, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP,
+                         pw2.taps, **kw)
+        ctx.cfg = cfg
+        ctx.save_for_backward(x, raw, y3, ca32, cb32, cscale.detach().float().contiguous() if cfg.epi == "emb_silu" else None,
+                              ret if (cfg.epi == "mpsum" and cfg.clip > 0) else None)
+        return ret
+
+    @staticmethod
+    def backward(ctx, g):
+        x, raw, y3, ca, cb, cs, xo = ctx.saved_tensors
+        cfg = ctx.cfg
+        pw2, pw3 = cfg.pw2, cfg.pw3
+        gated = pw3 is not None
+        N, H, W, Cin = x.shape
+        g = g.contiguous()
+        Co = g.shape[-1]
+        dev = x.device
+        dcs = dres = None
+        if cfg.epi == "emb_silu":
+            dout = torch.empty_like(g)
+            dcs = torch.empty((N, Co), dtype=torch.float32, device=dev)
+            check(lib.oniris_emb_silu_bwd(_p(g), _p(raw), _p(cs), _p(dout), _p(dcs), N, H * W, Co, _stream()), "emb_silu_bwd")
+        elif cfg.epi == "mpsum":
+            dres, dout = torch.empty_like(g), torch.empty_like(g)
+            check(lib.oniris_mpsum_bwd(_p(g), _p(xo), _p(dres), _p(dout), g.numel(), cfg.ta, cfg.tb, cfg.clip, _stream()),
+                  "mpsum_bwd")
+        else:
+            dout = g
+        dx = dca = dcb = None
+        if gated:
+            B, T = cfg.B, cfg.T
+            dca = torch.empty(N, dtype=torch.float32, device=dev)
+            dcb = torch.empty(N, dtype=torch.float32, device=dev)
+            dy3 = torch.empty_like(y3)
+            check(lib.oniris_gconv_bwd_prep(_p(dout), _p(raw), _p(y3), _p(ca), _p(cb), _p(dca), _p(dcb), _p(dy3), B, 2, T,
+                                            H * W * Co, _stream()), "gconv_bwd_prep")
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                sel = _clean_selector(B, T, dev)               # the context gradient only reaches the clean slot
+                _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca, sel, B, 2, T, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb, 9,
+                             ctx_bstride=T, ctx_T=T, coff=(2, 1), ctx_fill=0.0)
+            if pw2.param.requires_grad:
+                _wgrad_launch(x, dout, pw2.dwp, ca, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0)
+            if pw3.param.requires_grad:
+                per = 9 * pw3.CoutP * pw3.CinP
+                for j, coff in enumerate((-2, -1)):
+                    _wgrad_launch(x, dy3, pw3.dwp[j * per:], None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T,
+                                  coff, 1.0)
+        else:
+            if ctx.needs_input_grad[0]:
+                dx = torch.empty_like(x)
+                _conv_launch(dout, None, pw2.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
+                             pw2.taps)
+            if pw2.param.requires_grad:
+                _wgrad_launch(x, dout, pw2.dwp, None, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
+        if pw2.param.requires_grad or (gated and pw3.param.requires_grad):
             pw2.bank.request_finish()
-        # out = ca*y2 + cb*y3  ->  d ca = sum(dout*y2) = (S1 - cb*S2)/ca ,  d cb = S2
-        dca = (S1 - cb * S2) / ca
-        return dx, dca, S2, None, None, None, None, None, None, None
+        return dx, None, None, dca, dcb, dcs, dres, None
 
 
-def gated_conv_train(x, gate, pw2, pw3, B, T):
-    """gate: (B*2*T,) fp32 (autograd tensor from Gating).  mp_sum(y2, y3, g) coefficients in torch (tiny)."""
+_sel_cache = {}
+
+
+def _clean_selector(B, T, dev):
+    key = (B, T, str(dev))
+    if key not in _sel_cache:
+        sel = torch.zeros(B, 2, T, dtype=torch.float32, device=dev)
+        sel[:, 0] = 1.0
+        _sel_cache[key] = sel.reshape(-1)
+    return _sel_cache[key]
+
+
+def gate_coefs(gate):
+    """mp_sum(y2, y3, g) = ca*y2 + cb*y3 with ca = (1-g)/sqrt((1-g)^2+g^2), cb = g/sqrt(...)  (utils.py:118-123)."""
     den = torch.rsqrt((1 - gate) ** 2 + gate ** 2)
-    return _GatedConvFn.apply(x, (1 - gate) * den, gate * den, pw2.param, pw3.param, pw2, pw3, B, T,
-                              torch.is_grad_enabled())
+    return (1 - gate) * den, gate * den
+
+
+def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None):
+    """MPConv forward on packed weights.  Optional fused epilogues: res -> clip(ta*res + tb*conv(x));
+    cscale (N,Cout) fp32 -> silu(conv(x)*cscale)/0.596."""
+    epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
+    cfg = ConvCfg(pw, None, epi=epi, ta=ta, tb=tb, clip=clip, need_grad=torch.is_grad_enabled())
+    return _ConvOp.apply(x, pw.param, None, None, None, cscale, res, cfg)
+
+
+def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None):
+    """Training-mode MPCausal3DGatedConv.  gate: (B*2*T,) fp32 autograd tensor, or precomputed coefs=(ca, cb)."""
+    ca, cb = coefs if coefs is not None else gate_coefs(gate)
+    epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
+    cfg = ConvCfg(pw2, pw3, B, T, epi, ta, tb, clip, torch.is_grad_enabled())
+    return _ConvOp.apply(x, pw2.param, pw3.param, ca, cb, cscale, res, cfg)
 
 
 @torch.no_grad()
-def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames):
+def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None):
     """Eval-mode gated conv: x (B*t,H,W,C); ctx_frames (B, t+2, H, W, C) = [2 cached frames, x frames]."""
     N, H, W, Cin = x.shape
     Co = roundup(pw2.cout, 8)
     out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
-    den = torch.rsqrt((1 - gate) ** 2 + gate ** 2)
-    ca, cb = ((1 - gate) * den).float().contiguous(), (gate * den).float().contiguous()
+    ca, cb = coefs if coefs is not None else gate_coefs(gate)
+    ca, cb = ca.float().contiguous(), cb.float().contiguous()
+    kw, ret = {}, out
+    if res is not None:
+        kw = dict(epi=_lib.EPI_MPSUM, res=res, ta=ta, tb=tb, clip=clip)
+    elif cscale is not None:
+        ret = torch.empty_like(out)
+        kw = dict(epi=_lib.EPI_EMB_SILU, escale=cscale.float().contiguous(), out2=ret)
     _conv_launch(x, ctx_frames, pw2.wf, pw3.wf, out, ca, cb, B, 1, t, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
-                 ctx_bstride=t + 2, ctx_T=t + 2, coff=(0, 1), ctx_fill=0.0)
-    return out
+                 ctx_bstride=t + 2, ctx_T=t + 2, coff=(0, 1), ctx_fill=0.0, **kw)
+    return ret
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# fused magnitude-preserving glue (HBM-bound single-pass kernels, csrc/elementwise.hip)
+
+class _ActFn(torch.autograd.Function):
+    """(xo, a) = act(x[, skip]):  v = cat(w1*x, w2*skip); norm: v /= eps + |v|/sqrt(C); xo = v; a = silu(v)/0.596."""
+
+    @staticmethod
+    def forward(ctx, x, skip, w1, w2, norm, want_xo):
+        _need_gpu(x)
+        C1 = x.shape[-1]
+        C2 = skip.shape[-1] if skip is not None else 0
+        npix = x.numel() // C1
+        shape = (*x.shape[:-1], C1 + C2)
+        a = torch.empty(shape, dtype=BF16, device=x.device)
+        xo = torch.empty(shape, dtype=BF16, device=x.device) if (want_xo or norm) else None
+        sden = torch.empty(npix, dtype=torch.float32, device=x.device) if norm else None
+        x = x.contiguous()
+        skip = skip.contiguous() if skip is not None else None
+        check(lib.oniris_act_fwd(_p(x), _p(skip), _p(xo), _p(a), _p(sden), npix, C1, C2, w1, w2, int(norm), _stream()),
+              "act_fwd")
+        ctx.meta = (C1, C2, w1, w2, norm, npix, x.shape, skip.shape if skip is not None else None)
+        # without norm/cat xo would just be x itself: reuse the input for the silu' evaluation
+        ctx.save_for_backward(xo if xo is not None else x, sden)
+        if want_xo or norm:
+            return xo, a
+        return a
+
+    @staticmethod
+    def backward(ctx, *grads):
+        C1, C2, w1, w2, norm, npix, xshape, sshape = ctx.meta
+        xo, sden = ctx.saved_tensors
+        if len(grads) == 2:
+            dxo, da = grads
+        else:
+            dxo, da = None, grads[0]
+        if da is None:
+            da = torch.zeros(xo.shape, dtype=BF16, device=xo.device)
+        da = da.contiguous()
+        dxo = dxo.contiguous() if dxo is not None else None
+        dx = torch.empty(xshape, dtype=BF16, device=xo.device)
+        dskip = torch.empty(sshape, dtype=BF16, device=xo.device) if C2 else None
+        check(lib.oniris_act_bwd(_p(da), _p(dxo), _p(xo), _p(sden), _p(dx), _p(dskip), npix, C1, C2, w1, w2, int(norm),
+                                 _stream()), "act_bwd")
+        return dx, dskip, None, None, None, None
+
+
+def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False):
+    return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo))
+
+
+class _ResampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mode):
+        _need_gpu(x)
+        N, H, W, C = x.shape
+        x = x.contiguous()
+        out = torch.empty((N, H // 2, W // 2, C) if mode == 0 else (N, H * 2, W * 2, C), dtype=BF16, device=x.device)
+        check(lib.oniris_resample(_p(x), _p(out), N, H, W, C, mode, 1.0, _stream()), "resample")
+        ctx.mode = mode
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        N, H, W, C = g.shape
+        if ctx.mode == 0:      # adjoint of the 2x2 mean: nearest x2 scaled by 1/4
+            dx = torch.empty((N, H * 2, W * 2, C), dtype=BF16, device=g.device)
+            check(lib.oniris_resample(_p(g), _p(dx), N, H, W, C, 1, 0.25, _stream()), "resample")
+        else:                  # adjoint of nearest x2: 2x2 sum = 4 * mean
+            dx = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=g.device)
+            check(lib.oniris_resample(_p(g), _p(dx), N, H, W, C, 0, 4.0, _stream()), "resample")
+        return dx, None
+
+
+def resample(x, mode):
+    """mode 'keep' | 'down' (2x2 mean) | 'up' (nearest x2)   (utils.py:94-107 with f=[1,1])."""
+    if mode == "keep":
+        return x
+    return _ResampleFn.apply(x, 0 if mode == "down" else 1)
 
 
 # ------------------------------------------------------------------------------------------------------------------

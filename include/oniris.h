@@ -83,8 +83,9 @@ int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
  * ctx = dy3, coff = {+2,+1}, ctx_fill = 0, packed weights = desc.wb.
  * Epilogues (fused magnitude-preserving blocks, edm2/networks_edm2.py:73-93):
  *   ONIRIS_EPI_NONE      out = v
- *   ONIRIS_EPI_EMB_SILU  out = v ; out2 = silu(v * (1 + emb_gain * escale[n][co])) / 0.596
- *   ONIRIS_EPI_MPSUM     out = clip( ta * res[n][p][co] + tb * v , +-clip )     (clip <= 0: no clipping)
+ *   ONIRIS_EPI_EMB_SILU  out = v ; out2 = silu(v * escale[n][co]) / 0.596        (escale = 1 + emb_gain*emb_linear(emb))
+ *   ONIRIS_EPI_MPSUM     out = clip( ta * res[n][p][co] + tb * v , +-clip )     (clip <= 0: no clipping);
+ *                        out2 (optional) = v, the raw conv output (kept for the gate gradient)
  */
 enum { ONIRIS_EPI_NONE = 0, ONIRIS_EPI_EMB_SILU = 1, ONIRIS_EPI_MPSUM = 2 };
 
@@ -103,9 +104,9 @@ typedef struct OnirisConvArgs {
   float ctx_fill;
   int32_t epi;
   const void* res;        /* bf16 [B*S*T][H][W][Cout]   (EPI_MPSUM)                                               */
-  const void* escale;     /* bf16 [B*S*T][Cout]         (EPI_EMB_SILU): emb_linear(emb)                           */
-  const float* emb_gain;  /* device scalar              (EPI_EMB_SILU)                                            */
-  void* out2;             /* bf16 like out              (EPI_EMB_SILU)                                            */
+  const void* escale;     /* fp32 [B*S*T][Cout]         (EPI_EMB_SILU): per-(frame, channel) multiplier           */
+  const float* emb_gain;  /* reserved (unused)                                                                    */
+  void* out2;             /* bf16 like out              (EPI_EMB_SILU: activation; EPI_MPSUM: optional raw output) */
   float ta, tb, clip;
   void* ctx_out;          /* optional bf16 [B*T][H][W][Cout]: the un-gated context product y3 (for d gate)        */
 } OnirisConvArgs;
@@ -129,10 +130,34 @@ typedef struct OnirisWgradArgs {
 int oniris_conv_wgrad(const OnirisWgradArgs* args /* [host] */, oniris_stream_t stream);
 
 /* Backward pre-pass of the gated conv (autograd of edm2/conv.py:90-95): one pass over dout computing, per
- * frame-slot n, S1[n] = sum(dout*out), S2[n] = sum(dout*y3) (gate gradient) and the context-path gradient
- * dy3[b,t] = sum_s coef_ctx[b,s,t] * dout[b,s,t].  dout/out bf16 [B][S][T][frame_elems], y3/dy3 [B][T][frame_elems]. */
-int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_ctx, float* S1,
-                          float* S2, void* dy3, int B, int S, int T, int64_t frame_elems, oniris_stream_t stream);
+ * frame-slot n, d_coef_own[n] = sum(dout*y2) (recovered as (sum(dout*out) - coef_ctx*sum(dout*y3)) / coef_own),
+ * d_coef_ctx[n] = sum(dout*y3) (the gate gradient, chained to the 6 gating parameters on the host) and the
+ * context-path gradient dy3[b,t] = sum_s coef_ctx[b,s,t] * dout[b,s,t].
+ * dout/out bf16 [B][S][T][frame_elems], y3/dy3 [B][T][frame_elems]. */
+int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_own,
+                          const float* coef_ctx, float* d_coef_own, float* d_coef_ctx, void* dy3, int B, int S, int T,
+                          int64_t frame_elems, oniris_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Fused magnitude-preserving glue (HBM-bound, one pass each) -- the elementwise chains of Block.forward
+ * (edm2/networks_edm2.py:62-94) and their adjoints.  All tensors bf16 channels-last.
+ * oniris_act_fwd: v = concat(w1*x[C1], w2*skip[C2]) (mp_cat, utils.py:128-134; C2 = 0: none); norm != 0: pixel norm
+ *   v /= eps + |v|/sqrt(C) (utils.py:83-88), sden[pixel] receives the denominator; xo (optional) = v;
+ *   a = silu(v)/0.596 (utils.py:112).   oniris_act_bwd: given da (and optionally dxo) -> dx [C1], dskip [C2].
+ * oniris_emb_silu_bwd: backward of u = silu(y*c[n][co])/0.596: dy, and dc[n][co] = sum_pixels (fp32, overwritten).
+ * oniris_mpsum_bwd: backward of out = clip(ta*res + tb*v): dres, dv (clip <= 0: no mask, `out` may be NULL).
+ * oniris_resample: mode 0 = 2x2 mean (H,W = input size), mode 1 = nearest x2; result * scale
+ *   (utils.py:94-107 with f = [1,1]; adjoints: down^T = up * 0.25, up^T = down * 4).                             */
+int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sden, int64_t npix, int C1, int C2,
+                   float w1, float w2, int norm, oniris_stream_t stream);
+int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
+                   int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream);
+int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P, int C,
+                        oniris_stream_t stream);
+int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv, int64_t numel, float ta, float tb, float clip,
+                     oniris_stream_t stream);
+int oniris_resample(const void* in, void* out, int64_t N, int H, int W, int C, int mode, float scale,
+                    oniris_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * VideoAttention / FrameAttention (edm2/attention/attention_modules.py:30-82, 105-119; RoPe.py:43-68).

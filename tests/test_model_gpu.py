@@ -184,11 +184,12 @@ def test_g8_unet_loss(tag, cfg):
         print("g8", tag, mode, e, "worst gradnorm", [(w, round(gerr[w], 4)) for w in worst],
               "worst full grad", max(full.values()) if full else None)
         assert e["Dx"] < 2e-2 and e["loss"] < 2e-2 and e["unw"] < 2e-2
-        wg = {k: v for k, v in gerr.items() if "gating" not in k}
+        scalars = {n for n in names if prm[n].numel() <= 2}          # gate parameters and emb_gain / out_gain
+        wg = {k: v for k, v in gerr.items() if k not in scalars}
         assert np.median(list(wg.values())) < 2e-2 and max(wg.values()) < 0.1, sorted(wg.items(), key=lambda kv: kv[1])[-3:]
         # gate scalars: |err| <= 3% of the value + 0.3% of the largest gate gradient in the net (bf16 noise floor of
         # the sum(dout*out) / sum(dout*y3) reductions; measured floor ~5e-5 absolute on this fixture)
-        refs = {n: v for n, v in zip(names, vals) if "gating" in n}
+        refs = {n: v for n, v in zip(names, vals) if n in scalars}
         gmax = max(refs.values())
         for n, v in refs.items():
             assert abs(prm[n].grad.norm().item() - v) <= 3e-2 * v + 3e-3 * gmax, (n, prm[n].grad.norm().item(), v)
