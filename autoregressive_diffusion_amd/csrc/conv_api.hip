@@ -7,7 +7,7 @@ extern "C" int oniris_conv_fwd(const OnirisConvArgs* args, oniris_stream_t strea
   const OnirisConvArgs& a = *args;
   ONIRIS_CHECK_ARG(a.taps == 9 || a.taps == 1, "conv_fwd: taps must be 1 or 9 (got %d)", a.taps);
   ONIRIS_CHECK_ARG(a.B > 0 && a.T > 0 && a.H > 0 && a.W > 0 && (a.S == 1 || a.S == 2), "conv_fwd: bad sizes");
-  ONIRIS_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 4 == 0, "conv_fwd: Cin %% 8 / Cout %% 4 violated (%d,%d)", a.Cin, a.Cout);
+  ONIRIS_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv_fwd: Cin, Cout must be multiples of 8 (%d,%d)", a.Cin, a.Cout);
   ONIRIS_CHECK_ARG(a.CoutP % 32 == 0 && a.CinP % 64 == 0 && a.CoutP >= a.Cout && a.CinP >= a.Cin,
                    "conv_fwd: bad padded sizes CoutP=%d CinP=%d", a.CoutP, a.CinP);
   ONIRIS_CHECK_ARG(a.epi != ONIRIS_EPI_MPSUM || a.res, "conv_fwd: EPI_MPSUM needs res");

@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
     }
   }
 
-  // -------------------------------------------------------------------- epilogue (lane-local per position)
+  // -------------------------------------------------------------------- epilogue
+  // The math is lane-local (lane = position): gate combine, emb-scale+SiLU, mp_sum+clip.  The bf16 results are then
+  // transposed through a wave-private LDS tile ([32 positions][BN channels]) so that global stores are 16 B per lane
+  // and cover whole 128-byte channel rows (8-byte scattered stores cost ~10x write traffic: measured WRITE_SIZE).
   bool valid;
   size_t pix;       // pixel index inside the (b,s) block of T frames
   int tloc;
@@ -225,65 +228,106 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
     tloc = valid ? q / HWp : 0;
     pix = (size_t)q;
   }
-  if (!valid) return;
+  constexpr int EROW = BN * 2 + 16;
+  unsigned char* ep = smem + wave * 32 * EROW;
+  // coalesced write-out of the wave's LDS tile to tensor `dst` ((b,s)-block element offset `blk`)
+  auto flush = [&](bf16* dst, size_t blk) {
+    constexpr int PO = BN / 8;
+#pragma unroll
+    for (int it = 0; it < 32 * PO / 64; ++it) {
+      const int id = it * 64 + lane;
+      const int row = id / PO, part = id % PO;
+      const int pr = wave * 32 + row;
+      bool ok;
+      size_t px_;
+      if constexpr (TAPS == 9) {
+        const int f_ = pr / (P::PH * P::PW), yy = (pr / P::PW) % P::PH, xx = pr % P::PW;
+        ok = (t0 + f_) < T;
+        px_ = (size_t)(t0 + f_) * HWp + (y0 + yy) * W + (x0 + xx);
+      } else {
+        ok = (q0 + pr) < T * HWp;
+        px_ = (size_t)(q0 + pr);
+      }
+      const int co = co0 + part * 8;
+      if (ok && co < a.Cout) *(uint4*)(dst + (blk + px_) * a.Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
+    }
+  };
   bf16* og = (bf16*)a.out;
 #pragma unroll
   for (int s = 0; s < S; ++s) {
     const int n = (b * S + s) * T + tloc;
-    const float cown = a.coef_own ? a.coef_own[n] : 1.f;
+    const float cown = (a.coef_own && valid) ? a.coef_own[n] : 1.f;
     float cctx = 0.f;
-    if constexpr (HAS_CTX) cctx = a.coef_ctx ? a.coef_ctx[n] : 1.f;
-    const size_t obase = ((size_t)(b * S + s) * T * HWp + pix) * a.Cout;
+    if constexpr (HAS_CTX) cctx = (a.coef_ctx && valid) ? a.coef_ctx[n] : 1.f;
+    const size_t blk = (size_t)(b * S + s) * T * HWp;
+    const size_t obase = (blk + pix) * a.Cout;
+    float v[NT][16];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int co = co0 + nt * 32 + 8 * g + 4 * h;
-        if (co >= a.Cout) continue;
-        float v[4];
+      for (int i = 0; i < 16; ++i) {
+        v[nt][i] = cown * acc[s][nt][i];
+        if constexpr (HAS_CTX) v[nt][i] += cctx * accc[nt][i];
+      }
+    // helper: write v (as bf16) into the wave tile
+    auto stage = [&](float (&t)[NT][16]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          v[k] = cown * acc[s][nt][4 * g + k];
-          if constexpr (HAS_CTX) v[k] += cctx * accc[nt][4 * g + k];
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) o[k] = f2bf(t[nt][4 * g + k]);
+          *(bf16x4*)(ep + r * EROW + (nt * 32 + 8 * g + 4 * h) * 2) = o;
         }
-        if (a.epi == ONIRIS_EPI_MPSUM) {
-          if (a.out2) {                                   // keep the raw conv output (needed for d gate)
-            bf16x4 rawv;
+    };
+    if (a.epi == ONIRIS_EPI_MPSUM) {
+      if (a.out2) { stage(v); flush((bf16*)a.out2, blk); }       // raw conv output (needed for d gate)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) rawv[k] = f2bf(v[k]);
-            *(bf16x4*)((bf16*)a.out2 + obase + co) = rawv;
-          }
-          const bf16x4 rv = *(const bf16x4*)((const bf16*)a.res + obase + co);
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + nt * 32 + 8 * g + 4 * h;
+          bf16x4 rv;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) rv[k] = f2bf(0.f);
+          if (valid && co < a.Cout) rv = *(const bf16x4*)((const bf16*)a.res + obase + co);
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            float o = a.ta * bf2f(rv[k]) + a.tb * v[k];
+            float o = a.ta * bf2f(rv[k]) + a.tb * v[nt][4 * g + k];
             if (a.clip > 0.f) o = fminf(fmaxf(o, -a.clip), a.clip);
-            v[k] = o;
+            v[nt][4 * g + k] = o;
           }
         }
-        bf16x4 ov;
+    }
+    stage(v);
+    flush(og, blk);
+    if (a.epi == ONIRIS_EPI_EMB_SILU) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) ov[k] = f2bf(v[k]);
-        *(bf16x4*)(og + obase + co) = ov;
-        if (a.epi == ONIRIS_EPI_EMB_SILU) {
-          const float4 ev = *(const float4*)((const float*)a.escale + (size_t)n * a.Cout + co);
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int co = co0 + nt * 32 + 8 * g + 4 * h;
+          float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (valid && co < a.Cout) ev = *(const float4*)((const float*)a.escale + (size_t)n * a.Cout + co);
           const float cvv[4] = {ev.x, ev.y, ev.z, ev.w};
-          bf16x4 uv;
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
-            const float z = bf2f(ov[k]) * cvv[k];
-            uv[k] = f2bf(z / (1.f + __expf(-z)) * (1.f / 0.596f));
+            const float z = bf2f(f2bf(v[nt][4 * g + k])) * cvv[k];     // the activation sees the bf16-rounded y
+            v[nt][4 * g + k] = z / (1.f + __expf(-z)) * (1.f / 0.596f);
           }
-          *(bf16x4*)((bf16*)a.out2 + obase + co) = uv;
         }
-        if constexpr (HAS_CTX) {
-          if (a.ctx_out && s == 0) {        // unscaled context product y3 (shared by both slots), kept for d(gate)
-            bf16x4 cv;
+      stage(v);
+      flush((bf16*)a.out2, blk);
+    }
+    if constexpr (HAS_CTX) {
+      if (a.ctx_out && s == 0) {          // unscaled context product y3 (shared by both slots), kept for d(gate)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) cv[k] = f2bf(accc[nt][4 * g + k]);
-            *(bf16x4*)((bf16*)a.ctx_out + ((size_t)b * T * HWp + pix) * a.Cout + co) = cv;
-          }
-        }
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[nt][i] = accc[nt][i];
+        stage(v);
+        flush((bf16*)a.ctx_out, (size_t)b * T * HWp);
       }
     }
   }

@@ -176,7 +176,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
   }
 
   // ---- accumulate into the packed fp32 gradient  dwp[tap][co][ci]
+  // Split-K partial sums meet in HBM through fp32 atomics (~1.3 TB/s chip-wide): when several waves of the
+  // workgroup share one output tile (NKS > 1) they are first summed through LDS so only one wave issues atomics.
   const int cj = ci0 + it * 32 + (lane & 31);
+  if constexpr (NKS > 1) {
+    float* red = (float*)smem;                               // [NKS-1][16][64] floats = 12 KB, staging LDS is free now
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      __syncthreads();
+      if (my_ks > 0) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) red[((my_ks - 1) * 16 + rr) * 64 + lane] = acc[tap][rr];
+      }
+      __syncthreads();
+      if (my_ks == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          float v = acc[tap][rr];
+#pragma unroll
+          for (int w = 0; w < NKS - 1; ++w) v += red[(w * 16 + rr) * 64 + lane];
+          acc[tap][rr] = v;
+        }
+      }
+    }
+    if (my_ks != 0) return;
+  }
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap) {
     float* base = a.dwp + (size_t)tap * a.CoutP * a.CinP;
@@ -202,7 +226,7 @@ static int launch_wgrad(const OnirisWgradArgs& a, hipStream_t stream) {
   d.ncib = cdiv(a.Cin, 32 * IT);
   const int ncob = cdiv(a.Cout, 32 * CT);
   const int gy = d.ncib * ncob;
-  int gx = 1024 / gy;
+  int gx = 512 / gy;            // ~2 workgroups per CU: every extra split-K workgroup costs |tile| bytes of atomics
   if (gx < 1) gx = 1;
   if (gx > d.ntiles) gx = d.ntiles;
   constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
