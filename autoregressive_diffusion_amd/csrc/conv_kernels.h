@@ -94,121 +94,119 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   const int nchunk = (Cin + CK - 1) / CK;
   constexpr int NPH = HAS_CTX ? 3 : 1;
 
-  for (int ch = 0; ch < nchunk; ++ch) {
+  // Software pipeline: the global loads of phase i+1 (activation halo + weight slab, 16 B per lane) are issued into
+  // registers BEFORE the MFMA section of phase i and written to LDS after it, so HBM/L2 latency hides under the
+  // matrix work of the same workgroup (T14 "issue early / write late").
+  constexpr int TOTA = Cfg::AROWS * PARTS, TOTC = Cfg::CROWS * PARTS, TOTW = Cfg::WROWS * PARTS;
+  constexpr int NIA = (TOTA + 255) / 256, NIW = (TOTW + 255) / 256;
+  u32x4 ra[NIA], rw[NIW];
+  const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.ctx_fill));
+  const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
+
+  auto load_phase = [&](int ch, int ph) __attribute__((always_inline)) {
     const int c0 = ch * CK;
-#pragma unroll 1
-    for (int ph = 0; ph < NPH; ++ph) {
-      // ------------------------------------------------------------------ stage A (activations) into LDS
-      if (ph == 0) {
-        constexpr int TOT = Cfg::AROWS * PARTS;
-        constexpr int NI = (TOT + 255) / 256;
-        uint4 v[NI];
+    if (ph == 0) {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int e = tid + i * 256;
-          v[i] = make_uint4(0, 0, 0, 0);
-          if (e < TOT) {
-            const int row = e / PARTS, part = e % PARTS;
-            const int ci = c0 + part * 8;
-            if constexpr (TAPS == 9) {
-              const int s = row / P::HALO, hr = row % P::HALO;
-              const int f_ = hr / (P::HH * P::HW), rem = hr % (P::HH * P::HW);
-              const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1, t = t0 + f_;
-              if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin)
-                v[i] = *(const uint4*)(xg + ((size_t)((b * S + s) * T + t) * HWp + y * W + x) * Cin + ci);
-            } else {
-              const int s = row / 128, q = q0 + (row % 128);
-              if (q < T * HWp && ci < Cin)
-                v[i] = *(const uint4*)(xg + ((size_t)(b * S + s) * T * HWp + q) * Cin + ci);
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int e = tid + i * 256;
-          if (e < TOT) *(uint4*)(A_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = v[i];
-        }
-      } else {
-        constexpr int TOT = Cfg::CROWS * PARTS;
-        constexpr int NI = (TOT + 255) / 256;
-        const int coff = (ph == 1) ? a.coff0 : a.coff1;
-        const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.ctx_fill));
-        const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
-        uint4 v[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int e = tid + i * 256;
-          v[i] = make_uint4(0, 0, 0, 0);
-          if (e < TOT) {
-            const int row = e / PARTS, part = e % PARTS;
-            const int ci = c0 + part * 8;
-            const int f_ = row / (P::HH * P::HW), rem = row % (P::HH * P::HW);
+      for (int i = 0; i < NIA; ++i) {
+        const int e = tid + i * 256;
+        ra[i] = u32x4{0u, 0u, 0u, 0u};
+        if (e < TOTA) {
+          const int row = e / PARTS, part = e % PARTS;
+          const int ci = c0 + part * 8;
+          if constexpr (TAPS == 9) {
+            const int s = row / P::HALO, hr = row % P::HALO;
+            const int f_ = hr / (P::HH * P::HW), rem = hr % (P::HH * P::HW);
             const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1, t = t0 + f_;
-            if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin) {
-              const int f = t + coff;
-              if (f >= 0 && f < a.ctx_T)
-                v[i] = *(const uint4*)(cg + ((size_t)(b * a.ctx_bstride + f) * HWp + y * W + x) * Cin + ci);
-              else
-                v[i] = make_uint4(fill2, fill2, fill2, fill2);
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int e = tid + i * 256;
-          if (e < TOT) *(uint4*)(A_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = v[i];
-        }
-      }
-      // ------------------------------------------------------------------ stage W (packed weights) into LDS
-      {
-        const bf16* wg = (ph == 0) ? (const bf16*)a.w_own
-                                   : (const bf16*)a.w_ctx + (size_t)(ph - 1) * TAPS * a.CoutP * a.CinP;
-        constexpr int TOT = Cfg::WROWS * PARTS;
-        constexpr int NI = (TOT + 255) / 256;
-        uint4 v[NI];
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int e = tid + i * 256;
-          if (e < TOT) {
-            const int row = e / PARTS, part = e % PARTS;
-            const int tap = row / BN, co = row % BN;
-            v[i] = *(const uint4*)(wg + ((size_t)tap * a.CoutP + co0 + co) * a.CinP + c0 + part * 8);
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int e = tid + i * 256;
-          if (e < TOT) *(uint4*)(W_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = v[i];
-        }
-      }
-      __syncthreads();
-      // ------------------------------------------------------------------ MFMA over taps x k-steps
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
-        const int off = (TAPS == 9) ? ((tap / 3) * P::HW + (tap % 3)) : 0;
-#pragma unroll
-        for (int ks = 0; ks < CK / 16; ++ks) {
-          bf16x8 wf[NT];
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-            wf[n] = *(const bf16x8*)(W_lds + (tap * BN + n * 32 + r) * ROWB + ks * 32 + h * 16);
-          if (ph == 0) {
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-              const int srow = (TAPS == 9) ? s * P::HALO : s * 128;
-              const bf16x8 xf = *(const bf16x8*)(A_lds + (srow + arow + off) * ROWB + ks * 32 + h * 16);
-#pragma unroll
-              for (int n = 0; n < NT; ++n) acc[s][n] = mfma32(wf[n], xf, acc[s][n]);
-            }
+            if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin)
+              ra[i] = *(const u32x4*)(xg + ((size_t)((b * S + s) * T + t) * HWp + y * W + x) * Cin + ci);
           } else {
-            const bf16x8 xf = *(const bf16x8*)(A_lds + (arow + off) * ROWB + ks * 32 + h * 16);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) accc[n] = mfma32(wf[n], xf, accc[n]);
+            const int s = row / 128, q = q0 + (row % 128);
+            if (q < T * HWp && ci < Cin)
+              ra[i] = *(const u32x4*)(xg + ((size_t)(b * S + s) * T * HWp + q) * Cin + ci);
           }
         }
       }
-      __syncthreads();
+    } else {
+      const int coff = (ph == 1) ? a.coff0 : a.coff1;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i) {
+        const int e = tid + i * 256;
+        ra[i] = u32x4{0u, 0u, 0u, 0u};
+        if (e < TOTC) {
+          const int row = e / PARTS, part = e % PARTS;
+          const int ci = c0 + part * 8;
+          const int f_ = row / (P::HH * P::HW), rem = row % (P::HH * P::HW);
+          const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1, t = t0 + f_;
+          if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin) {
+            const int f = t + coff;
+            if (f >= 0 && f < a.ctx_T)
+              ra[i] = *(const u32x4*)(cg + ((size_t)(b * a.ctx_bstride + f) * HWp + y * W + x) * Cin + ci);
+            else
+              ra[i] = u32x4{fill2, fill2, fill2, fill2};
+          }
+        }
+      }
     }
+    const bf16* wg = (ph == 0) ? (const bf16*)a.w_own
+                               : (const bf16*)a.w_ctx + (size_t)(ph - 1) * TAPS * a.CoutP * a.CinP;
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const int e = tid + i * 256;
+      if (e < TOTW) {
+        const int row = e / PARTS, part = e % PARTS;
+        const int tap = row / BN, co = row % BN;
+        rw[i] = *(const u32x4*)(wg + ((size_t)tap * a.CoutP + co0 + co) * a.CinP + c0 + part * 8);
+      }
+    }
+  };
+  auto store_phase = [&](int ph) __attribute__((always_inline)) {
+    const int tot = (ph == 0) ? TOTA : TOTC;
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int e = tid + i * 256;
+      if (e < tot) *(u32x4*)(A_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+      const int e = tid + i * 256;
+      if (e < TOTW) *(u32x4*)(W_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = rw[i];
+    }
+  };
+
+  const int nphase = nchunk * NPH;
+  load_phase(0, 0);
+#pragma unroll 1
+  for (int itp = 0; itp < nphase; ++itp) {
+    const int ph = itp % NPH;
+    store_phase(ph);
+    __syncthreads();
+    if (itp + 1 < nphase) load_phase((itp + 1) / NPH, (itp + 1) % NPH);
+    // ------------------------------------------------------------------ MFMA over taps x k-steps
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int off = (TAPS == 9) ? ((tap / 3) * P::HW + (tap % 3)) : 0;
+#pragma unroll
+      for (int ks = 0; ks < CK / 16; ++ks) {
+        bf16x8 wf[NT];
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          wf[n] = *(const bf16x8*)(W_lds + (tap * BN + n * 32 + r) * ROWB + ks * 32 + h * 16);
+        if (ph == 0) {
+#pragma unroll
+          for (int s = 0; s < S; ++s) {
+            const int srow = (TAPS == 9) ? s * P::HALO : s * 128;
+            const bf16x8 xf = *(const bf16x8*)(A_lds + (srow + arow + off) * ROWB + ks * 32 + h * 16);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[s][n] = mfma32(wf[n], xf, acc[s][n]);
+          }
+        } else {
+          const bf16x8 xf = *(const bf16x8*)(A_lds + (arow + off) * ROWB + ks * 32 + h * 16);
+#pragma unroll
+          for (int n = 0; n < NT; ++n) accc[n] = mfma32(wf[n], xf, accc[n]);
+        }
+      }
+    }
+    __syncthreads();
   }
 
   // -------------------------------------------------------------------- epilogue
@@ -231,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   constexpr int EROW = BN * 2 + 16;
   unsigned char* ep = smem + wave * 32 * EROW;
   // coalesced write-out of the wave's LDS tile to tensor `dst` ((b,s)-block element offset `blk`)
-  auto flush = [&](bf16* dst, size_t blk) {
+  auto flush = [&](bf16* dst, size_t blk) __attribute__((always_inline)) {
     constexpr int PO = BN / 8;
 #pragma unroll
     for (int it = 0; it < 32 * PO / 64; ++it) {
@@ -270,19 +268,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
         if constexpr (HAS_CTX) v[nt][i] += cctx * accc[nt][i];
       }
     // helper: write v (as bf16) into the wave tile
-    auto stage = [&](float (&t)[NT][16]) {
+    auto stage = [&]() __attribute__((always_inline)) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           bf16x4 o;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) o[k] = f2bf(t[nt][4 * g + k]);
+          for (int k = 0; k < 4; ++k) o[k] = f2bf(v[nt][4 * g + k]);
           *(bf16x4*)(ep + r * EROW + (nt * 32 + 8 * g + 4 * h) * 2) = o;
         }
     };
     if (a.epi == ONIRIS_EPI_MPSUM) {
-      if (a.out2) { stage(v); flush((bf16*)a.out2, blk); }       // raw conv output (needed for d gate)
+      if (a.out2) { stage(); flush((bf16*)a.out2, blk); }       // raw conv output (needed for d gate)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
           }
         }
     }
-    stage(v);
+    stage();
     flush(og, blk);
     if (a.epi == ONIRIS_EPI_EMB_SILU) {
 #pragma unroll
@@ -317,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
             v[nt][4 * g + k] = z / (1.f + __expf(-z)) * (1.f / 0.596f);
           }
         }
-      stage(v);
+      stage();
       flush((bf16*)a.out2, blk);
     }
     if constexpr (HAS_CTX) {
@@ -326,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int i = 0; i < 16; ++i) v[nt][i] = accc[nt][i];
-        stage(v);
+        stage();
         flush((bf16*)a.ctx_out, (size_t)b * T * HWp);
       }
     }

@@ -57,7 +57,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
   // lane roles for the transposing reads
   const int grp = lane >> 4, hh = grp >> 1, q = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
 
-  for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+  // Software pipeline (issue early / write late): the global loads of the NEXT position tile are issued into
+  // registers before the MFMA section of the current one.
+  constexpr int DPARTS = DYB / 16, DTOT = 128 * DPARTS, DNI = DTOT / 256;
+  constexpr int XPARTS = XB / 16, XTOT = XROWS * XPARTS, XNI = (XTOT + 255) / 256;
+  u32x4 rd[DNI], rx[XNI];
+  float rsc[DNI];
+  const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.fill));
+  const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
+
+  auto load_tile = [&](int tile) __attribute__((always_inline)) {
     int bid = tile;
     int t0 = 0, y0 = 0, x0 = 0, q0 = 0;
     if constexpr (TAPS == 9) {
@@ -70,88 +79,78 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
       q0 = tq * 128;
     }
     const int b = bid;
-
-    // ---- stage dy tile [128 positions][32*CT co], scaled per frame
-    {
-      constexpr int PARTS = DYB / 16;
-      constexpr int TOT = 128 * PARTS;
-      constexpr int NI = TOT / 256;
-      uint4 v[NI];
-      float sc[NI];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int e = tid + i * 256;
-        const int row = e / PARTS, part = e % PARTS;
-        const int co = co0 + part * 8;
-        v[i] = make_uint4(0, 0, 0, 0);
-        sc[i] = 1.f;
-        int t; size_t pix; bool ok;
+    for (int i = 0; i < DNI; ++i) {           // dy tile [128 positions][32*CT co]
+      const int e = tid + i * 256;
+      const int row = e / DPARTS, part = e % DPARTS;
+      const int co = co0 + part * 8;
+      rd[i] = u32x4{0u, 0u, 0u, 0u};
+      rsc[i] = 1.f;
+      int t; size_t pix; bool ok;
+      if constexpr (TAPS == 9) {
+        const int f_ = row / (P::PH * P::PW), py = (row / P::PW) % P::PH, px = row % P::PW;
+        t = t0 + f_; ok = t < T; pix = (size_t)t * HWp + (y0 + py) * W + x0 + px;
+      } else {
+        const int qq = q0 + row;
+        ok = qq < T * HWp; t = ok ? qq / HWp : 0; pix = (size_t)qq;
+      }
+      if (ok && co < a.Cout) {
+        rd[i] = *(const u32x4*)(dyg + ((size_t)b * T * HWp + pix) * a.Cout + co);
+        if (a.scale) rsc[i] = a.scale[b * T + t];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XNI; ++i) {           // x halo [XROWS][32*IT ci]
+      const int e = tid + i * 256;
+      rx[i] = u32x4{0u, 0u, 0u, 0u};
+      if (e < XTOT) {
+        const int row = e / XPARTS, part = e % XPARTS;
+        const int ci = ci0 + part * 8;
+        int t, y, x; bool ok;
         if constexpr (TAPS == 9) {
-          const int f_ = row / (P::PH * P::PW), py = (row / P::PW) % P::PH, px = row % P::PW;
-          t = t0 + f_; ok = t < T; pix = (size_t)t * HWp + (y0 + py) * W + x0 + px;
+          const int f_ = row / (P::HH * P::HW), rem = row % (P::HH * P::HW);
+          y = y0 + rem / P::HW - 1; x = x0 + rem % P::HW - 1; t = t0 + f_;
+          ok = t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
         } else {
           const int qq = q0 + row;
-          ok = qq < T * HWp; t = ok ? qq / HWp : 0; pix = (size_t)qq;
+          ok = qq < T * HWp; t = ok ? qq / HWp : 0; const int pp = ok ? qq % HWp : 0; y = pp / W; x = pp % W;
         }
-        if (ok && co < a.Cout) {
-          v[i] = *(const uint4*)(dyg + ((size_t)b * T * HWp + pix) * a.Cout + co);
-          if (a.scale) sc[i] = a.scale[b * T + t];
+        if (ok && ci < a.Cin) {
+          const int f = t + a.coff;
+          if (f >= 0 && f < a.x_T)
+            rx[i] = *(const u32x4*)(xg + ((size_t)(b * a.xb_stride + f) * HWp + y * W + x) * a.Cin + ci);
+          else
+            rx[i] = u32x4{fill2, fill2, fill2, fill2};
         }
-      }
-#pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int e = tid + i * 256;
-        const int row = e / PARTS, part = e % PARTS;
-        uint4 o = v[i];
-        if (a.scale) {
-          bf16x8 bv = __builtin_bit_cast(bf16x8, o);
-#pragma unroll
-          for (int k = 0; k < 8; ++k) bv[k] = f2bf(bf2f(bv[k]) * sc[i]);
-          o = __builtin_bit_cast(uint4, bv);
-        }
-        *(uint4*)(dy_lds + row * DY_ROWB + part * 16) = o;
       }
     }
-    // ---- stage x halo [XROWS][32*IT ci]
-    {
-      constexpr int PARTS = XB / 16;
-      constexpr int TOT = XROWS * PARTS;
-      constexpr int NI = (TOT + 255) / 256;
-      const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.fill));
-      const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
-      uint4 v[NI];
+  };
+  auto store_tile = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int e = tid + i * 256;
-        v[i] = make_uint4(0, 0, 0, 0);
-        if (e < TOT) {
-          const int row = e / PARTS, part = e % PARTS;
-          const int ci = ci0 + part * 8;
-          int t, y, x; bool ok;
-          if constexpr (TAPS == 9) {
-            const int f_ = row / (P::HH * P::HW), rem = row % (P::HH * P::HW);
-            y = y0 + rem / P::HW - 1; x = x0 + rem % P::HW - 1; t = t0 + f_;
-            ok = t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
-          } else {
-            const int qq = q0 + row;
-            ok = qq < T * HWp; t = ok ? qq / HWp : 0; const int pp = ok ? qq % HWp : 0; y = pp / W; x = pp % W;
-          }
-          if (ok && ci < a.Cin) {
-            const int f = t + a.coff;
-            if (f >= 0 && f < a.x_T)
-              v[i] = *(const uint4*)(xg + ((size_t)(b * a.xb_stride + f) * HWp + y * W + x) * a.Cin + ci);
-            else
-              v[i] = make_uint4(fill2, fill2, fill2, fill2);
-          }
-        }
-      }
+    for (int i = 0; i < DNI; ++i) {
+      const int e = tid + i * 256;
+      u32x4 o = rd[i];
+      if (a.scale) {                          // per-frame coefficient folded into dy (bf16 rounding, like a dy2 tensor)
+        bf16x8 bv = __builtin_bit_cast(bf16x8, o);
 #pragma unroll
-      for (int i = 0; i < NI; ++i) {
-        const int e = tid + i * 256;
-        if (e < TOT) *(uint4*)(x_lds + (e / PARTS) * X_ROWB + (e % PARTS) * 16) = v[i];
+        for (int k = 0; k < 8; ++k) bv[k] = f2bf(bf2f(bv[k]) * rsc[i]);
+        o = __builtin_bit_cast(u32x4, bv);
       }
+      *(u32x4*)(dy_lds + (e / DPARTS) * DY_ROWB + (e % DPARTS) * 16) = o;
     }
+#pragma unroll
+    for (int i = 0; i < XNI; ++i) {
+      const int e = tid + i * 256;
+      if (e < XTOT) *(u32x4*)(x_lds + (e / XPARTS) * X_ROWB + (e % XPARTS) * 16) = rx[i];
+    }
+  };
+
+  if ((int)blockIdx.x < d.ntiles) load_tile(blockIdx.x);
+#pragma unroll 1
+  for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+    store_tile();
     __syncthreads();
+    if (tile + (int)gridDim.x < d.ntiles) load_tile(tile + gridDim.x);
     // ---- MFMA: k = 16 positions per step
 #pragma unroll
     for (int ksi = 0; ksi < 8 / NKS; ++ksi) {
@@ -226,7 +225,7 @@ static int launch_wgrad(const OnirisWgradArgs& a, hipStream_t stream) {
   d.ncib = cdiv(a.Cin, 32 * IT);
   const int ncob = cdiv(a.Cout, 32 * CT);
   const int gy = d.ncib * ncob;
-  int gx = 512 / gy;            // ~2 workgroups per CU: every extra split-K workgroup costs |tile| bytes of atomics
+  int gx = ((CT * IT == 4) ? 256 : 512) / gy;   // every extra split-K workgroup costs |tile| bytes of fp32 atomics
   if (gx < 1) gx = 1;
   if (gx > d.ntiles) gx = d.ntiles;
   constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
