@@ -7,17 +7,16 @@
 // Forward / dQ: one workgroup = 128 query rows (4 waves x 32 rows), S^T = K.Q^T is computed with the KEY index on
 // the MFMA rows and the QUERY on the lanes, so a lane owns one query row: row max / row sum are 32 in-register ops
 // plus one cross-half shuffle, and the S^T accumulator is directly the B operand of O^T += V^T.P^T (no LDS round
-// trip).  K / V^T tiles (64 keys) are staged in LDS with padded rows (144 B / 136 B: conflict-free 16 B / 8 B
-// fragment reads).  dK/dV: one workgroup = 128 keys, lane = key, S = Q.K^T with queries on the rows, P and dS feed
-// dV^T += dO^T.P and dK^T += Q^T.dS straight from registers.  The k-contiguous operands (V^T, K^T, Q^T, dO^T) are
-// read from transposed copies that the rope/transposition kernel writes once per layer (L x 64 per head: tiny).
+// trip).  K / V tiles (64 keys) are prefetched into registers one tile ahead and staged row-major in LDS (144-byte
+// rows); row fragments are 16-byte reads, the transposed operands (V^T, K^T, Q^T, dO^T: MFMA k index = token) come
+// from the SAME tiles through the gfx950 transposing read ds_read_b64_tr_b16.  dK/dV: one workgroup = 128 keys,
+// lane = key, S = Q.K^T with queries on the rows, P and dS feed dV^T += dO^T.P and dK^T += Q^T.dS from registers.
 #include "common.h"
 #include "../../include/oniris.h"
 
 #define NEG_BIG (-1.0e30f)
 #define SCALE_LOG2 (0.125f * 1.4426950408889634f)
 #define KROW 144   // bytes per row of a [64 tok][64 ch] bf16 tile (128 + 16 pad)
-#define TROW 136   // bytes per row of a [64 ch][64 tok] bf16 tile (128 + 8 pad)
 
 struct AttnDev {
   OnirisAttnArgs a;
@@ -70,43 +69,46 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int s2) {
   return o;
 }
 
-// stage a [64 tok][64 ch] tile (row-major, global row stride C elements) into LDS rows of KROW bytes
-__device__ __forceinline__ void stage_rows(unsigned char* lds, const bf16* g, int tok0, int L, int C, int tid) {
+// ---- 64-token x 64-channel bf16 tiles: global -> registers (prefetch) -> LDS rows of KROW bytes -----------------
+__device__ __forceinline__ void tile_load(u32x4 (&v)[2], const bf16* g, int tok0, int L, int C, int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = tid + i * 256;
     const int row = e >> 3, part = e & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (tok0 + row < L) v = *(const uint4*)(g + (size_t)(tok0 + row) * C + part * 8);
-    *(uint4*)(lds + row * KROW + part * 16) = v;
+    v[i] = u32x4{0u, 0u, 0u, 0u};
+    if (tok0 + row < L) v[i] = *(const u32x4*)(g + (size_t)(tok0 + row) * C + part * 8);
   }
 }
-// stage a [64 ch][64 tok] tile from a transposed tensor (row stride L elements) into LDS rows of TROW bytes
-__device__ __forceinline__ void stage_cols(unsigned char* lds, const bf16* gt, int tok0, int L, int tid) {
+__device__ __forceinline__ void tile_store(unsigned char* lds, const u32x4 (&v)[2], int tid) {
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int e = tid + i * 256;
-    const int row = e >> 3, part = e & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (tok0 + part * 8 < L) v = *(const uint4*)(gt + (size_t)row * L + tok0 + part * 8);
-    *(uint2*)(lds + row * TROW + part * 16) = make_uint2(v.x, v.y);
-    *(uint2*)(lds + row * TROW + part * 16 + 8) = make_uint2(v.z, v.w);
+    *(u32x4*)(lds + (e >> 3) * KROW + (e & 7) * 16) = v[i];
   }
 }
-// fragment of a transposed tile: row `row`, the 8 tokens {16*s2 + 4h + 0..3, 16*s2 + 8 + 4h + 0..3} (+ base)
-__device__ __forceinline__ bf16x8 tfrag(const unsigned char* lds, int row, int tokbase, int h) {
-  const unsigned char* p = lds + row * TROW + (tokbase + 4 * h) * 2;
-  const uint2 lo = *(const uint2*)p, hi = *(const uint2*)(p + 16);
-  return __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+// Transposed fragment of a row-major tile via the gfx950 transposing LDS read: this lane gets channel
+// chbase + (lane & 31) of the 8 tokens {tokbase + 4h + 0..3, tokbase + 8 + 4h + 0..3} -- exactly the k order in which
+// an S^T / P accumulator (rows = tokens) is consumed as the other MFMA operand.
+__device__ __forceinline__ bf16x8 trfrag(const unsigned char* lds, int tokbase, int chbase, int lane) {
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const int grp = lane >> 4, hh = grp >> 1, q = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
+  const unsigned char* p0 = lds + (tokbase + 4 * hh + q) * KROW + (chbase + pcol) * 2;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * KROW));
+  s16x8 v;
+  v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+  v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+  return __builtin_bit_cast(bf16x8, v);
 }
 
 // ================================================================================================================
 // forward
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[64 * KROW + 64 * TROW];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW];
   unsigned char* K_lds = smem;
-  unsigned char* Vt_lds = smem + 64 * KROW;
+  unsigned char* V_lds = smem + 64 * KROW;
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int nqb = gridDim.x;
@@ -118,13 +120,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 
   const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
   const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
-  const bf16* vtg = (const bf16*)a.vt + (size_t)(b * a.heads + head) * 64 * Lk;
+  const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
 
   bf16x8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (qrow < Lq) v = *(const uint4*)(qg + (size_t)qrow * C + ks * 16 + h * 8);
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (qrow < Lq) v = *(const u32x4*)(qg + (size_t)qrow * C + ks * 16 + h * 8);
     qf[ks] = __builtin_bit_cast(bf16x8, v);
   }
   f32x16 o[2];
@@ -134,73 +136,79 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 
   const int trow = qb >> d.tshift, tmask = (1 << d.tshift) - 1;
   const int nkv = a.kv_num ? (a.kv_num[trow] << d.tshift) : (Lk + 127) / 128;
-  for (int j = 0; j < nkv; ++j) {
+  const int nsub = nkv * 2;
+  auto key_start = [&](int idx) __attribute__((always_inline)) {
+    const int j = idx >> 1;
     const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
-    for (int sub = 0; sub < 2; ++sub) {
-      const int key0 = kb * 128 + sub * 64;
-      if (key0 >= Lk) break;
-      __syncthreads();
-      stage_rows(K_lds, kg, key0, Lk, C, tid);
-      stage_cols(Vt_lds, vtg, key0, Lk, tid);
-      __syncthreads();
-      int cls = classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
-      if (key0 + 63 >= Lk && cls == 2) cls = 1;
-      if (cls == 0 || qw0 >= Lq) continue;
+    return kb * 128 + (idx & 1) * 64;
+  };
+  u32x4 rk[2], rv[2];
+  if (nsub > 0) { const int k0 = key_start(0); tile_load(rk, kg, k0, Lk, C, tid); tile_load(rv, vg, k0, Lk, C, tid); }
+#pragma unroll 1
+  for (int idx = 0; idx < nsub; ++idx) {
+    const int key0 = key_start(idx);
+    __syncthreads();
+    tile_store(K_lds, rk, tid);
+    tile_store(V_lds, rv, tid);
+    __syncthreads();
+    if (idx + 1 < nsub) { const int k1 = key_start(idx + 1); tile_load(rk, kg, k1, Lk, C, tid); tile_load(rv, vg, k1, Lk, C, tid); }
+    int cls = (key0 >= Lk) ? 0 : classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
+    if (key0 + 63 >= Lk && cls == 2) cls = 1;
+    if (cls == 0 || qw0 >= Lq) continue;
 
-      f32x16 s[2];
+    f32x16 s[2];
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
+      for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
-          s[kt] = mfma32(kf, qf[ks], s[kt]);
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
+        s[kt] = mfma32(kf, qf[ks], s[kt]);
+      }
+    }
+    float mx = NEG_BIG;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        float v = s[kt][rr] * SCALE_LOG2;
+        if (cls == 1) {
+          const int key = key0 + kt * 32 + mfma_row(rr, lane);
+          if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) v = NEG_BIG;
+        }
+        s[kt][rr] = v;
+        mx = fmaxf(mx, v);
+      }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m, mx);
+    const float m_use = (m_new == NEG_BIG) ? 0.f : m_new;
+    const float alpha = exp2f(m - m_use);
+    float rs = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const float p = exp2f(s[kt][rr] - m_use);
+        s[kt][rr] = p;
+        rs += p;
+      }
+    rs += __shfl_xor(rs, 32);
+    l = l * alpha + rs;
+    m = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pb = pack8(s[kt], s2);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 vf = trfrag(V_lds, kt * 32 + 16 * s2, dt * 32, lane);
+          o[dt] = mfma32(vf, pb, o[dt]);                   // O^T[dv][q] += V^T[dv][key] P^T[key][q]
         }
       }
-      float mx = NEG_BIG;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          float v = s[kt][rr] * SCALE_LOG2;
-          if (cls == 1) {
-            const int key = key0 + kt * 32 + mfma_row(rr, lane);
-            if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) v = NEG_BIG;
-          }
-          s[kt][rr] = v;
-          mx = fmaxf(mx, v);
-        }
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m, mx);
-      const float m_use = (m_new == NEG_BIG) ? 0.f : m_new;
-      const float alpha = exp2f(m - m_use);
-      float rs = 0.f;
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const float p = exp2f(s[kt][rr] - m_use);
-          s[kt][rr] = p;
-          rs += p;
-        }
-      rs += __shfl_xor(rs, 32);
-      l = l * alpha + rs;
-      m = m_new;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-#pragma unroll
-      for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pb = pack8(s[kt], s2);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 vf = tfrag(Vt_lds, dt * 32 + r, kt * 32 + 16 * s2, h);
-            o[dt] = mfma32(vf, pb, o[dt]);
-          }
-        }
-    }
   }
   if (qrow >= Lq) return;
   const float inv = (l > 0.f) ? 1.f / l : 0.f;
@@ -221,10 +229,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 // backward: dQ   (same loop structure as the forward, lane = query row)
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW + 64 * TROW];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW];
   unsigned char* K_lds = smem;
   unsigned char* V_lds = smem + 64 * KROW;
-  unsigned char* Kt_lds = smem + 2 * 64 * KROW;
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int nqb = gridDim.x;
@@ -238,15 +245,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
   const bf16* dog = (const bf16*)a.dout + (size_t)b * Lq * C + head * 64;
   const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
   const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
-  const bf16* ktg = (const bf16*)a.kt + (size_t)(b * a.heads + head) * 64 * Lk;
 
   bf16x8 qf[4], dof[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+    u32x4 v = u32x4{0u, 0u, 0u, 0u}, w = u32x4{0u, 0u, 0u, 0u};
     if (qrow < Lq) {
-      v = *(const uint4*)(qg + (size_t)qrow * C + ks * 16 + h * 8);
-      w = *(const uint4*)(dog + (size_t)qrow * C + ks * 16 + h * 8);
+      v = *(const u32x4*)(qg + (size_t)qrow * C + ks * 16 + h * 8);
+      w = *(const u32x4*)(dog + (size_t)qrow * C + ks * 16 + h * 8);
     }
     qf[ks] = __builtin_bit_cast(bf16x8, v);
     dof[ks] = __builtin_bit_cast(bf16x8, w);
@@ -262,48 +268,53 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
 
   const int trow = qb >> d.tshift, tmask = (1 << d.tshift) - 1;
   const int nkv = a.kv_num ? (a.kv_num[trow] << d.tshift) : (Lk + 127) / 128;
-  for (int j = 0; j < nkv; ++j) {
+  const int nsub = nkv * 2;
+  auto key_start = [&](int idx) __attribute__((always_inline)) {
+    const int j = idx >> 1;
     const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
-    for (int sub = 0; sub < 2; ++sub) {
-      const int key0 = kb * 128 + sub * 64;
-      if (key0 >= Lk) break;
-      __syncthreads();
-      stage_rows(K_lds, kg, key0, Lk, C, tid);
-      stage_rows(V_lds, vg, key0, Lk, C, tid);
-      stage_cols(Kt_lds, ktg, key0, Lk, tid);
-      __syncthreads();
-      int cls = classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
-      if (key0 + 63 >= Lk && cls == 2) cls = 1;
-      if (cls == 0 || qw0 >= Lq) continue;
+    return kb * 128 + (idx & 1) * 64;
+  };
+  u32x4 rk[2], rv[2];
+  if (nsub > 0) { const int k0 = key_start(0); tile_load(rk, kg, k0, Lk, C, tid); tile_load(rv, vg, k0, Lk, C, tid); }
+#pragma unroll 1
+  for (int idx = 0; idx < nsub; ++idx) {
+    const int key0 = key_start(idx);
+    __syncthreads();
+    tile_store(K_lds, rk, tid);
+    tile_store(V_lds, rv, tid);
+    __syncthreads();
+    if (idx + 1 < nsub) { const int k1 = key_start(idx + 1); tile_load(rk, kg, k1, Lk, C, tid); tile_load(rv, vg, k1, Lk, C, tid); }
+    int cls = (key0 >= Lk) ? 0 : classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
+    if (key0 + 63 >= Lk && cls == 2) cls = 1;
+    if (cls == 0 || qw0 >= Lq) continue;
 #pragma unroll
-      for (int kt = 0; kt < 2; ++kt) {
-        f32x16 s, dp;
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x16 s, dp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
-          s = mfma32(kf, qf[ks], s);
-          const bf16x8 vf = *(const bf16x8*)(V_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
-          dp = mfma32(vf, dof[ks], dp);
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
+        s = mfma32(kf, qf[ks], s);
+        const bf16x8 vf = *(const bf16x8*)(V_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
+        dp = mfma32(vf, dof[ks], dp);
+      }
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        float p = exp2f(s[rr] * SCALE_LOG2 - lse);
+        if (cls == 1) {
+          const int key = key0 + kt * 32 + mfma_row(rr, lane);
+          if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
         }
+        s[rr] = p * (dp[rr] - delta) * 0.125f;          // dS (scaled)
+      }
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          float p = exp2f(s[rr] * SCALE_LOG2 - lse);
-          if (cls == 1) {
-            const int key = key0 + kt * 32 + mfma_row(rr, lane);
-            if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
-          }
-          s[rr] = p * (dp[rr] - delta) * 0.125f;          // dS (scaled)
-        }
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 db = pack8(s, s2);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 db = pack8(s, s2);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 ktf = tfrag(Kt_lds, dt * 32 + r, kt * 32 + 16 * s2, h);
-            dq[dt] = mfma32(ktf, db, dq[dt]);
-          }
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 ktf = trfrag(K_lds, kt * 32 + 16 * s2, dt * 32, lane);
+          dq[dt] = mfma32(ktf, db, dq[dt]);              // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
         }
       }
     }
@@ -325,12 +336,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
 // backward: dK, dV   (lane = key)
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW + 2 * 64 * TROW + 2 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW + 2 * 64 * 4];
   unsigned char* Q_lds = smem;
   unsigned char* dO_lds = smem + 64 * KROW;
-  unsigned char* Qt_lds = smem + 2 * 64 * KROW;
-  unsigned char* dOt_lds = Qt_lds + 64 * TROW;
-  float* lse_lds = (float*)(dOt_lds + 64 * TROW);
+  float* lse_lds = (float*)(smem + 2 * 64 * KROW);
   float* del_lds = lse_lds + 64;
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -343,18 +352,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
   const bf16* dog = (const bf16*)a.dout + (size_t)b * Lq * C + head * 64;
   const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
   const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
-  const bf16* qtg = (const bf16*)a.qt + (size_t)(b * a.heads + head) * 64 * Lq;
-  const bf16* dotg = (const bf16*)a.doutt + (size_t)(b * a.heads + head) * 64 * Lq;
   const float* lseg = a.lse + (size_t)(b * a.heads + head) * Lq;
   const float* delg = a.delta + (size_t)(b * a.heads + head) * Lq;
 
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+    u32x4 v = u32x4{0u, 0u, 0u, 0u}, w = u32x4{0u, 0u, 0u, 0u};
     if (krow < Lk) {
-      v = *(const uint4*)(kg + (size_t)krow * C + ks * 16 + h * 8);
-      w = *(const uint4*)(vg + (size_t)krow * C + ks * 16 + h * 8);
+      v = *(const u32x4*)(kg + (size_t)krow * C + ks * 16 + h * 8);
+      w = *(const u32x4*)(vg + (size_t)krow * C + ks * 16 + h * 8);
     }
     kf[ks] = __builtin_bit_cast(bf16x8, v);
     vf[ks] = __builtin_bit_cast(bf16x8, w);
@@ -365,59 +372,70 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
 
   const int trow = kb >> d.tshift, tmask = (1 << d.tshift) - 1;
   const int nq = a.q_num ? (a.q_num[trow] << d.tshift) : (Lq + 127) / 128;
-  for (int j = 0; j < nq; ++j) {
+  const int nsub = nq * 2;
+  auto q_start = [&](int idx) __attribute__((always_inline)) {
+    const int j = idx >> 1;
     const int qblk = a.q_idx ? ((a.q_idx[(size_t)trow * a.qtab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
-    for (int sub = 0; sub < 2; ++sub) {
-      const int q0 = qblk * 128 + sub * 64;
-      if (q0 >= Lq) break;
-      __syncthreads();
-      stage_rows(Q_lds, qg, q0, Lq, C, tid);
-      stage_rows(dO_lds, dog, q0, Lq, C, tid);
-      stage_cols(Qt_lds, qtg, q0, Lq, tid);
-      stage_cols(dOt_lds, dotg, q0, Lq, tid);
-      if (tid < 64) lse_lds[tid] = (q0 + tid < Lq) ? lseg[q0 + tid] : 0.f;
-      else if (tid < 128) del_lds[tid - 64] = (q0 + tid - 64 < Lq) ? delg[q0 + tid - 64] : 0.f;
-      __syncthreads();
-      if (kw0 >= Lk) continue;
+    return qblk * 128 + (idx & 1) * 64;
+  };
+  u32x4 rq[2], rdo[2];
+  float rstat = 0.f;
+  auto load_sub = [&](int q0) __attribute__((always_inline)) {
+    tile_load(rq, qg, q0, Lq, C, tid);
+    tile_load(rdo, dog, q0, Lq, C, tid);
+    rstat = 0.f;
+    if (tid < 64) { if (q0 + tid < Lq) rstat = lseg[q0 + tid]; }
+    else if (tid < 128) { if (q0 + tid - 64 < Lq) rstat = delg[q0 + tid - 64]; }
+  };
+  if (nsub > 0) load_sub(q_start(0));
+#pragma unroll 1
+  for (int idx = 0; idx < nsub; ++idx) {
+    const int q0 = q_start(idx);
+    __syncthreads();
+    tile_store(Q_lds, rq, tid);
+    tile_store(dO_lds, rdo, tid);
+    if (tid < 128) lse_lds[tid] = rstat;            // lse_lds[0..63] | del_lds[0..63] are contiguous
+    __syncthreads();
+    if (idx + 1 < nsub) load_sub(q_start(idx + 1));
+    if (kw0 >= Lk || q0 >= Lq) continue;
 #pragma unroll
-      for (int qt = 0; qt < 2; ++qt) {
-        const int qq0 = q0 + qt * 32;
-        int cls = classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off);
-        if ((qq0 + 31 >= Lq || kw0 + 31 >= Lk) && cls == 2) cls = 1;
-        if (cls == 0 || qq0 >= Lq) continue;
-        f32x16 s, dp;
+    for (int qt = 0; qt < 2; ++qt) {
+      const int qq0 = q0 + qt * 32;
+      int cls = classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off);
+      if ((qq0 + 31 >= Lq || kw0 + 31 >= Lk) && cls == 2) cls = 1;
+      if (cls == 0 || qq0 >= Lq) continue;
+      f32x16 s, dp;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+      for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 qa = *(const bf16x8*)(Q_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
-          s = mfma32(qa, kf[ks], s);                       // S[q][key]
-          const bf16x8 da = *(const bf16x8*)(dO_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
-          dp = mfma32(da, vf[ks], dp);                     // dP[q][key]
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 qa = *(const bf16x8*)(Q_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
+        s = mfma32(qa, kf[ks], s);                       // S[q][key]
+        const bf16x8 da = *(const bf16x8*)(dO_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
+        dp = mfma32(da, vf[ks], dp);                     // dP[q][key]
+      }
+      f32x16 pv;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int ql = qt * 32 + mfma_row(rr, lane);
+        float p = exp2f(s[rr] * SCALE_LOG2 - lse_lds[ql]);
+        if (cls == 1) {
+          const int qtok = q0 + ql;
+          if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
         }
-        f32x16 pv;
+        pv[rr] = p;
+        s[rr] = p * (dp[rr] - del_lds[ql]) * 0.125f;     // dS (scaled)
+      }
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) {
-          const int ql = qt * 32 + mfma_row(rr, lane);
-          float p = exp2f(s[rr] * SCALE_LOG2 - lse_lds[ql]);
-          if (cls == 1) {
-            const int qtok = q0 + ql;
-            if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
-          }
-          pv[rr] = p;
-          s[rr] = p * (dp[rr] - del_lds[ql]) * 0.125f;     // dS (scaled)
-        }
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const bf16x8 pb = pack8(pv, s2);
+        const bf16x8 db = pack8(s, s2);
 #pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pb = pack8(pv, s2);
-          const bf16x8 db = pack8(s, s2);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            const bf16x8 dof = tfrag(dOt_lds, dt * 32 + r, qt * 32 + 16 * s2, h);
-            dv[dt] = mfma32(dof, pb, dv[dt]);              // dV^T[dv][key] += dO^T[dv][q] P[q][key]
-            const bf16x8 qtf = tfrag(Qt_lds, dt * 32 + r, qt * 32 + 16 * s2, h);
-            dk[dt] = mfma32(qtf, db, dk[dt]);              // dK^T[d][key]  += Q^T[d][q] dS[q][key]
-          }
+        for (int dt = 0; dt < 2; ++dt) {
+          const bf16x8 dof = trfrag(dO_lds, qt * 32 + 16 * s2, dt * 32, lane);
+          dv[dt] = mfma32(dof, pb, dv[dt]);              // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+          const bf16x8 qtf = trfrag(Q_lds, qt * 32 + 16 * s2, dt * 32, lane);
+          dk[dt] = mfma32(qtf, db, dk[dt]);              // dK^T[d][key]  += Q^T[d][q] dS[q][key]
         }
       }
     }
@@ -638,7 +656,7 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
   AttnDev d;
   int rc = attn_prepare(args, d, "attn_fwd");
   if (rc) return rc;
-  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.vt && d.a.out, "attn_fwd: null pointer");
+  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.out, "attn_fwd: null pointer");
   const dim3 grid(cdiv(d.a.Lq, 128), d.a.heads, d.a.B);
   ATTN_DISPATCH(attn_fwd_kernel, grid);
   ONIRIS_LAUNCH_CHECK();
@@ -650,7 +668,7 @@ extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t st
   AttnDev d;
   int rc = attn_prepare(args, d, "attn_bwd_dq");
   if (rc) return rc;
-  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.kt && d.a.dout && d.a.lse && d.a.delta && d.a.dq,
+  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.dout && d.a.lse && d.a.delta && d.a.dq,
                    "attn_bwd_dq: null pointer");
   const dim3 grid(cdiv(d.a.Lq, 128), d.a.heads, d.a.B);
   ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
@@ -663,7 +681,7 @@ extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t s
   AttnDev d;
   int rc = attn_prepare(args, d, "attn_bwd_dkv");
   if (rc) return rc;
-  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.qt && d.a.dout && d.a.doutt && d.a.lse && d.a.delta && d.a.dk && d.a.dv,
+  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.dout && d.a.lse && d.a.delta && d.a.dk && d.a.dv,
                    "attn_bwd_dkv: null pointer");
   const dim3 grid(cdiv(d.a.Lk, 128), d.a.heads, d.a.B);
   ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);

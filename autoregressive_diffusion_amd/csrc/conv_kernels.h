@@ -68,8 +68,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   const int b = bid % a.B;
   const int co0 = (bid / a.B) * BN;
 
-  // ---- this lane's position
-  const int p = wave * 32 + r;
+  // ---- this lane's position.  For 16-wide patches the 32 positions of a wave (2 patch rows x 16 px) are dealt to
+  // the lanes so that each 16-lane group of a ds_read_b128 ({0-3,12-15,20-27} / {4-11,16-19,28-31}) reads 16
+  // CONSECUTIVE halo rows: with 80-byte rows that is conflict-free (the natural order is 2-way on every read).
+  int pr = r;
+  if constexpr (TAPS == 9 && PW == 16) {
+    const bool ga = (r < 4) || (r >= 12 && r < 16) || (r >= 20 && r < 28);
+    const int k = ga ? ((r < 4) ? r : (r < 16) ? r - 8 : r - 12) : ((r < 12) ? r - 4 : (r < 20) ? r - 8 : r - 16);
+    pr = (ga ? 0 : 16) + k;
+  }
+  const int p = wave * 32 + pr;
   int ft = 0, py = 0, px = 0, arow = p;
   if constexpr (TAPS == 9) {
     ft = p / (P::PH * P::PW); py = (p / P::PW) % P::PH; px = p % P::PW;
@@ -103,59 +111,79 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.ctx_fill));
   const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
 
+  // per-thread load descriptors, computed ONCE (the halo decode needs divisions by (PW+2), (PH+2)):
+  //   bit 31 valid | bit 30 slot | bits 25..29 frame-in-tile | bits 0..24 (y*W+x)*Cin + part*8
+  unsigned adesc[NIA];
+  if constexpr (TAPS == 9) {
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int e = tid + i * 256;
+      adesc[i] = 0u;
+      if (e < TOTA) {
+        const int row = e / PARTS, part = e % PARTS;
+        const int s = row / P::HALO, hr = row % P::HALO;
+        const int f_ = hr / (P::HH * P::HW), rem = hr % (P::HH * P::HW);
+        const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1;
+        if (t0 + f_ < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+          adesc[i] = 0x80000000u | ((unsigned)s << 30) | ((unsigned)f_ << 25) | (unsigned)((y * W + x) * Cin + part * 8);
+      }
+    }
+  }
+  const int part8 = (tid % PARTS) * 8;
+  const int frame_elems = HWp * Cin;
+  const bf16* xb = xg + (size_t)b * S * T * frame_elems;                       // this batch element's frames
+  const bf16* cb_ = HAS_CTX ? cg + (size_t)b * a.ctx_bstride * frame_elems : nullptr;
+  const int wrow0 = tid / PARTS;
+
   auto load_phase = [&](int ch, int ph) __attribute__((always_inline)) {
     const int c0 = ch * CK;
-    if (ph == 0) {
+    const bool cok = (c0 + part8) < Cin;
+    if constexpr (TAPS == 9) {
+      if (ph == 0) {
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+          const unsigned dsc = adesc[i];
+          ra[i] = u32x4{0u, 0u, 0u, 0u};
+          if ((dsc >> 31) && cok) {
+            const int fr = (int)((dsc >> 30) & 1u) * T + t0 + (int)((dsc >> 25) & 31u);
+            ra[i] = *(const u32x4*)(xb + (fr * frame_elems + (int)(dsc & 0x1ffffffu) + c0));
+          }
+        }
+      } else {
+        const int coff = (ph == 1) ? a.coff0 : a.coff1;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+          const unsigned dsc = adesc[i];
+          ra[i] = u32x4{0u, 0u, 0u, 0u};
+          if (tid + i * 256 < TOTC && (dsc >> 31) && cok) {     // rows < HALO are the slot-0 rows of the own image
+            const int f = t0 + (int)((dsc >> 25) & 31u) + coff;
+            if (f >= 0 && f < a.ctx_T) ra[i] = *(const u32x4*)(cb_ + (f * frame_elems + (int)(dsc & 0x1ffffffu) + c0));
+            else ra[i] = u32x4{fill2, fill2, fill2, fill2};
+          }
+        }
+      }
+    } else {
 #pragma unroll
       for (int i = 0; i < NIA; ++i) {
         const int e = tid + i * 256;
         ra[i] = u32x4{0u, 0u, 0u, 0u};
         if (e < TOTA) {
-          const int row = e / PARTS, part = e % PARTS;
-          const int ci = c0 + part * 8;
-          if constexpr (TAPS == 9) {
-            const int s = row / P::HALO, hr = row % P::HALO;
-            const int f_ = hr / (P::HH * P::HW), rem = hr % (P::HH * P::HW);
-            const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1, t = t0 + f_;
-            if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin)
-              ra[i] = *(const u32x4*)(xg + ((size_t)((b * S + s) * T + t) * HWp + y * W + x) * Cin + ci);
-          } else {
-            const int s = row / 128, q = q0 + (row % 128);
-            if (q < T * HWp && ci < Cin)
-              ra[i] = *(const u32x4*)(xg + ((size_t)(b * S + s) * T * HWp + q) * Cin + ci);
-          }
-        }
-      }
-    } else {
-      const int coff = (ph == 1) ? a.coff0 : a.coff1;
-#pragma unroll
-      for (int i = 0; i < NIA; ++i) {
-        const int e = tid + i * 256;
-        ra[i] = u32x4{0u, 0u, 0u, 0u};
-        if (e < TOTC) {
-          const int row = e / PARTS, part = e % PARTS;
-          const int ci = c0 + part * 8;
-          const int f_ = row / (P::HH * P::HW), rem = row % (P::HH * P::HW);
-          const int y = y0 + rem / P::HW - 1, x = x0 + rem % P::HW - 1, t = t0 + f_;
-          if (t < T && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W && ci < Cin) {
-            const int f = t + coff;
-            if (f >= 0 && f < a.ctx_T)
-              ra[i] = *(const u32x4*)(cg + ((size_t)(b * a.ctx_bstride + f) * HWp + y * W + x) * Cin + ci);
-            else
-              ra[i] = u32x4{fill2, fill2, fill2, fill2};
-          }
+          const int row = e / PARTS;
+          const int s = row / 128, q = q0 + (row % 128);
+          if (q < T * HWp && cok)
+            ra[i] = *(const u32x4*)(xg + ((size_t)(b * S + s) * T * HWp + q) * Cin + c0 + part8);
         }
       }
     }
-    const bf16* wg = (ph == 0) ? (const bf16*)a.w_own
-                               : (const bf16*)a.w_ctx + (size_t)(ph - 1) * TAPS * a.CoutP * a.CinP;
+    const bf16* wg = ((ph == 0) ? (const bf16*)a.w_own
+                                : (const bf16*)a.w_ctx + (size_t)(ph - 1) * TAPS * a.CoutP * a.CinP) +
+                     (size_t)co0 * a.CinP + c0 + part8;
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
-      const int e = tid + i * 256;
-      if (e < TOTW) {
-        const int row = e / PARTS, part = e % PARTS;
+      const int row = wrow0 + i * (256 / PARTS);
+      if (tid + i * 256 < TOTW) {
         const int tap = row / BN, co = row % BN;
-        rw[i] = *(const u32x4*)(wg + ((size_t)tap * a.CoutP + co0 + co) * a.CinP + c0 + part * 8);
+        rw[i] = *(const u32x4*)(wg + (tap * a.CoutP + co) * a.CinP);
       }
     }
   };
@@ -276,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
           bf16x4 o;
 #pragma unroll
           for (int k = 0; k < 4; ++k) o[k] = f2bf(v[nt][4 * g + k]);
-          *(bf16x4*)(ep + r * EROW + (nt * 32 + 8 * g + 4 * h) * 2) = o;
+          *(bf16x4*)(ep + pr * EROW + (nt * 32 + 8 * g + 4 * h) * 2) = o;
         }
     };
     if (a.epi == ONIRIS_EPI_MPSUM) {

@@ -585,41 +585,33 @@ class _AttentionFn(torch.autograd.Function):
         else:
             frames, Bq, L = 1, N, P
             tabs_r, mask_mode, tabs = None, 0, None
-        qt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev) if need_grad else None
-        kt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev) if need_grad else None
-        vt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev)
         if kind == "video":
             qr, kr = torch.empty_like(q), torch.empty_like(k)
-            _rope(q, qr, qt, tabs_r, 1, Bq, frames, P, C, 0, T)
-            _rope(k, kr, kt, tabs_r, 2, Bq, frames, P, C, 0, T)
+            _rope(q, qr, None, tabs_r, 1, Bq, frames, P, C, 0, T)
+            _rope(k, kr, None, tabs_r, 2, Bq, frames, P, C, 0, T)
         else:
             qr, kr = q, k
-            if need_grad:
-                _rope(q, None, qt, None, 0, Bq, L, 1, C, 0, 1)
-                _rope(k, None, kt, None, 0, Bq, L, 1, C, 0, 1)
-        _rope(v, None, vt, None, 0, Bq, L, 1, C, 0, 1)
         out = torch.empty((N, P, C), dtype=BF16, device=dev)
         lse = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
-        a = _attn_args(qr, kr, v, qt, kt, vt, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
+        a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
         check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
         ctx.meta = (kind, B, T, heads, Bq, L, frames, P, C, mask_mode)
         ctx.tabs, ctx.tabs_r = tabs, tabs_r
-        ctx.save_for_backward(qkv, qr, kr, v, qt, kt, vt, out, lse)
+        ctx.save_for_backward(qkv, qr, kr, v, out, lse)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, qr, kr, v, qt, kt, vt, out, lse = ctx.saved_tensors
+        qkv, qr, kr, v, out, lse = ctx.saved_tensors
         kind, B, T, heads, Bq, L, frames, P, C, mask_mode = ctx.meta
         dev = qkv.device
         dout = dout.contiguous()
         delta = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
-        doutt = torch.empty((Bq, heads, 64, L), dtype=BF16, device=dev)
-        check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), _p(doutt), Bq, heads, L, C, _stream()),
+        check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), None, Bq, heads, L, C, _stream()),
               "attn_bwd_prep")
         dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
-        a = _attn_args(qr, kr, v, qt, kt, vt, out, lse, ctx.tabs, Bq, heads, L, L, C, mask_mode, P, T)
-        a.dout, a.doutt, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(doutt), _p(delta), _p(dq), _p(dk), _p(dv)
+        a = _attn_args(qr, kr, v, None, None, None, out, lse, ctx.tabs, Bq, heads, L, L, C, mask_mode, P, T)
+        a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
         check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq")
         check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv")
         if kind == "video":
@@ -658,10 +650,8 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     Lq, Lk = t * P, nk * P
     tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], nk, dev)
     qr, kr = torch.empty_like(q), torch.empty_like(k)
-    vt = torch.empty((B, heads, 64, Lk), dtype=BF16, device=dev)
     _rope(q, qr, None, tabs_r, 1, B, t, P, C, nk - t, nk)
     _rope(k, kr, None, tabs_r, 2, B, nk, P, C, 0, nk)
-    _rope(v, None, vt, None, 0, B, Lk, 1, C, 0, 1)
     out = torch.empty((N, P, C), dtype=BF16, device=dev)
     if t == 1:
         mask_mode, tabs = 0, None                               # one new frame: dense SDPA over all keys (:69-70)
@@ -670,7 +660,7 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
         tabs = device_tables("infer", t, P, dev)
     else:
         raise NotImplementedError("The inference mask is not implemented for this case")
-    a = _attn_args(qr, kr, v, None, None, vt, out, None, tabs, B, heads, Lq, Lk, C, mask_mode, P, 0)
+    a = _attn_args(qr, kr, v.contiguous(), None, None, None, out, None, tabs, B, heads, Lq, Lk, C, mask_mode, P, 0)
     check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
     return out, new_cache
 

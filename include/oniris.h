@@ -179,7 +179,8 @@ int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const flo
 
 /* Block-sparse flash attention forward (replaces compiled_flex_attention / F.scaled_dot_product_attention,
  * attention_modules.py:41,66,70,75,115).  q [B][Lq][C], k,v [B][Lk][C] bf16 (head h = channels 64h..64h+63),
- * vt [B][heads][64][Lk].  softmax scale 1/sqrt(64).
+ * (the transposed operands V^T, K^T, Q^T, dO^T are produced inside the kernels by transposing LDS reads; the
+ * qt/kt/vt/doutt fields are reserved and may be NULL).  softmax scale 1/sqrt(64).
  *   mask_mode 0: dense;  1: frame-causal (key frame <= query frame, frames of P tokens; query frames are the
  *   LAST Lq/P frames of the key sequence);  2: DART training mask (mask_mod of TrainingMask, T frames per half).
  *   kv_num/kv_idx: device int32 table of 128-token blocks for one (b,h) ([nrows], [nrows][ncols]); NULL = every
