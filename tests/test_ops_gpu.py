@@ -298,3 +298,117 @@ def test_adamw():
         opt.step()
         ops.adamw_(p, (g0 * step).to(DEV), m, v, 1e-2, 0.9, 0.99, 1e-8, 0.01, step)
     assert rel(p, pr.data) < 1e-5
+
+
+@pytest.mark.parametrize("C1,C2,norm", [(64, 0, True), (32, 0, True), (256, 0, True), (64, 32, False), (96, 96, False), (48, 0, False)])
+def test_act_fused(C1, C2, norm):
+    """[mp_cat | pixel norm] + mp_silu in one pass (utils.py:83-134) and its adjoint, vs the oracle primitives."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(9)
+    N, H = 3, 8
+    x0 = bfr(torch.randn(N, C1, H, H) * 1.5)
+    s0 = bfr(torch.randn(N, C2, H, H)) if C2 else None
+    w1, w2 = (0.8, 1.3) if C2 else (1.0, 1.0)
+    x = nhwc(x0).requires_grad_(True)
+    sk = nhwc(s0).requires_grad_(True) if C2 else None
+    res = ops.act(x, sk, w1, w2, norm=norm, want_xo=bool(C2))
+    xo, a = res if isinstance(res, tuple) else (None, res)
+    ga0 = bfr(torch.randn(N, C1 + C2, H, H))
+    gx0 = bfr(torch.randn(N, C1 + C2, H, H))
+    tot = (a.float() * nhwc(ga0).float()).sum()
+    if xo is not None:
+        tot = tot + (xo.float() * nhwc(gx0).float()).sum()
+    tot.backward()
+    xr = x0.clone().requires_grad_(True)
+    sr = s0.clone().requires_grad_(True) if C2 else None
+    v = torch.cat([xr * w1, sr * w2], 1) if C2 else xr
+    if norm:
+        v = O.normalize(v, dim=1)
+    ar = O.mp_silu(v)
+    totr = (ar * ga0).sum() + ((v * gx0).sum() if xo is not None else 0)
+    totr.backward()
+    e = [rel(nchw(a), ar), rel(nchw(x.grad), xr.grad)]
+    if xo is not None:
+        e.append(rel(nchw(xo), v))
+    if C2:
+        e.append(rel(nchw(sk.grad), sr.grad))
+    print("act", (C1, C2, norm), e)
+    assert max(e) < 1e-2
+
+
+def test_resample_fused():
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(10)
+    x0 = bfr(torch.randn(3, 32, 8, 8))
+    for mode in ("down", "up"):
+        x = nhwc(x0).requires_grad_(True)
+        y = ops.resample(x, mode)
+        g0 = bfr(torch.randn(nchw(y).shape))
+        y.backward(nhwc(g0))
+        xr = x0.clone().requires_grad_(True)
+        yr = O.resample(xr, mode)
+        (yr * g0).sum().backward()
+        assert rel(nchw(y), yr) < 5e-3 and rel(nchw(x.grad), xr.grad) < 5e-3
+
+
+@pytest.mark.parametrize("gated", [False, True])
+def test_conv_epilogues(gated):
+    """conv + (x c, mp_silu) and conv + (mp_sum with residual, clip) epilogues, forward and backward."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(11)
+    B, T, H, cin, cout = 1, 4, 8, 32, 64
+    N = B * 2 * T
+    w2 = O.normalize(O.normalize(torch.randn(cout, cin, 3, 3)))
+    w3 = O.normalize(O.normalize(torch.randn(cout, cin, 2, 3, 3)))
+    F = torch.nn.functional
+    for epi in ("emb_silu", "mpsum"):
+        p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
+        bank, (pw2, pw3) = make_bank([p2, p3])
+        bank.prepare(training=True)
+        x0 = bfr(torch.randn(N, cin, H, H))
+        g0 = torch.rand(N) * 0.5 + 0.05
+        c0 = 1 + 0.3 * torch.randn(N, cout)
+        r0 = bfr(torch.randn(N, cout, H, H) * 200)            # large residual so that the +-256 clip is active
+        gy0 = bfr(torch.randn(N, cout, H, H))
+        x = nhwc(x0).requires_grad_(True)
+        gate = g0.clone().to(DEV).requires_grad_(True)
+        cs = c0.clone().to(DEV).requires_grad_(True)
+        res = nhwc(r0).requires_grad_(True)
+        kw = dict(cscale=cs) if epi == "emb_silu" else dict(res=res, ta=0.9, tb=0.4, clip=256.0)
+        y = ops.gated_conv_train(x, gate, pw2, pw3, B, T, **kw) if gated else ops.conv(x, pw2, **kw)
+        y.backward(nhwc(gy0))
+        # oracle
+        xr, gr = x0.clone().requires_grad_(True), g0.clone().requires_grad_(True)
+        cr, rr = c0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+        w2r, w3r = w2.clone().requires_grad_(True), w3.clone().requires_grad_(True)
+        e2, _ = O.weight_effective(w2r, 1.0, True)
+        v = F.conv2d(xr, e2, padding=1)
+        if gated:
+            e3, _ = O.weight_effective(w3r, 1.0, True)
+            clean = xr.reshape(B, 2, T, cin, H, H)[:, 0]
+            ctx = torch.cat([torch.ones(B, 2, cin, H, H), clean], 1)
+            y3 = F.conv2d(ctx[:, 0:T].reshape(B * T, cin, H, H), e3[:, :, 0], padding=1) + \
+                F.conv2d(ctx[:, 1:T + 1].reshape(B * T, cin, H, H), e3[:, :, 1], padding=1)
+            y3 = y3.reshape(B, 1, T, cout, H, H).expand(B, 2, T, cout, H, H).reshape(N, cout, H, H)
+            v = O.mp_sum(v, y3, gr)
+        if epi == "emb_silu":
+            yr = O.mp_silu(v * cr[:, :, None, None])
+        else:
+            # the pass-through mask of clamp is taken from the bf16 result: elements within one bf16 ulp (2.0) of +-256
+            # legitimately fall on the other side of the threshold than in fp32, and each such element is an O(1)
+            # gradient difference (sqrt(fraction) in relative L2) that says nothing about the kernel
+            pre = 0.9 * rr + 0.4 * v
+            keep = (nchw(y).abs() < 256).float()
+            yr = pre * keep + pre.detach().clamp(-256, 256) * (1 - keep)
+        (yr * gy0).sum().backward()
+        e = dict(y=rel(nchw(y), yr), dx=rel(nchw(x.grad), xr.grad), dw2=rel(p2.grad, w2r.grad))
+        if epi == "emb_silu":
+            e["dc"] = rel(cs.grad, cr.grad)
+        else:
+            e["dres"] = rel(nchw(res.grad), rr.grad)
+            assert float((nchw(y).abs() >= 256).float().mean()) > 0.01, "clip not exercised"
+        if gated:
+            e["dw3"], e["dg"] = rel(p3.grad, w3r.grad), rel(gate.grad, gr.grad)
+        print("conv epilogue", epi, "gated" if gated else "plain", e)
+        assert e["y"] < 1e-2 and e["dx"] < 1.5e-2 and e["dw2"] < 2e-2
+        assert all(v_ < 3e-2 for v_ in e.values()), e
