@@ -48,6 +48,39 @@ def cpu_baseline(frames):
                        f"forward+backward step, {dt:.1f} s")
 
 
+def rollout(args):
+    """BASELINE config 5: edm2/sampler.py autoregressive rollout with KV / activation caches (plotting.py:163-166
+    settings: num_steps=16, rho=2, sigma in [0.01, 80], S_churn=0, guidance=1 -> 31 UNet evaluations per frame)."""
+    import torch
+    from edm2.networks_edm2 import UNet, Precond
+    from edm2.sampler import edm_sampler_with_mse
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    unet = UNet(**GYM_CFG).to(dev)
+    torch.nn.init.constant_(unet.out_gain, 1.0)
+    net = Precond(unet, sigma_data=1.0).to(dev).eval()
+    B, ctx_frames = args.batch, 8
+    with torch.no_grad():
+        ctx = torch.randn(B, ctx_frames, 8, 64, 64, device=dev)
+        lab = torch.randint(0, 4, (B, ctx_frames), device=dev)
+        _, cache = net(ctx, torch.ones(B, ctx_frames, device=dev) * 0.05, lab, update_cache=True)
+        for i in range(2):                      # warm-up frames
+            _, _, _, cache = edm_sampler_with_mse(net, cache, conditioning=lab[:, :1], num_steps=16, sigma_min=0.01,
+                                                  sigma_max=80, rho=2)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.gen_frames):
+            x, _, _, cache = edm_sampler_with_mse(net, cache, conditioning=lab[:, :1], num_steps=16, sigma_min=0.01,
+                                                  sigma_max=80, rho=2)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    evals = 31 * args.gen_frames
+    print(json.dumps({"metric": "rollout generated frames/s (config 5, KV-cached sampler)", "value": B * args.gen_frames / dt,
+                      "unit": "frames/s", "n_gpus": 1, "ms_per_unet_eval": dt / evals * 1e3, "frames_generated": args.gen_frames,
+                      "context_frames": ctx_frames + 2, "batch": B, "dtype": "bf16", "data": "synthetic",
+                      "finite": bool(torch.isfinite(x).all())}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -57,7 +90,12 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--mode", choices=["train", "rollout"], default="train",
+                    help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
+    ap.add_argument("--gen-frames", type=int, default=8)
     args = ap.parse_args()
+    if args.mode == "rollout":
+        return rollout(args)
 
     import torch
     import torch.distributed as dist
