@@ -114,7 +114,9 @@ def batched_gates(convs, c_noise, caches, training):
     lo = torch.sigmoid(torch.stack([m.gating.min_gating for m in convs]))[:, None, None]
     hi = torch.sigmoid(torch.stack([m.gating.max_gating for m in convs]))[:, None, None]
     base = (torch.arange(B * tt, device=dev) % T).reshape(1, B, tt)
-    pos = (base + torch.tensor(n_ctx, device=dev).reshape(-1, 1, 1)).to(c_noise.dtype).log1p()
+    if any(n_ctx):
+        base = base + torch.tensor(n_ctx, device=dev).reshape(-1, 1, 1)
+    pos = base.to(c_noise.dtype).log1p()              # (no host->device copy in training: hipGraph-capturable)
     sv = c_noise[None] * mult[:, 0, None, None] + off[:, 0, None, None] + pos * mult[:, 1, None, None] + off[:, 1, None, None]
     g = (lo + (1 - lo) * hi * torch.sigmoid(sv)).reshape(len(convs), -1)
     ca, cb = ops.gate_coefs(g)

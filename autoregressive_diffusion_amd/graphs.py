@@ -1,0 +1,42 @@
+"""hipGraph capture of a static-shape training micro-step (forward + backward of the denoiser), replayed every step.
+
+The reference relies on torch.compile for its attention kernel only; here the whole launch sequence (~1500 small and
+large kernels per step, all enqueued on one HIP stream with caller-allocated buffers and no host synchronisation)
+is captured once per step flavour (3-D / 2-D) and replayed, which removes the per-launch host cost.  The optimizer and
+the gradient all-reduce stay outside the graph (their arguments change per step / they talk to RCCL)."""
+import torch
+
+_capture_stream = None
+
+
+class GraphedStep:
+    def __init__(self, fn, warmup=3):
+        """fn(): runs forward+backward on STATIC input tensors and returns a (loss) tensor."""
+        self.fn, self.warmup = fn, warmup
+        self.graph, self.out, self.calls = None, None, 0
+        # ONE side stream for the warm-up and the capture of EVERY GraphedStep: autograd pins each parameter's
+        # AccumulateGrad node to the stream it was first used on; a node living on another stream would run outside
+        # the capture (its work silently missing from the replay).
+        global _capture_stream
+        if _capture_stream is None:
+            _capture_stream = torch.cuda.Stream()
+        self.stream = _capture_stream
+
+    def __call__(self):
+        if self.graph is not None:
+            self.graph.replay()
+            return self.out
+        self.calls += 1
+        if self.calls <= self.warmup:              # eager warm-up: builds tables, sets kernel attributes, fills caches
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                out = self.fn()
+            torch.cuda.current_stream().wait_stream(self.stream)
+            return out
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self.stream):
+            out = self.fn()
+        self.graph, self.out = g, out
+        g.replay()
+        return self.out

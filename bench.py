@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs")
     ap.add_argument("--mode", choices=["train", "rollout"], default="train",
                     help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
     ap.add_argument("--gen-frames", type=int, default=8)
@@ -132,11 +133,35 @@ def main():
     latents = torch.randn(B, T, 8, 64, 64, device=dev, generator=g)
     actions = torch.randint(0, 4, (B, T), device=dev, generator=g)
 
-    def step(i):
-        just_2d = (i % 4 == 0)                                   # gym_train.py:96
+    def fwd_bwd(just_2d):
         opt.zero_grad()
         loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
         loss.backward()
+        return loss
+
+    use_graph = not args.no_graph
+    graphed = {}
+    if use_graph:
+        from autoregressive_diffusion_amd.graphs import GraphedStep
+        if world > 1:      # the graph holds forward+backward only; the RCCL exchange is issued eagerly after the replay
+            def make(j2d):
+                def f():
+                    with model.no_sync():
+                        return fwd_bwd(j2d)
+                return f
+        else:
+            def make(j2d):
+                return lambda: fwd_bwd(j2d)
+        graphed = {False: GraphedStep(make(False)), True: GraphedStep(make(True))}
+
+    def step(i, profile=False):
+        just_2d = (i % 4 == 0)                                   # gym_train.py:96
+        if use_graph and not profile:
+            loss = graphed[just_2d]()
+            if world > 1:
+                model.allreduce_grads()
+        else:
+            loss = fwd_bwd(just_2d)
         if world > 1:
             model.wait()
         opt.step()
@@ -147,7 +172,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 16 if use_graph else 0)):     # graphs: 3 eager + 1 capture call per step flavour
         step(i)
     fence()
     t0 = time.perf_counter()
@@ -170,8 +195,8 @@ def main():
     roof, kernels = None, None
     if rank == 0 and not args.no_profile:
         ops.KernelProfile.start()
-        for i in range(4):                                        # one full 3:1 cycle, every MFMA conv launch bracketed
-            step(i)                                               # by HIP events on its own stream
+        for i in range(4):                                        # one full 3:1 cycle (eager), every MFMA conv launch
+            step(i, profile=True)                                 # bracketed by HIP events on its own stream
         agg = ops.KernelProfile.stop()
         kernels = {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
                            tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in
@@ -183,7 +208,7 @@ def main():
                     unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=None)
     elif world > 1:
         for i in range(4):
-            step(i)                                               # keep collectives matched across ranks
+            step(i, profile=True)                                 # keep collectives matched across ranks
     cpu = None
     if rank == 0 and world == 1 and args.cpu_frames > 0:
         cpu = cpu_baseline(args.cpu_frames)
@@ -199,7 +224,8 @@ def main():
                "config": {"workload": f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), "
                                       f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + AdamW, 3:1 mix of "
                                       f"3-D/2-D steps", "global_batch": world * B, "seq_len": T,
-                          "parallelism": f"dp{world}", **{k: round(v, 2) for k, v in per_mode.items()}},
+                          "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                          **{k: round(v, 2) for k, v in per_mode.items()}},
                "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
         print(json.dumps(out))
     if world > 1:

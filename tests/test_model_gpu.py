@@ -252,3 +252,40 @@ def test_cs_shaped_unet_vs_oracle():
     assert abs(loss.item() - ref.item()) / abs(ref.item()) < 2e-2
     assert np.median(list(errs.values())) < 2e-2 and errs[worst] < 8e-2
     assert prm["unet.emb_label.weight.weight"].grad is None or float(prm["unet.emb_label.weight.weight"].grad.abs().max()) == 0
+
+
+def test_hipgraph_step_matches_eager():
+    """The captured-and-replayed training micro-step (graphs.GraphedStep) follows the eager trajectory."""
+    from edm2.loss import EDM2Loss
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW
+    from autoregressive_diffusion_amd.graphs import GraphedStep
+    g = torch.Generator().manual_seed(77)
+    images = torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (1, 4), generator=g).to(DEV)
+    sig3, eps3 = (torch.randn(1, 8, generator=g) + 0.4).exp().to(DEV), torch.randn(1, 8, 4, 32, 32, generator=g).to(DEV)
+    sig2, eps2 = (torch.randn(1, 4, generator=g) + 0.4).exp().to(DEV), torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    traj = {}
+    for mode in ("eager", "graph"):
+        net = build_precond(SMALL_CFG, 55, 1.0).train()
+        flat = FlatParams(net.unet)
+        opt = FlatAdamW(flat, lr=2e-3)
+        loss_fn = EDM2Loss(sigma_data=1.0)
+
+        def fwd_bwd(j2d):
+            opt.zero_grad()
+            loss, _ = loss_fn(net, images, labels, sigma=sig2 if j2d else sig3, noise=eps2 if j2d else eps3, just_2d=j2d,
+                              sync=False)
+            loss.backward()
+            return loss
+        steps = {False: GraphedStep(lambda: fwd_bwd(False)), True: GraphedStep(lambda: fwd_bwd(True))}
+        out = []
+        for i in range(20):
+            j2d = (i % 4 == 0)
+            loss = steps[j2d]() if mode == "graph" else fwd_bwd(j2d)
+            opt.step()
+            out.append(float(loss.item()))
+        traj[mode] = out
+        assert flat.check()
+    print("eager", [round(v, 4) for v in traj["eager"][-6:]], "graph", [round(v, 4) for v in traj["graph"][-6:]])
+    for a, b in zip(traj["eager"], traj["graph"]):
+        assert abs(a - b) <= 5e-3 * abs(a) + 1e-4, (traj["eager"], traj["graph"])
