@@ -5,6 +5,14 @@
 template <int S, bool HAS_CTX, int NT>
 static int conv3x3_pick_patch(const OnirisConvArgs& a, hipStream_t st) {
   const int W = a.W, H = a.H;
+  if constexpr (S == 2 && NT == 2) {   // DART training layout: 8-wave workgroups (256 positions) halve the weight-slab
+    // LDS traffic per MFMA (the slab is shared by twice as many positions) -- when that still leaves >= 1 workgroup per CU
+    const long long wg8 = (long long)a.B * cdiv(a.T * H * W, 256) * (a.CoutP / 64);
+    if (a.big_tile == 2 || (a.big_tile == 1 && wg8 >= 256)) {
+      if (W >= 16 && W % 16 == 0 && H % 16 == 0) return launch_conv_fwd<S, 9, 32, NT, HAS_CTX, 16, 8>(a, st);
+      if (W == 8 && H % 8 == 0) return launch_conv_fwd<S, 9, 32, NT, HAS_CTX, 8, 8>(a, st);
+    }
+  }
   if (W >= 16 && W % 16 == 0 && H % 8 == 0) return launch_conv_fwd<S, 9, 32, NT, HAS_CTX, 16>(a, st);
   if (W == 8 && H % 8 == 0) return launch_conv_fwd<S, 9, 32, NT, HAS_CTX, 8>(a, st);
   if (W == 4 && H % 4 == 0) return launch_conv_fwd<S, 9, 32, NT, HAS_CTX, 4>(a, st);

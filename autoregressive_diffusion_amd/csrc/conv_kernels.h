@@ -14,11 +14,12 @@
 #include "common.h"
 #include "../../include/oniris.h"
 
-template <int PW_>
+template <int PW_, int NPOS_ = 128>
 struct Patch {
   static constexpr int PW = PW_;
-  static constexpr int PH = (PW_ == 16) ? 8 : PW_;
-  static constexpr int FT = 128 / (PW * PH);
+  static constexpr int NPOS = NPOS_;                       // positions per workgroup tile (32 per wave)
+  static constexpr int PH = (PW_ == 16) ? (NPOS_ / 16) : PW_;
+  static constexpr int FT = NPOS_ / (PW * PH);
   static constexpr int HW = PW + 2, HH = PH + 2;
   static constexpr int HALO = FT * HH * HW;
 };
@@ -28,23 +29,25 @@ struct ConvDev {
   int ntx, nty, ntt, ncob;
 };
 
-template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW>
+template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW, int NW = 4>
 struct ConvCfg {
-  using P = Patch<PW>;
+  using P = Patch<PW, 32 * NW>;
+  static constexpr int NPOS = 32 * NW, NTHR = 64 * NW;
   static constexpr int BN = 32 * NT;
   static constexpr int ROWB = CK * 2 + 16;
   static constexpr int PARTS = CK / 8;
-  static constexpr int AROWS = (TAPS == 9) ? S * P::HALO : S * 128;
-  static constexpr int CROWS = (TAPS == 9) ? P::HALO : 128;
+  static constexpr int AROWS = (TAPS == 9) ? S * P::HALO : S * NPOS;
+  static constexpr int CROWS = (TAPS == 9) ? P::HALO : NPOS;
   static constexpr int WROWS = TAPS * BN;
   static constexpr int LDS_BYTES = (AROWS + WROWS) * ROWB;
 };
 
-template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW>
-__global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
-  using Cfg = ConvCfg<S, TAPS, CK, NT, HAS_CTX, PW>;
-  using P = Patch<PW>;
+template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW, int NW = 4>
+__global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(const ConvDev d) {
+  using Cfg = ConvCfg<S, TAPS, CK, NT, HAS_CTX, PW, NW>;
+  using P = typename Cfg::P;
   constexpr int BN = Cfg::BN, ROWB = Cfg::ROWB, PARTS = Cfg::PARTS;
+  constexpr int NTHR = Cfg::NTHR, NPOS = Cfg::NPOS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* A_lds = smem;
   unsigned char* W_lds = smem + Cfg::AROWS * ROWB;
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
     t0 = tc * P::FT; y0 = ty * P::PH; x0 = tx * P::PW;
   } else {
     const int tq = bid % d.ntt; bid /= d.ntt;      // ntt = number of 128-position tiles per (b,s)
-    q0 = tq * 128;
+    q0 = tq * NPOS;
   }
   const int b = bid % a.B;
   const int co0 = (bid / a.B) * BN;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   // registers BEFORE the MFMA section of phase i and written to LDS after it, so HBM/L2 latency hides under the
   // matrix work of the same workgroup (T14 "issue early / write late").
   constexpr int TOTA = Cfg::AROWS * PARTS, TOTC = Cfg::CROWS * PARTS, TOTW = Cfg::WROWS * PARTS;
-  constexpr int NIA = (TOTA + 255) / 256, NIW = (TOTW + 255) / 256;
+  constexpr int NIA = (TOTA + NTHR - 1) / NTHR, NIW = (TOTW + NTHR - 1) / NTHR;
   u32x4 ra[NIA], rw[NIW];
   const unsigned short fb = __builtin_bit_cast(unsigned short, f2bf(a.ctx_fill));
   const unsigned fill2 = (unsigned)fb | ((unsigned)fb << 16);
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   if constexpr (TAPS == 9) {
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NTHR;
       adesc[i] = 0u;
       if (e < TOTA) {
         const int row = e / PARTS, part = e % PARTS;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
         for (int i = 0; i < NIA; ++i) {
           const unsigned dsc = adesc[i];
           ra[i] = u32x4{0u, 0u, 0u, 0u};
-          if (tid + i * 256 < TOTC && (dsc >> 31) && cok) {     // rows < HALO are the slot-0 rows of the own image
+          if (tid + i * NTHR < TOTC && (dsc >> 31) && cok) {     // rows < HALO are the slot-0 rows of the own image
             const int f = t0 + (int)((dsc >> 25) & 31u) + coff;
             if (f >= 0 && f < a.ctx_T) ra[i] = *(const u32x4*)(cb_ + (f * frame_elems + (int)(dsc & 0x1ffffffu) + c0));
             else ra[i] = u32x4{fill2, fill2, fill2, fill2};
@@ -165,11 +168,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
     } else {
 #pragma unroll
       for (int i = 0; i < NIA; ++i) {
-        const int e = tid + i * 256;
+        const int e = tid + i * NTHR;
         ra[i] = u32x4{0u, 0u, 0u, 0u};
         if (e < TOTA) {
           const int row = e / PARTS;
-          const int s = row / 128, q = q0 + (row % 128);
+          const int s = row / NPOS, q = q0 + (row % NPOS);
           if (q < T * HWp && cok)
             ra[i] = *(const u32x4*)(xg + ((size_t)(b * S + s) * T * HWp + q) * Cin + c0 + part8);
         }
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
                      (size_t)co0 * a.CinP + c0 + part8;
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
-      const int row = wrow0 + i * (256 / PARTS);
-      if (tid + i * 256 < TOTW) {
+      const int row = wrow0 + i * (NTHR / PARTS);
+      if (tid + i * NTHR < TOTW) {
         const int tap = row / BN, co = row % BN;
         rw[i] = *(const u32x4*)(wg + (tap * a.CoutP + co) * a.CinP);
       }
@@ -191,12 +194,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
     const int tot = (ph == 0) ? TOTA : TOTC;
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NTHR;
       if (e < tot) *(u32x4*)(A_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = ra[i];
     }
 #pragma unroll
     for (int i = 0; i < NIW; ++i) {
-      const int e = tid + i * 256;
+      const int e = tid + i * NTHR;
       if (e < TOTW) *(u32x4*)(W_lds + (e / PARTS) * ROWB + (e % PARTS) * 16) = rw[i];
     }
   };
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
         if (ph == 0) {
 #pragma unroll
           for (int s = 0; s < S; ++s) {
-            const int srow = (TAPS == 9) ? s * P::HALO : s * 128;
+            const int srow = (TAPS == 9) ? s * P::HALO : s * NPOS;
             const bf16x8 xf = *(const bf16x8*)(A_lds + (srow + arow + off) * ROWB + ks * 32 + h * 16);
 #pragma unroll
             for (int n = 0; n < NT; ++n) acc[s][n] = mfma32(wf[n], xf, acc[s][n]);
@@ -359,21 +362,21 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_kernel(const ConvDev d) {
   }
 }
 
-template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW>
+template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW, int NW = 4>
 static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
-  using Cfg = ConvCfg<S, TAPS, CK, NT, HAS_CTX, PW>;
-  using P = Patch<PW>;
+  using Cfg = ConvCfg<S, TAPS, CK, NT, HAS_CTX, PW, NW>;
+  using P = typename Cfg::P;
   ConvDev d;
   d.a = a;
   d.ncob = a.CoutP / Cfg::BN;
   if (TAPS == 9) {
     d.ntx = a.W / P::PW; d.nty = a.H / P::PH; d.ntt = cdiv(a.T, P::FT);
   } else {
-    d.ntx = 1; d.nty = 1; d.ntt = cdiv(a.T * a.H * a.W, 128);
+    d.ntx = 1; d.nty = 1; d.ntt = cdiv(a.T * a.H * a.W, Cfg::NPOS);
   }
   const long long nblk = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { oniris_set_error("conv_fwd: bad grid %lld", nblk); return ONIRIS_EINVAL; }
-  auto kern = conv_fwd_kernel<S, TAPS, CK, NT, HAS_CTX, PW>;
+  auto kern = conv_fwd_kernel<S, TAPS, CK, NT, HAS_CTX, PW, NW>;
   if (Cfg::LDS_BYTES > 64 * 1024) {
     static bool attr_done = false;   // per instantiation
     if (!attr_done) {
@@ -385,7 +388,7 @@ static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
       attr_done = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), Cfg::LDS_BYTES, stream, d);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), Cfg::LDS_BYTES, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

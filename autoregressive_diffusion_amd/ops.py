@@ -195,6 +195,9 @@ class WeightBank:
 # ------------------------------------------------------------------------------------------------------------------
 # convolution
 
+BIG_TILE = 1     # conv tuning knob (see OnirisConvArgs.big_tile)
+
+
 class KernelProfile:
     """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg).  Events are recorded on
     the stream the kernel is launched on (torch's current stream)."""
@@ -251,6 +254,7 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     a.ctx_bstride, a.ctx_T, a.coff0, a.coff1, a.ctx_fill = ctx_bstride, ctx_T, coff[0], coff[1], ctx_fill
     a.epi, a.res, a.escale, a.emb_gain, a.out2 = epi, _p(res), _p(escale), _p(emb_gain), _p(out2)
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
+    a.big_tile = BIG_TILE
     check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
 
 

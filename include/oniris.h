@@ -109,6 +109,8 @@ typedef struct OnirisConvArgs {
   void* out2;             /* bf16 like out              (EPI_EMB_SILU: activation; EPI_MPSUM: optional raw output) */
   float ta, tb, clip;
   void* ctx_out;          /* optional bf16 [B*T][H][W][Cout]: the un-gated context product y3 (for d gate)        */
+  int32_t big_tile;       /* tuning: 1 = 8-wave workgroups (256 positions) where available                        */
+  int32_t pad_;
 } OnirisConvArgs;
 
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);
