@@ -24,7 +24,8 @@ class WeightDesc(C.Structure):
     _fields_ = [("w", c_void_p), ("grad", c_void_p), ("wf", c_void_p), ("wb", c_void_p), ("dwp", c_void_p),
                 ("cout", c_int32), ("cin", c_int32), ("taps", c_int32), ("kt", c_int32),
                 ("CoutP", c_int32), ("CinP", c_int32), ("CoutPb", c_int32), ("CinPb", c_int32),
-                ("row_start", c_int32), ("perm3", c_int32), ("gain", c_float), ("pad_", c_int32)]
+                ("row_start", c_int32), ("perm3", c_int32), ("gain", c_float), ("nsplit_cap", c_int32),
+                ("nsplit", c_void_p)]
 
 
 class ConvArgs(C.Structure):
@@ -43,7 +44,9 @@ class WgradArgs(C.Structure):
     _fields_ = [("x", c_void_p), ("dy", c_void_p), ("dwp", c_void_p), ("scale", c_void_p),
                 ("B", c_int32), ("T", c_int32), ("H", c_int32), ("W", c_int32), ("Cin", c_int32), ("CinP", c_int32),
                 ("Cout", c_int32), ("CoutP", c_int32), ("taps", c_int32),
-                ("xb_stride", c_int32), ("x_T", c_int32), ("coff", c_int32), ("fill", c_float)]
+                ("xb_stride", c_int32), ("x_T", c_int32), ("coff", c_int32), ("fill", c_float),
+                ("nsplit_cap", c_int32), ("taps_total", c_int32), ("tap0", c_int32), ("pad_", c_int32),
+                ("nsplit_out", c_void_p)]
 
 
 class AttnArgs(C.Structure):

@@ -4,8 +4,9 @@
 // row-major ([position][channel]) in LDS and the k-contiguous MFMA fragments are produced by the gfx950
 // transposing LDS read ds_read_b64_tr_b16 (4 rows x 16 columns per 16-lane group).  The x tile is the halo image
 // of the patch, shared by the 9 taps.  A workgroup owns a (32*CT co) x (32*IT ci) x 9-tap output tile and walks
-// a strided subset of the position tiles (split-K); partial sums are added with fp32 global atomics whose wave
-// shape is two 128-byte row segments (full atomic rate on gfx950).
+// a strided subset of the position tiles (split-K) and writes its partial sums to ITS OWN fp32 slab with plain stores
+// (two 128-byte row segments per wave store); the slabs are summed by weight_bwd_kernel.  The first version used
+// fp32 atomics, which run at ~1.3 TB/s chip-wide and took about half of the kernel time.
 #include "conv_kernels.h"
 
 struct WgradDev {
@@ -174,9 +175,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
     __syncthreads();
   }
 
-  // ---- accumulate into the packed fp32 gradient  dwp[tap][co][ci]
-  // Split-K partial sums meet in HBM through fp32 atomics (~1.3 TB/s chip-wide): when several waves of the
-  // workgroup share one output tile (NKS > 1) they are first summed through LDS so only one wave issues atomics.
+  // ---- write this workgroup column's slab  dwp[blockIdx.x][tap0 + tap][co][ci]
+  // When several waves of the workgroup share one output tile (NKS > 1) they are first summed through LDS.
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.nsplit_out) *a.nsplit_out = gridDim.x;
   const int cj = ci0 + it * 32 + (lane & 31);
   if constexpr (NKS > 1) {
     float* red = (float*)smem;                               // [NKS-1][16][64] floats = 12 KB, staging LDS is free now
@@ -200,13 +201,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
     }
     if (my_ks != 0) return;
   }
+  float* slab = a.dwp + (size_t)blockIdx.x * a.taps_total * a.CoutP * a.CinP;
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap) {
-    float* base = a.dwp + (size_t)tap * a.CoutP * a.CinP;
+    float* base = slab + (size_t)(a.tap0 + tap) * a.CoutP * a.CinP;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
       const int co = co0 + ct * 32 + mfma_row(rr, lane);
-      if (co < a.CoutP && cj < a.CinP) atomicAdd(base + (size_t)co * a.CinP + cj, acc[tap][rr]);
+      if (co < a.CoutP && cj < a.CinP) base[(size_t)co * a.CinP + cj] = acc[tap][rr];
     }
   }
 }
@@ -225,7 +227,8 @@ static int launch_wgrad(const OnirisWgradArgs& a, hipStream_t stream) {
   d.ncib = cdiv(a.Cin, 32 * IT);
   const int ncob = cdiv(a.Cout, 32 * CT);
   const int gy = d.ncib * ncob;
-  int gx = ((CT * IT == 4) ? 256 : 512) / gy;   // every extra split-K workgroup costs |tile| bytes of fp32 atomics
+  int gx = ((CT * IT == 4) ? 256 : 512) / gy;   // ~1-2 workgroups per CU; every split-K column owns one slab
+  if (gx > a.nsplit_cap) gx = a.nsplit_cap;
   if (gx < 1) gx = 1;
   if (gx > d.ntiles) gx = d.ntiles;
   constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
@@ -255,6 +258,8 @@ static int wgrad_pick_tile(const OnirisWgradArgs& a, hipStream_t stream) {
 extern "C" int oniris_conv_wgrad(const OnirisWgradArgs* args, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(args && args->x && args->dy && args->dwp, "conv_wgrad: null pointer");
+  ONIRIS_CHECK_ARG(args->nsplit_cap >= 1 && args->taps_total >= args->taps + args->tap0 && args->tap0 >= 0,
+                   "conv_wgrad: bad slab description");
   const OnirisWgradArgs& a = *args;
   ONIRIS_CHECK_ARG(a.taps == 9 || a.taps == 1, "conv_wgrad: taps must be 1 or 9 (got %d)", a.taps);
   ONIRIS_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv_wgrad: Cin/Cout must be multiples of 8");

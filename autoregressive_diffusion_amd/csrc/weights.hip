@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const OnirisWeightDesc
   const int fan = cin * taps;
   float* w = d->w + (size_t)co * fan;
   const float rs = rsqrtf((float)fan);
+  if (co == 0 && threadIdx.x == 0 && d->nsplit) *d->nsplit = 0;      // a new step: no weight-gradient slab is valid yet
 
   float ss = 0.f;
   for (int e = threadIdx.x; e < fan; e += 256) { float v = w[e]; ss += v * v; }
@@ -79,26 +80,32 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
   float* dwp = d->dwp;
   const float rs = rsqrtf((float)fan);
 
+  const int nsp = d->nsplit ? *d->nsplit : 1;
+  if (nsp <= 0) return;                                         // no wgrad ran for this weight in this step
+  const size_t slab = (size_t)taps * d->CoutP * d->CinP;
+  // pass 1 (packed order: ci contiguous -> coalesced slab reads): G = sum over the split-K slabs, kept in slab 0
   float dot = 0.f, nn = 0.f;
-  for (int e = threadIdx.x; e < fan; e += 256) {
-    const int ci = e / taps, tap = e - ci * taps;
-    const float G = dwp[((size_t)tap * d->CoutP + cop) * d->CinP + ci];
-    const float v = w[e];
+  for (int q = threadIdx.x; q < fan; q += 256) {
+    const int tap = q / cin, ci = q - tap * cin;
+    const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
+    float G = dwp[pi];
+    for (int s_ = 1; s_ < nsp; ++s_) G += dwp[s_ * slab + pi];
+    if (nsp > 1) dwp[pi] = G;
+    const float v = w[ci * taps + tap];
     dot += G * v; nn += v * v;
   }
-  dot = block_sum(dot, red);
+  dot = block_sum(dot, red);          // (block_sum's barriers also order the slab-0 writes before pass 2)
   nn = block_sum(nn, red);
   const float n = sqrtf(nn);
   const float s = W_EPS + n * rs;
   const float c = d->gain * rs;
   const float k1 = c / s;
   const float k2 = (n > 0.f) ? c * dot * rs / (s * s * n) : 0.f;
-  for (int e = threadIdx.x; e < fan; e += 256) {
-    const int ci = e / taps, tap = e - ci * taps;
+  for (int q = threadIdx.x; q < fan; q += 256) {
+    const int tap = q / cin, ci = q - tap * cin;
     const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
-    const float G = dwp[pi];
-    dwp[pi] = 0.f;                                                // leave the accumulator clean for the next step
-    g[e] += k1 * G - k2 * w[e];
+    const int e = ci * taps + tap;
+    g[e] += k1 * dwp[pi] - k2 * w[e];
   }
 }
 

@@ -24,7 +24,14 @@ class GraphedStep:
 
     def __call__(self):
         if self.graph is not None:
-            self.graph.replay()
+            # replay on the capture stream, fenced by events against the caller's stream on both sides: on ROCm 7.0 a
+            # graph launched directly behind eager kernels of the same stream was observed to start before they
+            # finished (AdamW of step n racing the zero_grad/weight_prep of step n+1)
+            cur = torch.cuda.current_stream()
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                self.graph.replay()
+            cur.wait_stream(self.stream)
             return self.out
         self.calls += 1
         if self.calls <= self.warmup:              # eager warm-up: builds tables, sets kernel attributes, fills caches
@@ -38,5 +45,4 @@ class GraphedStep:
         with torch.cuda.graph(g, stream=self.stream):
             out = self.fn()
         self.graph, self.out = g, out
-        g.replay()
-        return self.out
+        return self.__call__()

@@ -97,7 +97,7 @@ def device_tables(kind, n_frames, image_size, device):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp", "bank")
+                 "wf", "wb", "dwp", "bank", "nsplit_cap", "nsplit")
 
 
 class WeightBank:
@@ -119,7 +119,11 @@ class WeightBank:
         w.CoutP, w.CinP = roundup(w.cout, 32), roundup(w.cin, 64)
         w.CoutPb, w.CinPb = roundup(w.cin, 32), roundup(w.cout, 64)
         w.perm3, w.gain = bool(perm3), float(gain)
-        w.wf = w.wb = w.dwp = None
+        w.wf = w.wb = w.dwp = w.nsplit = None
+        # split-K slabs of the weight-gradient kernel: same bound as launch_wgrad() in csrc/conv_wgrad.hip
+        tile = 2 if (w.cin > 32 and w.cout > 32) else 1
+        gy = -(-roundup(w.cin, 16) // (32 * tile)) * -(-roundup(w.cout, 8) // (32 * tile))
+        w.nsplit_cap = max(1, (256 if tile == 2 else 512) // gy)
         w.bank = self
         self.items.append((w, need_dgrad))
         return w
@@ -131,6 +135,10 @@ class WeightBank:
     def _build(self, device):
         descs = (_lib.WeightDesc * len(self.items))()
         row = 0
+        if getattr(self, "nsplit_all", None) is None or self.nsplit_all.device != device:
+            self.nsplit_all = torch.zeros(len(self.items), dtype=torch.int32, device=device)
+        for i, (w, _) in enumerate(self.items):
+            w.nsplit = self.nsplit_all[i:i + 1]
         for i, (w, need_dgrad) in enumerate(self.items):
             p = w.param
             if p.dtype != torch.float32 or not p.is_contiguous():
@@ -138,7 +146,7 @@ class WeightBank:
             if w.wf is None or w.wf.device != p.device:
                 w.wf = torch.zeros(w.taps * w.CoutP * w.CinP, dtype=BF16, device=device)
                 w.wb = torch.zeros(w.taps * w.CoutPb * w.CinPb, dtype=BF16, device=device) if need_dgrad else None
-                w.dwp = torch.zeros(w.taps * w.CoutP * w.CinP, dtype=torch.float32, device=device)
+                w.dwp = torch.empty(w.nsplit_cap * w.taps * w.CoutP * w.CinP, dtype=torch.float32, device=device)
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
             d = descs[i]
@@ -150,6 +158,7 @@ class WeightBank:
             d.cout, d.cin, d.taps, d.kt = w.cout, w.cin, w.taps, w.kt
             d.CoutP, d.CinP, d.CoutPb, d.CinPb = w.CoutP, w.CinP, w.CoutPb, w.CinPb
             d.row_start, d.perm3, d.gain = row, int(w.perm3), w.gain
+            d.nsplit_cap, d.nsplit = w.nsplit_cap, w.nsplit.data_ptr()
             row += w.cout
         self.total_rows = row
         raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
@@ -175,6 +184,7 @@ class WeightBank:
         """Packed fp32 weight gradients (from the wgrad kernels) -> parameter .grad (accumulated); one launch."""
         self._ensure()
         check(lib.oniris_weight_bwd(_p(self._dev_table), len(self.items), self.total_rows, _stream()), "weight_bwd")
+        self.nsplit_all.zero_()        # the slabs are consumed: a second backward() must not add them again
 
     def request_finish(self):
         """Called from inside a conv backward: run `backward()` once, after the autograd engine has finished the
@@ -195,7 +205,8 @@ class WeightBank:
 # ------------------------------------------------------------------------------------------------------------------
 # convolution
 
-BIG_TILE = 1     # conv tuning knob (see OnirisConvArgs.big_tile)
+import os as _os
+BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "1"))     # conv tuning knob (see OnirisConvArgs.big_tile)
 
 
 class KernelProfile:
@@ -258,7 +269,8 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
 
 
-def _wgrad_launch(x, dy, dwp, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill):
+def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
+    """pw: PackedWeight whose slabs receive the partial sums (taps [tap0, tap0+taps) of its pw.taps-deep slabs)."""
     if KernelProfile.enabled:
         tile = 2 if (Cin > 32 and Cout > 32) else 1
         key = f"conv_wgrad_kernel<TAPS={taps},PW={_patch_w(W)},CT={tile},IT={tile}>"
@@ -266,14 +278,15 @@ def _wgrad_launch(x, dy, dwp, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, x
         e0.record()
         KernelProfile.enabled = False
         try:
-            _wgrad_launch(x, dy, dwp, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill)
+            _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0)
         finally:
             KernelProfile.enabled = True
         e1.record()
         KernelProfile.records.append((key, 2.0 * B * T * H * W * Cout * Cin * taps, e0, e1))
         return
     a = _lib.WgradArgs()
-    a.x, a.dy, a.dwp, a.scale = _p(x), _p(dy), _p(dwp), _p(scale)
+    a.x, a.dy, a.dwp, a.scale = _p(x), _p(dy), _p(pw.dwp), _p(scale)
+    a.nsplit_cap, a.taps_total, a.tap0, a.nsplit_out = pw.nsplit_cap, pw.taps, tap0, _p(pw.nsplit)
     a.B, a.T, a.H, a.W, a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = B, T, H, W, Cin, CinP, Cout, CoutP, taps
     a.xb_stride, a.x_T, a.coff, a.fill = xb_stride, x_T, coff, fill
     check(lib.oniris_conv_wgrad(ctypes.byref(a), _stream()), "conv_wgrad")
@@ -373,19 +386,18 @@ class _ConvOp(torch.autograd.Function):
                 _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca, sel, B, 2, T, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb, 9,
                              ctx_bstride=T, ctx_T=T, coff=(2, 1), ctx_fill=0.0)
             if pw2.param.requires_grad:
-                _wgrad_launch(x, dout, pw2.dwp, ca, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0)
+                _wgrad_launch(x, dout, pw2, ca, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0)
             if pw3.param.requires_grad:
-                per = 9 * pw3.CoutP * pw3.CinP
                 for j, coff in enumerate((-2, -1)):
-                    _wgrad_launch(x, dy3, pw3.dwp[j * per:], None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T,
-                                  coff, 1.0)
+                    _wgrad_launch(x, dy3, pw3, None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T, coff, 1.0,
+                                  tap0=9 * j)
         else:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 _conv_launch(dout, None, pw2.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
                              pw2.taps)
             if pw2.param.requires_grad:
-                _wgrad_launch(x, dout, pw2.dwp, None, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
+                _wgrad_launch(x, dout, pw2, None, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
         if pw2.param.requires_grad or (gated and pw3.param.requires_grad):
             pw2.bank.request_finish()
         return dx, None, None, dca, dcb, dcs, dres, None

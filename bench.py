@@ -90,7 +90,10 @@ def main():
     ap.add_argument("--frames", type=int, default=64)
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying captured hipGraphs")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay captured hipGraphs instead of launching eagerly (the step is GPU-bound either way; on ROCm "
+                         "7.0 replays of graphs that contain the 8-wave / 98 KB-LDS conv kernel were observed to be "
+                         "nondeterministic, so eager launch is the default -- DESIGN.md section 8)")
     ap.add_argument("--mode", choices=["train", "rollout"], default="train",
                     help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
     ap.add_argument("--gen-frames", type=int, default=8)
@@ -139,7 +142,7 @@ def main():
         loss.backward()
         return loss
 
-    use_graph = not args.no_graph
+    use_graph = bool(args.graph)
     graphed = {}
     if use_graph:
         from autoregressive_diffusion_amd.graphs import GraphedStep
@@ -172,13 +175,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    dbg = os.environ.get("ONIRIS_DEBUG_LOSS")
     for i in range(max(args.warmup, 16 if use_graph else 0)):     # graphs: 3 eager + 1 capture call per step flavour
-        step(i)
+        l_ = step(i)
+        if dbg:
+            print("warmup", i, float(l_.item()), file=sys.stderr)
     fence()
     t0 = time.perf_counter()
+    hist = []
     for i in range(args.steps):
         last = step(i)
+        if dbg == "2":
+            print("timed", i, float(last.item()), file=sys.stderr)
+        if dbg == "3":
+            hist.append(last.detach().clone())
     fence()
+    if dbg == "3":
+        print("timed losses", [round(float(h.item()), 4) for h in hist], file=sys.stderr)
     dt = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)

@@ -54,15 +54,17 @@ typedef struct OnirisWeightDesc {
   float* grad;     /* fp32 gradient, same shape; oniris_weight_bwd ACCUMULATES into it                           */
   void* wf;        /* bf16 packed forward weight  [taps][CoutP][CinP]   (ci contiguous)                          */
   void* wb;        /* bf16 packed dgrad weight    [taps][CoutPb][CinPb] = flipped/transposed copy (may be NULL)  */
-  float* dwp;      /* fp32 packed weight gradient [taps][CoutP][CinP] written by oniris_conv_wgrad (atomics);    *
-                    * consumed AND re-zeroed by oniris_weight_bwd                                                */
+  float* dwp;      /* fp32 split-K slabs [nsplit_cap][taps][CoutP][CinP]: oniris_conv_wgrad workgroup column s   *
+                    * overwrites slab s with plain stores; oniris_weight_bwd sums the first *nsplit slabs        */
   int32_t cout, cin, taps, kt;     /* taps = kt*kh*kw (1, 9 or 18); kt = temporal taps (1 or 2)                  */
   int32_t CoutP, CinP;             /* CoutP = roundup(cout,32), CinP = roundup(cin,64)                           */
   int32_t CoutPb, CinPb;           /* CoutPb = roundup(cin,32), CinPb = roundup(cout,64)                         */
   int32_t row_start;               /* prefix sum of cout over the table                                          */
   int32_t perm3;                   /* 1: attn_qkv rows (m c s) are packed as (s m c) (attention_modules.py:48)   */
   float gain;                      /* static gain folded into the packed weight                                  */
-  int32_t pad_;
+  int32_t nsplit_cap;              /* slabs allocated behind dwp                                                 */
+  int32_t* nsplit;                 /* device int: slabs written since the last oniris_weight_prep (which resets  *
+                                    * it to 0); set by oniris_conv_wgrad, read by oniris_weight_bwd              */
 } OnirisWeightDesc;
 
 int oniris_weight_prep(const OnirisWeightDesc* descs, int ndesc, int total_rows, int training, oniris_stream_t stream);
@@ -116,17 +118,21 @@ typedef struct OnirisConvArgs {
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);
 
 /* Weight gradient of the same operator (replaces the autograd of F.conv2d / F.conv3d wrt the weight):
- *   dwp[tap][co][ci] += sum_{n,p} scale[n] * dy[n][p][co] * xframe(n)[p + tap][ci]           (fp32 atomics)
+ *   slab[s][tap0+tap][co][ci] = sum_{(n,p) in split s} scale[n] * dy[n][p][co] * xframe(n)[p + tap][ci]
+ * Split-K over position tiles: workgroup column s (gridDim.x = *nsplit_out <= nsplit_cap) owns slab s and writes
+ * it with plain stores (no fp32 atomics: those run at ~1.3 TB/s chip-wide and dominated the first version).
  * path 0: xframe(n) = x[n] for all B*S*T frames.  path 1+j: frames n = (b,t), xframe = ctxframe(b, t+coff[j]),
- * dy = dy3 [B*T], accumulated into dwp + (j*taps) slices.                                                        */
+ * dy = dy3 [B*T], tap0 = j*taps inside the 2*taps-deep slabs of the (2,3,3) weight.                              */
 typedef struct OnirisWgradArgs {
   const void* x;          /* bf16 input frames   [B*xb_stride][H][W][Cin]                                         */
   const void* dy;         /* bf16 output grads   [B*T][H][W][Cout]                                                */
-  float* dwp;             /* fp32 packed [taps][CoutP][CinP] (pre-zeroed / accumulated)                           */
+  float* dwp;             /* fp32 slabs [nsplit_cap][taps_total][CoutP][CinP]                                      */
   const float* scale;     /* [B*T] or NULL                                                                        */
   int32_t B, T, H, W, Cin, CinP, Cout, CoutP, taps;
   int32_t xb_stride, x_T, coff;   /* xframe(b,t) = x[b*xb_stride + t + coff] if 0 <= t+coff < x_T else fill       */
   float fill;
+  int32_t nsplit_cap, taps_total, tap0, pad_;
+  int32_t* nsplit_out;    /* device int receiving the number of slabs written (= OnirisWeightDesc.nsplit)          */
 } OnirisWgradArgs;
 
 int oniris_conv_wgrad(const OnirisWgradArgs* args /* [host] */, oniris_stream_t stream);

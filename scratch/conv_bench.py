@@ -16,7 +16,7 @@ def bench_gated(B, T, H, C, Cout, iters=20, wgrad=False):
     y3 = torch.empty(B * T, H, H, Cout, device=dev, dtype=torch.bfloat16)
     def run():
         if wgrad:
-            ops._wgrad_launch(x, out, pw2.dwp, ca, 1, N, H, H, C, pw2.CinP, Cout, pw2.CoutP, 9, N, N, 0, 0.0)
+            ops._wgrad_launch(x, out, pw2, ca, 1, N, H, H, C, pw2.CinP, Cout, pw2.CoutP, 9, N, N, 0, 0.0)
         else:
             ops._conv_launch(x, x, pw2.wf, pw3.wf, out, ca, cb, B, 2, T, H, H, C, pw2.CinP, Cout, pw2.CoutP, 9,
                              ctx_bstride=2 * T, ctx_T=T, coff=(-2, -1), ctx_fill=1.0, ctx_out=y3)

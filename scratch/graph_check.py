@@ -18,8 +18,9 @@ net = Precond(unet, sigma_data=1.0).to(dev).train()
 opt = FlatAdamW(flat, lr=float(sys.argv[2]) if len(sys.argv) > 2 else 1e-2, eps=1e-8)
 loss_fn = EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5)
 g = torch.Generator(device=dev).manual_seed(1234)
-latents = torch.randn(2, 16, 8, 64, 64, device=dev, generator=g)
-actions = torch.randint(0, 4, (2, 16), device=dev, generator=g)
+TT = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+latents = torch.randn(2, TT, 8, 64, 64, device=dev, generator=g)
+actions = torch.randint(0, 4, (2, TT), device=dev, generator=g)
 def fwd_bwd(j2d):
     opt.zero_grad()
     loss, _ = loss_fn(net, latents, actions, just_2d=j2d, sync=False)
@@ -31,5 +32,6 @@ for i in range(48):
     j2d = (i % 4 == 0)
     loss = graphed[j2d]() if mode == "graph" else fwd_bwd(j2d)
     opt.step()
-    if i % 4 == 1: out.append(round(float(loss.item()), 3))
+    if i % 4 == 1: out.append(loss.detach().clone())
+out = [round(float(o.item()), 3) for o in out]
 print(mode, out, "grad finite", bool(torch.isfinite(flat.grad).all()), "param absmax", float(flat.flat.abs().max()))

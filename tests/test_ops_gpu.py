@@ -67,15 +67,18 @@ def test_weight_prep_and_bwd(shape):
     assert rel(wb, refb) < 5e-3, "packed dgrad weight (flipped, transposed)"
     # backward: random packed gradient
     G = torch.randn(cout, cin, taps)
-    pw.dwp.zero_()
-    dwp = torch.zeros(taps, pw.CoutP, pw.CinP)
+    dwp = torch.zeros(taps, pw.CoutP, pw.CinP)          # two split-K slabs: 0.25*G + 0.75*G
     dwp[:, :cout, :cin] = G.permute(2, 0, 1)
-    pw.dwp.copy_(dwp.reshape(-1))
+    assert pw.nsplit_cap >= 2
+    pw.dwp[:dwp.numel()].copy_(0.25 * dwp.reshape(-1))
+    pw.dwp[dwp.numel():2 * dwp.numel()].copy_(0.75 * dwp.reshape(-1))
+    pw.nsplit.fill_(2)
     p.grad.zero_()
     bank.backward()
     (w_eff * G.reshape(w_eff.shape)).sum().backward()
     assert rel(p.grad, w_ref.grad) < 1e-4, "gradient through the normalisation"
-    assert float(pw.dwp.abs().max()) == 0.0, "dwp re-zeroed"
+    bank.prepare(training=True)
+    assert int(pw.nsplit.item()) == 0, "weight_prep invalidates the slabs of the previous step"
 
 
 def test_weight_perm3():
