@@ -78,6 +78,9 @@ _SIGS = {
     "oniris_conv_wgrad": (c_int, [C.POINTER(WgradArgs), c_void_p]),
     "oniris_gconv_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_int, c_int64, c_void_p]),
+    "oniris_gconv_bwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                       c_float, c_float, c_float, c_void_p]),
     "oniris_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
                                c_int, c_void_p]),
     "oniris_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float,

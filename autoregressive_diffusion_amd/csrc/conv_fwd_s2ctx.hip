@@ -1,2 +1,15 @@
 #include "conv_fwd_common.h"
-int conv_dispatch_s2ctx(const OnirisConvArgs& a, hipStream_t st) { return conv3x3_pick<2, true>(a, st); }
+#include "conv_glds.h"
+
+// DART training layout.  big_tile: 0/1/2 = register-staged kernels (conv_kernels.h), >= 3 = persistent LDS-DMA kernel
+// (conv_glds.h: 8 waves, 16x16-pixel workgroup tiles) wherever the shape allows it.
+template <int NT>
+static int glds_pick(const OnirisConvArgs& a, hipStream_t st) {
+  return launch_conv_glds<NT, 16, 8, 1>(a, st);
+}
+
+int conv_dispatch_s2ctx(const OnirisConvArgs& a, hipStream_t st) {
+  if (a.big_tile >= 3 && conv_glds_ok(a, 16, 16, (a.CoutP % 64 == 0) ? 64 : 32))
+    return (a.CoutP % 64 == 0) ? glds_pick<2>(a, st) : glds_pick<1>(a, st);
+  return conv3x3_pick<2, true>(a, st);
+}

@@ -1,0 +1,464 @@
+// Gated causal 3x3 convolution, DART training layout (S = 2 slots + 2 context frames), LDS-DMA variant for gfx950.
+//
+// Same math and HBM layout as conv_kernels.h (implicit GEMM, D[co][position], own / ctx0 / ctx1 phases per 32-channel
+// chunk), different staging:
+//   * the halo image and the weight slab of a phase go global -> LDS with `global_load_lds_dwordx4` (no VGPR staging,
+//     no ds_write pass); the two LDS buffers alternate, so the DMA of phase i+1 runs under the MFMAs of phase i and
+//     there is ONE barrier per phase;
+//   * LDS rows are 64 B (32 channels) with no padding -- the DMA image is lane-linear -- and the four 16-byte parts
+//     of a row are XOR-swizzled with row bits 2..3 on the SOURCE side (part p of row R holds channels
+//     8*(p ^ ((R>>2)&3))..), which makes every ds_read_b128 of 16 consecutive rows conflict-free;
+//   * out-of-image halo pixels and padded context frames read a 64-byte constant row (zeros / ones) from global
+//     memory instead of branching;
+//   * a wave owns MT position tiles (32 positions each) x NT channel tiles x both slots (MT = 1 is what ships: the
+//     MT = 2 / 4-wave form needs 192 accumulator registers and hipcc shuffles them between VGPRs and AGPRs);
+//   * workgroups are PERSISTENT: each walks a run of tiles that sit next to each other in its XCD's L2, and issues
+//     the first DMA of the next tile before the epilogue of the current one, so the store tail and the cold first
+//     load of a tile hide under each other (the epilogue inputs are fetched before that DMA goes out: hipcc drains
+//     vmcnt to 0 at the first use of an ordinary load issued while LDS-DMA is in flight).
+// Requirements (checked by the dispatcher): S == 2, context path, taps == 9, Cin % 32 == 0, CoutP % (32*NT) == 0,
+// H % PH == 0, W % PW == 0, ctx_fill in {0, 1}.
+#pragma once
+#include <type_traits>
+#include "conv_kernels.h"
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+// [0] = zeros (spatial padding, dgrad frame padding), [1] = ones (forward temporal padding)
+static __device__ __attribute__((aligned(64))) const unsigned short oniris_fill_rows[2][32] = {
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80,
+     0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80,
+     0x3F80, 0x3F80, 0x3F80, 0x3F80}};
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// raw buffer resource (stride 0, 32-bit num_records, gfx950 dword-3 flags)
+__device__ __forceinline__ i32x4 make_rsrc(const void* p, int bytes) {
+  const unsigned long long u = (unsigned long long)p;
+  i32x4 r;
+  r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)u);
+  r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((u >> 32) & 0xffffu));
+  r[2] = __builtin_amdgcn_readfirstlane(bytes);
+  r[3] = 0x00020000;
+  return r;
+}
+
+// One LDS-DMA instruction: 16 B per active lane, source = rsrc base + soff + voff (per lane; beyond num_records -> 0),
+// destination = LDS byte address `lds` + 16 * lane.  Issued through inline asm ON PURPOSE: hipcc orders every later
+// LDS access and every later use of an ordinary load behind a builtin LDS-DMA with `s_waitcnt vmcnt(0)`, which
+// serialises the epilogue stores and drains the prefetch.  The kernel waits for its DMA itself (dma_wait() before the
+// barrier that publishes a buffer); hipcc's own counted waits stay conservative (it sees fewer VMEM ops than exist).
+__device__ __forceinline__ void dma16(const i32x4& rs, int voff, int soff, unsigned lds) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "s"(lds), "v"(voff), "s"(rs), "s"(soff)
+               : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+template <int NT, int PW, int NW, int MT>
+struct GldsCfg {
+  static constexpr int NPOS = 32 * NW * MT, NTHR = 64 * NW, BN = 32 * NT;
+  using P = Patch<PW, NPOS>;
+  static constexpr int SROWS = (P::HALO + 15) / 16 * 16;      // slot stride in rows: a multiple of 16 keeps the swizzle
+  static constexpr int AROWS = 2 * SROWS, CROWS = P::HALO, WROWS = 9 * BN;   // phase of slot 1 equal to slot 0's
+  static constexpr int BUF = (AROWS + WROWS) * 64;
+  static constexpr int EROW = BN * 2 + 16;
+  static constexpr int EPI = NW * 32 * EROW;
+  static constexpr int LDS_BYTES = (2 * BUF > EPI) ? 2 * BUF : EPI;
+  static_assert(LDS_BYTES <= 160 * 1024, "two staging buffers must fit the 160 KB LDS");
+  static_assert(2 * BN * 4 + EPI <= BUF, "the epilogue stages through ONE of the two buffers");
+  static_assert((NW * 2 * P::HW) % 16 == 0 || MT == 1, "position tiles of a wave must be 16-row aligned apart");
+};
+
+template <int NT, int PW, int NW, int MT>
+__global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(const ConvDev d) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (the stub needs no body)
+  using Cfg = GldsCfg<NT, PW, NW, MT>;
+  using P = typename Cfg::P;
+  constexpr int S = 2, TAPS = 9, CK = 32, KS = CK / 16;
+  constexpr int BN = Cfg::BN, NTHR = Cfg::NTHR, AROWS = Cfg::AROWS, BUF = Cfg::BUF;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const OnirisConvArgs& a = d.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int H = a.H, W = a.W, T = a.T, Cin = a.Cin, HWp = a.H * a.W;
+
+  // ---- this workgroup's run of tiles.  Workgroup ids go round-robin over the 8 XCDs; XCD k owns the CONTIGUOUS tile
+  // range [lo, hi) (channel block fastest, then x, y, frame, batch) and its workgroups stride through it together, so
+  // the blocks that share an activation halo (other channel blocks, neighbouring tiles, the next two frames whose
+  // context this frame is) run at the same time on the same L2.
+  const int ntiles = d.ntx * d.nty * d.ntt * a.B * d.ncob;
+  int tl, tl_hi, tl_step;
+  {
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7;
+    const int q = ntiles >> 3, rr = ntiles & 7;
+    const int lo = (xcd < rr) ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q;
+    tl_hi = lo + q + ((xcd < rr) ? 1 : 0);
+    tl_step = (nwg - xcd + 7) >> 3;
+    tl = lo + (blockIdx.x >> 3);
+  }
+  if (tl >= tl_hi) return;
+  struct Tile { int co0, x0, y0, t0, b; };
+  auto decode = [&](int id) __attribute__((always_inline)) {
+    Tile t;
+    t.co0 = (id % d.ncob) * BN; id /= d.ncob;
+    t.x0 = (id % d.ntx) * P::PW; id /= d.ntx;
+    t.y0 = (id % d.nty) * P::PH; id /= d.nty;
+    t.t0 = (id % d.ntt) * P::FT; id /= d.ntt;
+    t.b = id;
+    return t;
+  };
+
+  // lane -> position inside a 32-position tile (see conv_kernels.h: 16-lane read groups get 16 consecutive halo rows)
+  int pr = r;
+  if constexpr (PW == 16) {
+    const bool ga = (r < 4) || (r >= 12 && r < 16) || (r >= 20 && r < 28);
+    const int k = ga ? ((r < 4) ? r : (r < 16) ? r - 8 : r - 12) : ((r < 12) ? r - 4 : (r < 20) ? r - 8 : r - 16);
+    pr = (ga ? 0 : 16) + k;
+  }
+  int arow[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    const int p = (wave + NW * m) * 32 + pr;     // tile m of a wave sits NW*32 positions (a multiple of 16 halo rows) on
+    const int ft = p / (P::PH * P::PW), py = (p / P::PW) % P::PH, px = p % P::PW;
+    arow[m] = (ft * P::HH + py) * P::HW + px;
+  }
+
+  // ---- DMA descriptors (one 16-byte piece per lane per instruction; piece e of a region lands at region + 16*e).
+  // All per-lane byte offsets are phase-invariant (`buffer_load ... offen lds`: the phase / chunk / frame part of the
+  // address is the uniform soffset), and out-of-image halo pixels use an offset beyond num_records: the buffer range
+  // check then writes zeros, so spatial padding costs neither branches nor address math.
+  static_assert(P::FT == 1, "one frame per workgroup tile (the padded-frame test below is uniform)");
+  constexpr int TOTA = AROWS * 4, TOTC = Cfg::CROWS * 4, TOTW = Cfg::WROWS * 4;
+  constexpr int NIA = (TOTA + NTHR - 1) / NTHR, NIC = (TOTC + NTHR - 1) / NTHR, NIW = (TOTW + NTHR - 1) / NTHR;
+  constexpr int OOB = (int)0x80000000;
+  const int frame_elems = HWp * Cin;
+  int adesc[NIA], wdesc[NIW];
+  auto set_adesc = [&](const Tile& t) __attribute__((always_inline)) {
+    int tid_ = tid;
+    asm volatile("" : "+v"(tid_));      // opaque: keeps hipcc from hoisting (and then spilling) the per-piece constants
+#pragma unroll
+    for (int i = 0; i < NIA; ++i) {
+      const int e = i * NTHR + tid_;
+      const int row = e >> 2, gp = (e & 3) ^ ((row >> 2) & 3);
+      const int s = row / Cfg::SROWS, rem = row % Cfg::SROWS;
+      const int y = t.y0 + rem / P::HW - 1, x = t.x0 + rem % P::HW - 1;
+      adesc[i] = OOB;
+      if (e < TOTA && rem < P::HALO && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+        adesc[i] = (s * T * frame_elems + (y * W + x) * Cin + gp * 8) * 2;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < NIW; ++i) {
+    const int e = (i * NW + wave) * 64 + lane;
+    const int row = e >> 2, gp = (e & 3) ^ ((row >> 2) & 3);
+    const int tap = row / BN, co = row % BN;
+    wdesc[i] = ((tap * a.CoutP + co) * a.CinP + gp * 8) * 2;
+  }
+  const int wbytes = TAPS * a.CoutP * a.CinP * 2;
+  const i32x4 rs_f = make_rsrc(oniris_fill_rows, 128);
+  const i32x4 rs_wo = make_rsrc(a.w_own, wbytes), rs_wc = make_rsrc(a.w_ctx, 2 * wbytes);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+  const int fillsel = (a.ctx_fill != 0.f) ? 64 : 0;
+
+  auto issue = [&](const Tile& t, int ch, int ph, int bsel) __attribute__((always_inline)) {
+    const int c0 = ch * CK;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + bsel * BUF + wave * 1024);   // + i * NW * 1024 per piece
+    if (ph == 0) {
+      const bf16* xb = (const bf16*)a.x + (size_t)t.b * S * T * frame_elems;
+      const i32x4 rs_x = make_rsrc(xb, S * T * frame_elems * 2);
+      const int so = (t.t0 * frame_elems + c0) * 2;
+#pragma unroll
+      for (int i = 0; i < NIA; ++i)
+        if ((i * NW + wave) * 64 + lane < TOTA) dma16(rs_x, adesc[i], so, dst + i * NW * 1024);
+    } else {
+      const int f = t.t0 + ((ph == 1) ? a.coff0 : a.coff1);
+      if (f >= 0 && f < a.ctx_T) {
+        const bf16* cb_ = (const bf16*)a.ctx + (size_t)t.b * a.ctx_bstride * frame_elems;
+        const i32x4 rs_c = make_rsrc(cb_, a.ctx_T * frame_elems * 2);
+        const int so = (f * frame_elems + c0) * 2;
+#pragma unroll
+        for (int i = 0; i < NIC; ++i)                        // rows < HALO: the slot-0 rows of the halo image
+          if ((i * NW + wave) * 64 + lane < TOTC) dma16(rs_c, adesc[i], so, dst + i * NW * 1024);
+      } else {                                               // padded frame: constant row (spatial padding stays 0)
+#pragma unroll
+        for (int i = 0; i < NIC; ++i)
+          if ((i * NW + wave) * 64 + lane < TOTC) dma16(rs_f, (adesc[i] < 0) ? OOB : fillsel, 0, dst + i * NW * 1024);
+      }
+    }
+    const int sw = ((t.co0 * a.CinP + c0) + ((ph == 2) ? TAPS * a.CoutP * a.CinP : 0)) * 2;
+    if (ph == 0) {
+#pragma unroll
+      for (int i = 0; i < NIW; ++i)
+        if ((i * NW + wave) * 64 + lane < TOTW) dma16(rs_wo, wdesc[i], sw, dst + AROWS * 64 + i * NW * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < NIW; ++i)
+        if ((i * NW + wave) * 64 + lane < TOTW) dma16(rs_wc, wdesc[i], sw, dst + AROWS * 64 + i * NW * 1024);
+    }
+  };
+
+  // ---- fragment addresses (k-step 0; k-step 1 is the same address ^ 32)
+  const int wa0 = r * 64 + ((h ^ ((r >> 2) & 3)) << 4) + AROWS * 64;
+  // slot 1 and the wave's further position tiles are whole multiples of 16 rows away: same swizzle, constant offset
+  int xa0[TAPS];
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    const int R = arow[0] + (tap / 3) * P::HW + (tap % 3);
+    xa0[tap] = R * 64 + ((h ^ ((R >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[S][MT][NT];
+  f32x16 accc[MT][NT];
+
+  auto mfma_steps = [&](auto own_, int bsel) __attribute__((always_inline)) {
+    constexpr bool OWN = decltype(own_)::value;
+    constexpr int NX = OWN ? S : 1;
+    constexpr int NSTEP = TAPS * KS;
+    const unsigned char* base = smem + bsel * BUF;
+    bf16x8 wf[2][NT], xf[2][NX][MT];
+    auto ld = [&](int fb, int st) __attribute__((always_inline)) {
+      const int tap = st / KS, ks = st % KS;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        wf[fb][n] = *(const bf16x8*)(base + ((wa0 ^ (ks * 32)) + (tap * BN + n * 32) * 64));
+#pragma unroll
+      for (int s = 0; s < NX; ++s)
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          xf[fb][s][m] = *(const bf16x8*)(base + ((xa0[tap] ^ (ks * 32)) + (s * Cfg::SROWS + m * (NW * 2 * P::HW)) * 64));
+    };
+    ld(0, 0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      if (st + 1 < NSTEP) ld((st + 1) & 1, st + 1);
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          if constexpr (OWN) {
+#pragma unroll
+            for (int s = 0; s < S; ++s) acc[s][m][n] = mfma32(wf[st & 1][n], xf[st & 1][s][m], acc[s][m][n]);
+          } else {
+            accc[m][n] = mfma32(wf[st & 1][n], xf[st & 1][0][m], accc[m][n]);
+          }
+        }
+      // pin the pipeline: the fragment reads of step st+1 go out BEFORE the MFMAs of step st (T19)
+      if (st + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, NT + NX * MT, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, NX * MT * NT, 0);
+    }
+  };
+
+  constexpr int EROW = Cfg::EROW;
+  constexpr int ESC = 2 * BN * 4;                       // emb-scale vectors of the two slots, in front of the staging tiles
+  const int nphase = (Cin / CK) * 3;
+  Tile cur = decode(tl);
+  set_adesc(cur);
+  int bsel = 0;
+  issue(cur, 0, 0, 0);
+#pragma unroll 1
+  for (;;) {
+    dma_wait();
+    __syncthreads();     // phase 0 of `cur` has landed for everybody; the previous epilogue is over
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { acc[0][m][n][i] = 0.f; acc[1][m][n][i] = 0.f; accc[m][n][i] = 0.f; }
+      }
+    float esc_v = 0.f;
+    const int n0 = (cur.b * S) * T + cur.t0, n1 = n0 + T;        // frame index of slot 0 / slot 1 (uniform: FT == 1)
+    // gate coefficients: fetched now (nothing in flight) so that no wait on them can fall behind a later LDS-DMA
+    const float cown0 = a.coef_own ? a.coef_own[n0] : 1.f, cown1 = a.coef_own ? a.coef_own[n1] : 1.f;
+    const float cctx0 = a.coef_ctx ? a.coef_ctx[n0] : 1.f, cctx1 = a.coef_ctx ? a.coef_ctx[n1] : 1.f;
+    if (a.epi == ONIRIS_EPI_EMB_SILU && tid < 2 * BN) {          // emb-scale vector element of this thread (parked in LDS later)
+      const int co = cur.co0 + tid % BN;
+      if (co < a.Cout) esc_v = ((const float*)a.escale)[(size_t)((tid / BN) ? n1 : n0) * a.Cout + co];
+    }
+#pragma unroll 1
+    for (int itp = 0; itp < nphase; ++itp) {
+      const int ph = itp % 3;
+      if (itp + 1 < nphase && !(a.pad_ & 1)) issue(cur, (itp + 1) / 3, (itp + 1) % 3, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
+      if (!(a.pad_ & 2)) {
+      if (ph == 0) mfma_steps(std::true_type{}, bsel);
+      else mfma_steps(std::false_type{}, bsel);
+      }
+      dma_wait();                        // this wave's share of the next phase has landed ...
+      __syncthreads();                   // ... everybody's has; and everybody is done reading buffer bsel
+      bsel ^= 1;
+    }
+    // Both buffers are free now.  The epilogue stages through buffer bsel^1 (the one just consumed); the first DMA of
+    // the next tile goes to buffer bsel, continuing the alternation.
+    unsigned char* stg = smem + (bsel ^ 1) * BUF;
+    unsigned char* ep = stg + ESC + wave * 32 * EROW;
+
+    // -- epilogue inputs must not wait behind the next LDS-DMA (vmcnt is in order, and hipcc waits vmcnt(0) at the
+    // first use of an ordinary load issued while DMA is in flight): gate coefficients and emb-scale were fetched at
+    // the top of the tile; the emb-scale vectors are parked in LDS now
+    if (a.epi == ONIRIS_EPI_EMB_SILU) {
+      if (tid < 2 * BN) *(float*)(stg + tid * 4) = esc_v;
+      __syncthreads();
+    }
+    asm volatile("" ::"v"(cown0), "v"(cown1), "v"(cctx0), "v"(cctx1));   // consume here: nothing is in flight at this point
+    // -- first DMA of the next tile (runs under the epilogue below)
+    const int tl_next = tl + tl_step;
+    const bool more = tl_next < tl_hi;
+    Tile nxt = cur;
+    if (more) {
+      nxt = decode(tl_next);
+      set_adesc(nxt);
+      if (!(a.pad_ & 8)) issue(nxt, 0, 0, bsel);
+    }
+
+    // -- epilogue: lane-local math (lane = position), bf16 results transposed through a wave-private LDS tile so that
+    // global stores are 16 B per lane over whole channel rows
+    bf16* og = (bf16*)a.out;
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int ptile = (wave + NW * m) * 32;             // first position of this tile inside the workgroup tile
+      auto flush = [&](bf16* dst, size_t blk) __attribute__((always_inline)) {
+        constexpr int PO = BN / 8;
+#pragma unroll
+        for (int it = 0; it < 32 * PO / 64; ++it) {
+          const int id = it * 64 + lane;
+          const int row = id / PO, part = id % PO;
+          const int q = ptile + row;
+          const int yy = (q / P::PW) % P::PH, xx = q % P::PW;
+          const size_t px_ = (size_t)cur.t0 * HWp + (cur.y0 + yy) * W + (cur.x0 + xx);
+          const int co = cur.co0 + part * 8;
+          if (co < a.Cout && !(a.pad_ & 4)) *(uint4*)(dst + (blk + px_) * a.Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
+        }
+      };
+#pragma unroll
+      for (int s = 0; s < S; ++s) {
+        const float cown = s ? cown1 : cown0, cctx = s ? cctx1 : cctx0;
+        const size_t blk = (size_t)(cur.b * S + s) * T * HWp;
+        // one channel tile (16 values per lane) at a time keeps the epilogue's register footprint small; the gated
+        // sum is simply recomputed from the accumulators for every output that needs it
+        auto raw = [&](int nt, float (&v)[16]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(cctx, accc[m][nt][i], cown * acc[s][m][nt][i]);
+        };
+        auto put = [&](int nt, const float (&v)[16]) __attribute__((always_inline)) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            bf16x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = f2bf(v[4 * g + k]);
+            *(bf16x4*)(ep + pr * EROW + (nt * 32 + 8 * g + 4 * h) * 2) = o;
+          }
+        };
+        float v[16];
+        if (a.epi == ONIRIS_EPI_MPSUM) {     // (the res loads queue behind the DMA just issued: vmcnt is in order)
+          if (a.out2) {                      // raw conv output (needed for d gate)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { raw(nt, v); put(nt, v); }
+            flush((bf16*)a.out2, blk);
+          }
+          const int p = ptile + pr;
+          const size_t obase = (blk + (size_t)cur.t0 * HWp + (cur.y0 + (p / P::PW) % P::PH) * W + cur.x0 + p % P::PW) * a.Cout;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            raw(nt, v);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int co = cur.co0 + nt * 32 + 8 * g + 4 * h;
+              bf16x4 rv;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) rv[k] = f2bf(0.f);
+              if (co < a.Cout) rv = *(const bf16x4*)((const bf16*)a.res + obase + co);
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                float o = a.ta * bf2f(rv[k]) + a.tb * v[4 * g + k];
+                if (a.clip > 0.f) o = fminf(fmaxf(o, -a.clip), a.clip);
+                v[4 * g + k] = o;
+              }
+            }
+            put(nt, v);
+          }
+          flush(og, blk);
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) { raw(nt, v); put(nt, v); }
+          flush(og, blk);
+          if (a.epi == ONIRIS_EPI_EMB_SILU) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+              raw(nt, v);
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const float4 ev = *(const float4*)(stg + (s * BN + nt * 32 + 8 * g + 4 * h) * 4);
+                const float cvv[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const float z = bf2f(f2bf(v[4 * g + k])) * cvv[k];     // the activation sees the bf16-rounded y
+                  v[4 * g + k] = z / (1.f + __expf(-z)) * (1.f / 0.596f);
+                }
+              }
+              put(nt, v);
+            }
+            flush((bf16*)a.out2, blk);
+          }
+        }
+        if (a.ctx_out && s == 0) {          // unscaled context product y3 (shared by both slots), kept for d(gate)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = accc[m][nt][i];
+            put(nt, v);
+          }
+          flush((bf16*)a.ctx_out, (size_t)cur.b * T * HWp);
+        }
+      }
+    }
+    if (!more) break;
+    cur = nxt;
+    tl = tl_next;
+  }
+#endif
+}
+
+template <int NT, int PW, int NW, int MT>
+static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
+  using Cfg = GldsCfg<NT, PW, NW, MT>;
+  using P = typename Cfg::P;
+  ConvDev d;
+  d.a = a;
+  d.ncob = a.CoutP / Cfg::BN;
+  d.ntx = a.W / P::PW; d.nty = a.H / P::PH; d.ntt = cdiv(a.T, P::FT);
+  const long long ntiles = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
+  if (ntiles <= 0 || ntiles > 0x7fffffffLL) { oniris_set_error("conv_fwd: bad grid %lld", ntiles); return ONIRIS_EINVAL; }
+  static int ncu = 0;                  // persistent workgroups: one per CU (the two LDS buffers fill a CU)
+  if (ncu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;
+  }
+  const long long nblk = ntiles < ncu ? ntiles : ncu;
+  auto kern = conv_glds_kernel<NT, PW, NW, MT>;
+  static bool attr_done = false;   // per instantiation
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
+      oniris_set_error("conv_fwd: cannot raise dynamic LDS to %d", Cfg::LDS_BYTES);
+      return ONIRIS_ELAUNCH;
+    }
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), Cfg::LDS_BYTES, stream, d);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// true when the LDS-DMA variant can run this problem
+static inline bool conv_glds_ok(const OnirisConvArgs& a, int PH, int PW, int BN) {
+  return a.S == 2 && a.ctx && a.taps == 9 && a.Cin % 32 == 0 && a.CoutP % BN == 0 && a.H % PH == 0 && a.W % PW == 0 &&
+         (a.ctx_fill == 0.f || a.ctx_fill == 1.f) &&
+         2LL * a.T * a.H * a.W * a.Cin * 2 < (1LL << 31) && (long long)a.ctx_T * a.H * a.W * a.Cin * 2 < (1LL << 31) &&
+         18LL * a.CoutP * a.CinP * 2 < (1LL << 31);
+}

@@ -11,6 +11,7 @@
 // LDS rows are padded by 16 B (row = CK*2+16 bytes) which makes the 16-byte fragment reads conflict-free.
 // Roofline: MFMA-bound for C >= 64 (intensity ~ 27*C FLOP/B of activation), HBM-bound below.
 #pragma once
+#include <type_traits>
 #include "common.h"
 #include "../../include/oniris.h"
 
@@ -204,6 +205,39 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
     }
   };
 
+  auto mfma_steps = [&](auto own_) __attribute__((always_inline)) {
+    constexpr bool OWN = decltype(own_)::value;
+    constexpr int NX = OWN ? S : 1;
+    constexpr int KS = CK / 16, NSTEP = TAPS * KS;
+    bf16x8 wf[2][NT], xf[2][NX];
+    auto ld = [&](int buf, int st) __attribute__((always_inline)) {
+      const int tap = st / KS, ks = st % KS;
+      const int off = (TAPS == 9) ? ((tap / 3) * P::HW + (tap % 3)) : 0;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+        wf[buf][n] = *(const bf16x8*)(W_lds + (tap * BN + n * 32 + r) * ROWB + ks * 32 + h * 16);
+#pragma unroll
+      for (int s = 0; s < NX; ++s) {
+        const int srow = (TAPS == 9) ? s * P::HALO : s * NPOS;
+        xf[buf][s] = *(const bf16x8*)(A_lds + (srow + arow + off) * ROWB + ks * 32 + h * 16);
+      }
+    };
+    ld(0, 0);
+#pragma unroll
+    for (int st = 0; st < NSTEP; ++st) {
+      if (st + 1 < NSTEP) ld((st + 1) & 1, st + 1);
+      if constexpr (OWN) {
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[s][n] = mfma32(wf[st & 1][n], xf[st & 1][s], acc[s][n]);
+      } else {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) accc[n] = mfma32(wf[st & 1][n], xf[st & 1][0], accc[n]);
+      }
+    }
+  };
+
   const int nphase = nchunk * NPH;
   load_phase(0, 0);
 #pragma unroll 1
@@ -213,30 +247,11 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
     __syncthreads();
     if (itp + 1 < nphase) load_phase((itp + 1) / NPH, (itp + 1) % NPH);
     // ------------------------------------------------------------------ MFMA over taps x k-steps
-#pragma unroll
-    for (int tap = 0; tap < TAPS; ++tap) {
-      const int off = (TAPS == 9) ? ((tap / 3) * P::HW + (tap % 3)) : 0;
-#pragma unroll
-      for (int ks = 0; ks < CK / 16; ++ks) {
-        bf16x8 wf[NT];
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          wf[n] = *(const bf16x8*)(W_lds + (tap * BN + n * 32 + r) * ROWB + ks * 32 + h * 16);
-        if (ph == 0) {
-#pragma unroll
-          for (int s = 0; s < S; ++s) {
-            const int srow = (TAPS == 9) ? s * P::HALO : s * NPOS;
-            const bf16x8 xf = *(const bf16x8*)(A_lds + (srow + arow + off) * ROWB + ks * 32 + h * 16);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) acc[s][n] = mfma32(wf[n], xf, acc[s][n]);
-          }
-        } else {
-          const bf16x8 xf = *(const bf16x8*)(A_lds + (arow + off) * ROWB + ks * 32 + h * 16);
-#pragma unroll
-          for (int n = 0; n < NT; ++n) accc[n] = mfma32(wf[n], xf, accc[n]);
-        }
-      }
-    }
+    // The own / context phases are separate straight-line sequences (a branch per step would pin every LDS read
+    // right in front of its MFMA); fragments are double-buffered in registers: the reads of step i+1 are in flight
+    // while the MFMAs of step i run.
+    if (ph == 0) mfma_steps(std::true_type{});
+    else mfma_steps(std::false_type{});
     __syncthreads();
   }
 

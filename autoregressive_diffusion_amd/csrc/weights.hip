@@ -88,8 +88,14 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
   for (int q = threadIdx.x; q < fan; q += 256) {
     const int tap = q / cin, ci = q - tap * cin;
     const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
-    float G = dwp[pi];
-    for (int s_ = 1; s_ < nsp; ++s_) G += dwp[s_ * slab + pi];
+    float G0 = 0.f, G1 = 0.f, G2 = 0.f, G3 = 0.f;            // 4 independent load chains (HBM latency)
+    int s_ = 0;
+    for (; s_ + 3 < nsp; s_ += 4) {
+      G0 += dwp[(size_t)s_ * slab + pi];       G1 += dwp[(size_t)(s_ + 1) * slab + pi];
+      G2 += dwp[(size_t)(s_ + 2) * slab + pi]; G3 += dwp[(size_t)(s_ + 3) * slab + pi];
+    }
+    for (; s_ < nsp; ++s_) G0 += dwp[(size_t)s_ * slab + pi];
+    const float G = (G0 + G1) + (G2 + G3);
     if (nsp > 1) dwp[pi] = G;
     const float v = w[ci * taps + tap];
     dot += G * v; nn += v * v;
@@ -217,6 +223,139 @@ __global__ __launch_bounds__(256) void gconv_bwd_prep_kernel(const bf16* __restr
     const float a = block_sum(s1[s], red), bsum = block_sum(s2[s], red);
     if (threadIdx.x == 0) { const size_t n = (size_t)(b * S + s) * T + t; S1[n] = (a - cb[n] * bsum) / ca[n]; S2[n] = bsum; }
   }
+}
+
+// Same pre-pass fused with the adjoint of the conv epilogue, so the incoming gradient is read ONCE:
+//   mode 1 (EPI_EMB_SILU): g = d u, u = silu(y*c)/0.596  ->  dout = g*silu'(y*c)/0.596*c ; dc[n][co] += sum_pixels(...)*y
+//   mode 2 (EPI_MPSUM):    g = d out, out = clip(ta*res + tb*v) -> dres = ta*g*mask ; dout = tb*g*mask
+// then S1/S2/dy3 exactly as gconv_bwd_prep_kernel.  raw = y (mode 1) or v (mode 2).
+template <int MODE>
+__global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __restrict__ g, const bf16* __restrict__ raw,
+                                                              const bf16* __restrict__ y3, const float* __restrict__ ca,
+                                                              const float* __restrict__ cb, const float* __restrict__ cs,
+                                                              const bf16* __restrict__ xo, bf16* __restrict__ dout,
+                                                              bf16* __restrict__ dres, bf16* __restrict__ dy3,
+                                                              float* __restrict__ dca, float* __restrict__ dcb,
+                                                              float* __restrict__ dcs, int T, int P, int C, float ta,
+                                                              float tb, float clip, int pix_per_block) {
+  __shared__ float red[16];
+  __shared__ float accs[2][512];
+  const int bt = blockIdx.x, b = bt / T, t = bt % T;
+  const size_t PC = (size_t)P * C;
+  const int G8 = C >> 3;
+  const int cg = threadIdx.x % G8, pl = threadIdx.x / G8, npl = 256 / G8;
+  if (MODE == 1)
+    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&accs[0][0])[i] = 0.f;
+  __syncthreads();
+  float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+  float part[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[s][i] = 0.f;
+  size_t nn[2];
+  float cbv[2], cv[2][8];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    nn[s] = (size_t)(b * 2 + s) * T + t;
+    cbv[s] = cb[nn[s]];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) cv[s][i] = 1.f;
+    if (MODE == 1 && pl < npl) {
+      const float4 c0 = *(const float4*)(cs + nn[s] * C + cg * 8), c1 = *(const float4*)(cs + nn[s] * C + cg * 8 + 4);
+      cv[s][0] = c0.x; cv[s][1] = c0.y; cv[s][2] = c0.z; cv[s][3] = c0.w;
+      cv[s][4] = c1.x; cv[s][5] = c1.y; cv[s][6] = c1.z; cv[s][7] = c1.w;
+    }
+  }
+  if (pl < npl) {
+    const int p0 = blockIdx.y * pix_per_block, p1 = min(P, p0 + pix_per_block);
+    for (int p = p0 + pl; p < p1; p += npl) {
+      const size_t off = (size_t)p * C + cg * 8;
+      const bf16x8 yv3 = *(const bf16x8*)(y3 + (size_t)bt * PC + off);
+      float acc3[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) acc3[i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const size_t o = nn[s] * PC + off;
+        const bf16x8 gv = *(const bf16x8*)(g + o);
+        const bf16x8 rv = *(const bf16x8*)(raw + o);
+        bf16x8 dv, drv;
+        bf16x8 xv;
+        if (MODE == 2 && clip > 0.f) xv = *(const bf16x8*)(xo + o);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const float r_ = bf2f(rv[i]);
+          float d;
+          if (MODE == 1) {
+            const float z = r_ * cv[s][i];
+            const float sg = 1.f / (1.f + __expf(-z));
+            const float dz = bf2f(gv[i]) * (sg * (1.f + z * (1.f - sg))) * (1.0f / 0.596f);
+            part[s][i] += dz * r_;
+            d = dz * cv[s][i];
+          } else {
+            float gg = bf2f(gv[i]);
+            if (clip > 0.f && !(fabsf(bf2f(xv[i])) < clip)) gg = 0.f;
+            drv[i] = f2bf(gg * ta);
+            d = gg * tb;
+          }
+          dv[i] = f2bf(d);
+          const float dr = bf2f(dv[i]);                 // the rounded value is what dgrad / wgrad will consume
+          s1[s] += dr * r_; s2[s] += dr * bf2f(yv3[i]); acc3[i] += cbv[s] * dr;
+        }
+        *(bf16x8*)(dout + o) = dv;
+        if (MODE == 2) *(bf16x8*)(dres + o) = drv;
+      }
+      bf16x8 o3;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o3[i] = f2bf(acc3[i]);
+      *(bf16x8*)(dy3 + (size_t)bt * PC + off) = o3;
+    }
+    if (MODE == 1) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) atomicAdd(&accs[s][cg * 8 + i], part[s][i]);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    const float a_ = block_sum(s1[s], red), b_ = block_sum(s2[s], red);
+    if (threadIdx.x == 0) { atomicAdd(dca + nn[s], (a_ - cbv[s] * b_) / ca[nn[s]]); atomicAdd(dcb + nn[s], b_); }
+  }
+  if (MODE == 1) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) {
+      atomicAdd(dcs + nn[0] * C + i, accs[0][i]); atomicAdd(dcs + nn[1] * C + i, accs[1][i]);
+    }
+  }
+}
+
+extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void* y3, const float* coef_own,
+                                      const float* coef_ctx, const float* cscale, const void* xo, void* dout, void* dres,
+                                      void* dy3, float* d_coef_own, float* d_coef_ctx, float* d_cscale, int B, int T,
+                                      int P, int C, float ta, float tb, float clip, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG((mode == 1 || mode == 2) && g && raw && y3 && coef_own && coef_ctx && dout && dy3 && d_coef_own &&
+                   d_coef_ctx && B > 0 && T > 0 && P > 0 && C % 8 == 0 && C <= 512, "gconv_bwd_fused: bad arguments");
+  ONIRIS_CHECK_ARG(mode != 1 || (cscale && d_cscale), "gconv_bwd_fused: mode 1 needs cscale / d_cscale");
+  ONIRIS_CHECK_ARG(mode != 2 || (dres && (clip <= 0.f || xo)), "gconv_bwd_fused: mode 2 needs dres (and xo when clipping)");
+  // pixel slices so that the launch covers the chip (B*T alone is ~128 blocks); partial sums meet through atomics,
+  // so d_coef_own / d_coef_ctx / d_cscale must be ZERO on entry.
+  int slices = 1;
+  const int npl = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
+  while (slices < 32 && P / (slices * 2) >= npl * 2 && (long long)B * T * slices < 2048) slices *= 2;
+  const int ppb = cdiv(P, slices);
+  if (mode == 1)
+    hipLaunchKernelGGL(gconv_bwd_fused_kernel<1>, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)g,
+                       (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
+                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb);
+  else
+    hipLaunchKernelGGL(gconv_bwd_fused_kernel<2>, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)g,
+                       (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
+                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
 }
 
 extern "C" int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_own,

@@ -206,7 +206,7 @@ class WeightBank:
 # convolution
 
 import os as _os
-BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "1"))     # conv tuning knob (see OnirisConvArgs.big_tile)
+BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (see OnirisConvArgs.big_tile)
 
 
 class KernelProfile:
@@ -266,6 +266,7 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     a.epi, a.res, a.escale, a.emb_gain, a.out2 = epi, _p(res), _p(escale), _p(emb_gain), _p(out2)
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
     a.big_tile = BIG_TILE
+    a.pad_ = int(_os.environ.get('ONIRIS_DBG', '0'))
     check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
 
 
@@ -362,7 +363,22 @@ class _ConvOp(torch.autograd.Function):
         Co = g.shape[-1]
         dev = x.device
         dcs = dres = None
-        if cfg.epi == "emb_silu":
+        dx = dca = dcb = None
+        fused = gated and cfg.epi in ("emb_silu", "mpsum") and Co <= 512
+        if fused:                                   # epilogue adjoint + gate/context pre-pass in ONE pass over g
+            B, T = cfg.B, cfg.T
+            dout = torch.empty_like(g)
+            dy3 = torch.empty_like(y3)
+            acc = torch.zeros(N * (2 + (Co if cfg.epi == "emb_silu" else 0)), dtype=torch.float32, device=dev)
+            dca, dcb = acc[:N], acc[N:2 * N]
+            if cfg.epi == "emb_silu":
+                dcs = acc[2 * N:].view(N, Co)
+            else:
+                dres = torch.empty_like(g)
+            check(lib.oniris_gconv_bwd_fused(1 if cfg.epi == "emb_silu" else 2, _p(g), _p(raw), _p(y3), _p(ca), _p(cb),
+                                             _p(cs), _p(xo), _p(dout), _p(dres), _p(dy3), _p(dca), _p(dcb), _p(dcs), B, T,
+                                             H * W, Co, cfg.ta, cfg.tb, cfg.clip, _stream()), "gconv_bwd_fused")
+        elif cfg.epi == "emb_silu":
             dout = torch.empty_like(g)
             dcs = torch.empty((N, Co), dtype=torch.float32, device=dev)
             check(lib.oniris_emb_silu_bwd(_p(g), _p(raw), _p(cs), _p(dout), _p(dcs), N, H * W, Co, _stream()), "emb_silu_bwd")
@@ -372,14 +388,14 @@ class _ConvOp(torch.autograd.Function):
                   "mpsum_bwd")
         else:
             dout = g
-        dx = dca = dcb = None
         if gated:
             B, T = cfg.B, cfg.T
-            dca = torch.empty(N, dtype=torch.float32, device=dev)
-            dcb = torch.empty(N, dtype=torch.float32, device=dev)
-            dy3 = torch.empty_like(y3)
-            check(lib.oniris_gconv_bwd_prep(_p(dout), _p(raw), _p(y3), _p(ca), _p(cb), _p(dca), _p(dcb), _p(dy3), B, 2, T,
-                                            H * W * Co, _stream()), "gconv_bwd_prep")
+            if not fused:
+                dca = torch.empty(N, dtype=torch.float32, device=dev)
+                dcb = torch.empty(N, dtype=torch.float32, device=dev)
+                dy3 = torch.empty_like(y3)
+                check(lib.oniris_gconv_bwd_prep(_p(dout), _p(raw), _p(y3), _p(ca), _p(cb), _p(dca), _p(dcb), _p(dy3), B, 2,
+                                                T, H * W * Co, _stream()), "gconv_bwd_prep")
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 sel = _clean_selector(B, T, dev)               # the context gradient only reaches the clean slot

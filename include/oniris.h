@@ -146,6 +146,16 @@ int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, con
                           const float* coef_ctx, float* d_coef_own, float* d_coef_ctx, void* dy3, int B, int S, int T,
                           int64_t frame_elems, oniris_stream_t stream);
 
+/* The same pre-pass fused with the adjoint of the conv epilogue (the upstream gradient is read once):
+ * mode 1 = ONIRIS_EPI_EMB_SILU (g = d u; raw = y; outputs dout = d y and d_cscale[n][co]),
+ * mode 2 = ONIRIS_EPI_MPSUM    (g = d out; raw = v; xo = the clipped output, needed when clip > 0; outputs dres, dout = d v).
+ * S = 2 (DART training layout), P = H*W pixels per frame, C channels (C % 8 == 0, C <= 512).
+ * d_coef_own / d_coef_ctx / d_cscale are ACCUMULATED (pixel slices meet through atomics): zero them first.        */
+int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void* y3, const float* coef_own,
+                           const float* coef_ctx, const float* cscale, const void* xo, void* dout, void* dres, void* dy3,
+                           float* d_coef_own, float* d_coef_ctx, float* d_cscale, int B, int T, int P, int C, float ta,
+                           float tb, float clip, oniris_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused magnitude-preserving glue (HBM-bound, one pass each) -- the elementwise chains of Block.forward
  * (edm2/networks_edm2.py:62-94) and their adjoints.  All tensors bf16 channels-last.

@@ -122,7 +122,10 @@ def test_conv_plain(N, H, cin, cout, k):
 
 
 @pytest.mark.parametrize("B,T,H,cin,cout", [(2, 4, 8, 32, 32), (1, 2, 16, 64, 64), (1, 8, 4, 32, 64), (2, 3, 8, 96, 32),
-                                            (1, 2, 32, 16, 32)])
+                                            (1, 2, 32, 16, 32),
+                                            # shapes the persistent LDS-DMA kernel takes (16x16 tiles, Cin % 32 == 0):
+                                            # several tiles per frame / per workgroup, 1..4 channel chunks, ragged Cout
+                                            (2, 5, 32, 32, 96), (1, 3, 16, 128, 64), (3, 7, 16, 32, 32)])
 def test_gated_conv_train(B, T, H, cin, cout):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(3)
@@ -354,12 +357,12 @@ def test_resample_fused():
         assert rel(nchw(y), yr) < 5e-3 and rel(nchw(x.grad), xr.grad) < 5e-3
 
 
-@pytest.mark.parametrize("gated", [False, True])
-def test_conv_epilogues(gated):
+@pytest.mark.parametrize("gated,H", [(False, 8), (True, 8), (True, 16)])     # H = 16: the LDS-DMA kernel's epilogues
+def test_conv_epilogues(gated, H):
     """conv + (x c, mp_silu) and conv + (mp_sum with residual, clip) epilogues, forward and backward."""
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(11)
-    B, T, H, cin, cout = 1, 4, 8, 32, 64
+    B, T, cin, cout = 1, 4, 32, 64
     N = B * 2 * T
     w2 = O.normalize(O.normalize(torch.randn(cout, cin, 3, 3)))
     w3 = O.normalize(O.normalize(torch.randn(cout, cin, 2, 3, 3)))
