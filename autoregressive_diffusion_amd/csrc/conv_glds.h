@@ -283,11 +283,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 #pragma unroll 1
     for (int itp = 0; itp < nphase; ++itp) {
       const int ph = itp % 3;
-      if (itp + 1 < nphase && !(a.pad_ & 1)) issue(cur, (itp + 1) / 3, (itp + 1) % 3, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
-      if (!(a.pad_ & 2)) {
+      if (itp + 1 < nphase) issue(cur, (itp + 1) / 3, (itp + 1) % 3, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
       if (ph == 0) mfma_steps(std::true_type{}, bsel);
       else mfma_steps(std::false_type{}, bsel);
-      }
       dma_wait();                        // this wave's share of the next phase has landed ...
       __syncthreads();                   // ... everybody's has; and everybody is done reading buffer bsel
       bsel ^= 1;
@@ -312,7 +310,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     if (more) {
       nxt = decode(tl_next);
       set_adesc(nxt);
-      if (!(a.pad_ & 8)) issue(nxt, 0, 0, bsel);
+      issue(nxt, 0, 0, bsel);
     }
 
     // -- epilogue: lane-local math (lane = position), bf16 results transposed through a wave-private LDS tile so that
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
           const int yy = (q / P::PW) % P::PH, xx = q % P::PW;
           const size_t px_ = (size_t)cur.t0 * HWp + (cur.y0 + yy) * W + (cur.x0 + xx);
           const int co = cur.co0 + part * 8;
-          if (co < a.Cout && !(a.pad_ & 4)) *(uint4*)(dst + (blk + px_) * a.Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
+          if (co < a.Cout) *(uint4*)(dst + (blk + px_) * a.Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
         }
       };
 #pragma unroll

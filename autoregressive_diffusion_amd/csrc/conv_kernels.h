@@ -311,7 +311,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         v[nt][i] = cown * acc[s][nt][i];
-        if constexpr (HAS_CTX) v[nt][i] += cctx * accc[nt][i];
+        if constexpr (HAS_CTX) v[nt][i] = __builtin_fmaf(cctx, accc[nt][i], v[nt][i]);   // explicit: same rounding in every variant
       }
     // helper: write v (as bf16) into the wave tile
     auto stage = [&]() __attribute__((always_inline)) {

@@ -245,7 +245,11 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         if ctx is not None:
             flops += 2.0 * B * T * H * W * Cout * Cin * 2 * taps
         nt = 2 if CoutP % 64 == 0 else 1
-        key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
+        if (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H % 16 == 0 and W % 16 == 0
+                and ctx_fill in (0.0, 1.0)):          # mirrors conv_glds_ok() in csrc/conv_glds.h
+            key = f"conv_glds_kernel<NT={nt},PW=16,NW=8,MT=1>"
+        else:
+            key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         KernelProfile.enabled = False
@@ -266,7 +270,6 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     a.epi, a.res, a.escale, a.emb_gain, a.out2 = epi, _p(res), _p(escale), _p(emb_gain), _p(out2)
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
     a.big_tile = BIG_TILE
-    a.pad_ = int(_os.environ.get('ONIRIS_DBG', '0'))
     check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
 
 

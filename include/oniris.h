@@ -111,7 +111,8 @@ typedef struct OnirisConvArgs {
   void* out2;             /* bf16 like out              (EPI_EMB_SILU: activation; EPI_MPSUM: optional raw output) */
   float ta, tb, clip;
   void* ctx_out;          /* optional bf16 [B*T][H][W][Cout]: the un-gated context product y3 (for d gate)        */
-  int32_t big_tile;       /* tuning: 1 = 8-wave workgroups (256 positions) where available                        */
+  int32_t big_tile;       /* variant: 0 = 4-wave register-staged kernels, 1/2 = 8-wave ones where they fill the chip /
+                           * always, >= 3 = persistent LDS-DMA kernel (csrc/conv_glds.h) wherever the shape allows   */
   int32_t pad_;
 } OnirisConvArgs;
 
