@@ -152,24 +152,50 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
     store_tile();
     __syncthreads();
     if (tile + (int)gridDim.x < d.ntiles) load_tile(tile + gridDim.x);
-    // ---- MFMA: k = 16 positions per step
-#pragma unroll
-    for (int ksi = 0; ksi < 8 / NKS; ++ksi) {
-      const int ks = ksi * NKS + my_ks;
-      // rows (positions) this lane addresses for the two transposing reads
-      const int p0 = ks * 16 + 8 * hh + q, p1 = p0 + 4;
-      const bf16x8 af = tr_frag(dy_lds + p0 * DY_ROWB + (ct * 32 + pcol) * 2, dy_lds + p1 * DY_ROWB + (ct * 32 + pcol) * 2);
-      int r0 = p0, r1 = p1;
-      if constexpr (TAPS == 9) {
-        r0 = ((p0 / (P::PH * P::PW)) * P::HH + (p0 / P::PW) % P::PH) * P::HW + p0 % P::PW;
-        r1 = ((p1 / (P::PH * P::PW)) * P::HH + (p1 / P::PW) % P::PH) * P::HW + p1 % P::PW;
-      }
-#pragma unroll
-      for (int tap = 0; tap < TAPS; ++tap) {
+    // ---- MFMA: k = 16 positions per step; (k-step, tap) pairs form one flat sequence whose fragment reads run one
+    // step ahead of the MFMAs (double-buffered registers, order pinned with sched_group_barrier)
+    {
+      constexpr int NK = 8 / NKS, NSTEP = NK * TAPS;
+      bf16x8 af[4], bfm[4];                               // rings: the lookahead (<= 3 steps) never laps a live fragment
+      auto ld_a = [&](int kb, int ksi) __attribute__((always_inline)) {
+        const int ks = ksi * NKS + my_ks;
+        const int p0 = ks * 16 + 8 * hh + q, p1 = p0 + 4;
+        af[kb] = tr_frag(dy_lds + p0 * DY_ROWB + (ct * 32 + pcol) * 2, dy_lds + p1 * DY_ROWB + (ct * 32 + pcol) * 2);
+      };
+      auto ld_b = [&](int fb, int st) __attribute__((always_inline)) {
+        const int ksi = st / TAPS, tap = st % TAPS;
+        const int ks = ksi * NKS + my_ks;
+        const int p0 = ks * 16 + 8 * hh + q, p1 = p0 + 4;
+        int r0 = p0, r1 = p1;
+        if constexpr (TAPS == 9) {
+          r0 = ((p0 / (P::PH * P::PW)) * P::HH + (p0 / P::PW) % P::PH) * P::HW + p0 % P::PW;
+          r1 = ((p1 / (P::PH * P::PW)) * P::HH + (p1 / P::PW) % P::PH) * P::HW + p1 % P::PW;
+        }
         const int off = (TAPS == 9) ? ((tap / 3) * P::HW + (tap % 3)) : 0;
-        const bf16x8 bfm = tr_frag(x_lds + (r0 + off) * X_ROWB + (it * 32 + pcol) * 2,
-                                   x_lds + (r1 + off) * X_ROWB + (it * 32 + pcol) * 2);
-        acc[tap] = mfma32(af, bfm, acc[tap]);
+        bfm[fb] = tr_frag(x_lds + (r0 + off) * X_ROWB + (it * 32 + pcol) * 2, x_lds + (r1 + off) * X_ROWB + (it * 32 + pcol) * 2);
+      };
+      constexpr int LA = (NSTEP > 3) ? 3 : 1;            // fragment reads run LA MFMAs ahead (one wave per SIMD: the
+      constexpr int NA0 = (LA + TAPS - 1) / TAPS;         // wave has to cover the LDS latency by itself)
+#pragma unroll
+      for (int j = 0; j < LA; ++j) {
+        if (j % TAPS == 0) ld_a((j / TAPS) & 3, j / TAPS);
+        ld_b(j, j);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * NA0 + 2 * LA, 0);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const int ksi = st / TAPS, tap = st % TAPS;
+        const int nx = st + LA;
+        if (nx < NSTEP) {
+          if (nx % TAPS == 0) ld_a((nx / TAPS) & 3, nx / TAPS);
+          ld_b(nx & 3, nx);
+        }
+        acc[tap] = mfma32(af[ksi & 3], bfm[st & 3], acc[tap]);
+        if (nx < NSTEP) {
+          if (nx % TAPS == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
       }
     }
     __syncthreads();
