@@ -76,6 +76,7 @@ _SIGS = {
                              c_float, c_int, c_float, c_void_p]),
     "oniris_conv_fwd": (c_int, [C.POINTER(ConvArgs), c_void_p]),
     "oniris_conv_wgrad": (c_int, [C.POINTER(WgradArgs), c_void_p]),
+    "oniris_conv_wgrad_group": (c_int, [C.POINTER(WgradArgs), c_int, c_void_p]),
     "oniris_gconv_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                       c_int, c_int, c_int, c_int64, c_void_p]),
     "oniris_gconv_bwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

@@ -9,9 +9,14 @@
 // fp32 atomics, which run at ~1.3 TB/s chip-wide and took about half of the kernel time.
 #include "conv_kernels.h"
 
+// Up to three sub-problems of identical geometry (H, W, channels, taps) share one launch: the own-frame weight and the
+// two context taps of a gated conv.  Workgroup columns [gstart[g], gstart[g+1]) belong to group g; every column
+// writes ONE slab, so one launch writes as many slabs as three separate ones used to write each.
+#define WGRAD_MAXG 3
 struct WgradDev {
-  OnirisWgradArgs a;
-  int ntx, nty, ntt, ntiles, ncib;
+  OnirisWgradArgs a[WGRAD_MAXG];
+  int ntiles[WGRAD_MAXG], ntt[WGRAD_MAXG], gstart[WGRAD_MAXG + 1];
+  int ntx, nty, ncib;
 };
 
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base0, const unsigned char* base1) {
@@ -39,7 +44,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
   unsigned char* dy_lds = smem;
   unsigned char* x_lds = smem + 128 * DY_ROWB;
 
-  const OnirisWgradArgs& a = d.a;
+  int gsel = 0;
+  if ((int)blockIdx.x >= d.gstart[1]) gsel = 1;
+  if ((int)blockIdx.x >= d.gstart[2]) gsel = 2;
+  const OnirisWgradArgs& a = d.a[gsel];
+  const int bx = blockIdx.x - d.gstart[gsel], gxg = d.gstart[gsel + 1] - d.gstart[gsel];
+  const int g_ntiles = d.ntiles[gsel], g_ntt = d.ntt[gsel];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = a.H, W = a.W, T = a.T, HWp = H * W;
   const int my_tile = wave % NTILE, my_ks = wave / NTILE;
@@ -73,10 +83,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
     if constexpr (TAPS == 9) {
       const int tx = bid % d.ntx; bid /= d.ntx;
       const int ty = bid % d.nty; bid /= d.nty;
-      const int tc = bid % d.ntt; bid /= d.ntt;
+      const int tc = bid % g_ntt; bid /= g_ntt;
       t0 = tc * P::FT; y0 = ty * P::PH; x0 = tx * P::PW;
     } else {
-      const int tq = bid % d.ntt; bid /= d.ntt;
+      const int tq = bid % g_ntt; bid /= g_ntt;
       q0 = tq * 128;
     }
     const int b = bid;
@@ -146,12 +156,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
     }
   };
 
-  if ((int)blockIdx.x < d.ntiles) load_tile(blockIdx.x);
+  if (bx < g_ntiles) load_tile(bx);
 #pragma unroll 1
-  for (int tile = blockIdx.x; tile < d.ntiles; tile += gridDim.x) {
+  for (int tile = bx; tile < g_ntiles; tile += gxg) {
     store_tile();
     __syncthreads();
-    if (tile + (int)gridDim.x < d.ntiles) load_tile(tile + gridDim.x);
+    if (tile + gxg < g_ntiles) load_tile(tile + gxg);
     // ---- MFMA: k = 16 positions per step; (k-step, tap) pairs form one flat sequence whose fragment reads run one
     // step ahead of the MFMAs (double-buffered registers, order pinned with sched_group_barrier)
     {
@@ -203,7 +213,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
 
   // ---- write this workgroup column's slab  dwp[blockIdx.x][tap0 + tap][co][ci]
   // When several waves of the workgroup share one output tile (NKS > 1) they are first summed through LDS.
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.nsplit_out) *a.nsplit_out = gridDim.x;
+  if (bx == 0 && blockIdx.y == 0 && tid == 0 && a.nsplit_out) *a.nsplit_out = gxg;
   const int cj = ci0 + it * 32 + (lane & 31);
   if constexpr (NKS > 1) {
     float* red = (float*)smem;                               // [NKS-1][16][64] floats = 12 KB, staging LDS is free now
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
     }
     if (my_ks != 0) return;
   }
-  float* slab = a.dwp + (size_t)blockIdx.x * a.taps_total * a.CoutP * a.CinP;
+  float* slab = a.dwp + (size_t)bx * a.taps_total * a.CoutP * a.CinP;
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap) {
     float* base = slab + (size_t)(a.tap0 + tap) * a.CoutP * a.CinP;
@@ -240,23 +250,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
 }
 
 template <int TAPS, int PW, int CT, int IT>
-static int launch_wgrad(const OnirisWgradArgs& a, hipStream_t stream) {
+static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream) {
   using P = Patch<PW>;
+  const OnirisWgradArgs& a = args[0];
   WgradDev d;
-  d.a = a;
-  if (TAPS == 9) {
-    d.ntx = a.W / P::PW; d.nty = a.H / P::PH; d.ntt = cdiv(a.T, P::FT);
-  } else {
-    d.ntx = 1; d.nty = 1; d.ntt = cdiv(a.T * a.H * a.W, 128);
-  }
-  d.ntiles = d.ntx * d.nty * d.ntt * a.B;
+  memset(&d, 0, sizeof(d));
+  if (TAPS == 9) { d.ntx = a.W / P::PW; d.nty = a.H / P::PH; } else { d.ntx = 1; d.nty = 1; }
   d.ncib = cdiv(a.Cin, 32 * IT);
   const int ncob = cdiv(a.Cout, 32 * CT);
   const int gy = d.ncib * ncob;
-  int gx = ((CT * IT == 4) ? 256 : 512) / gy;   // ~1-2 workgroups per CU; every split-K column owns one slab
-  if (gx > a.nsplit_cap) gx = a.nsplit_cap;
-  if (gx < 1) gx = 1;
-  if (gx > d.ntiles) gx = d.ntiles;
+  long long tot = 0;
+  for (int g = 0; g < ng; ++g) {
+    d.a[g] = args[g];
+    d.ntt[g] = (TAPS == 9) ? cdiv(args[g].T, P::FT) : cdiv(args[g].T * a.H * a.W, 128);
+    d.ntiles[g] = d.ntx * d.nty * d.ntt[g] * args[g].B;
+    tot += d.ntiles[g];
+  }
+  // ~1-2 workgroups per CU in total; the split-K columns are dealt to the groups in proportion to their position
+  // tiles (every column owns one slab of ITS group's weight)
+  const int gx_all = ((CT * IT == 4) ? 256 : 512) / gy > ng ? ((CT * IT == 4) ? 256 : 512) / gy : ng;
+  int gx_tot = 0;
+  for (int g = 0; g < ng; ++g) {
+    int gx = (int)((long long)gx_all * d.ntiles[g] / (tot > 0 ? tot : 1));
+    if (gx > args[g].nsplit_cap) gx = args[g].nsplit_cap;
+    if (gx > d.ntiles[g]) gx = d.ntiles[g];
+    if (gx < 1) gx = 1;
+    d.gstart[g] = gx_tot;
+    gx_tot += gx;
+  }
+  for (int g = ng; g <= WGRAD_MAXG; ++g) d.gstart[g] = gx_tot;      // empty groups
   constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
   constexpr int LDS = 128 * ((CT == 1) ? 64 : 192) + XROWS * ((IT == 1) ? 64 : 192);
   auto kern = conv_wgrad_kernel<TAPS, PW, CT, IT>;
@@ -270,33 +292,44 @@ static int launch_wgrad(const OnirisWgradArgs& a, hipStream_t stream) {
       attr_done = true;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256), LDS, stream, d);
+  hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256), LDS, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
 
 template <int TAPS, int PW>
-static int wgrad_pick_tile(const OnirisWgradArgs& a, hipStream_t stream) {
-  if (a.Cin > 32 && a.Cout > 32) return launch_wgrad<TAPS, PW, 2, 2>(a, stream);
-  return launch_wgrad<TAPS, PW, 1, 1>(a, stream);
+static int wgrad_pick_tile(const OnirisWgradArgs* a, int ng, hipStream_t stream) {
+  if (a[0].Cin > 32 && a[0].Cout > 32) return launch_wgrad<TAPS, PW, 2, 2>(a, ng, stream);
+  return launch_wgrad<TAPS, PW, 1, 1>(a, ng, stream);
 }
 
-extern "C" int oniris_conv_wgrad(const OnirisWgradArgs* args, oniris_stream_t stream_) {
+extern "C" int oniris_conv_wgrad_group(const OnirisWgradArgs* args, int ngroups, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ONIRIS_CHECK_ARG(args && args->x && args->dy && args->dwp, "conv_wgrad: null pointer");
-  ONIRIS_CHECK_ARG(args->nsplit_cap >= 1 && args->taps_total >= args->taps + args->tap0 && args->tap0 >= 0,
-                   "conv_wgrad: bad slab description");
-  const OnirisWgradArgs& a = *args;
+  ONIRIS_CHECK_ARG(args && ngroups >= 1 && ngroups <= WGRAD_MAXG, "conv_wgrad: 1..%d groups", WGRAD_MAXG);
+  const OnirisWgradArgs& a = args[0];
+  for (int g = 0; g < ngroups; ++g) {
+    const OnirisWgradArgs& b = args[g];
+    ONIRIS_CHECK_ARG(b.x && b.dy && b.dwp, "conv_wgrad: null pointer (group %d)", g);
+    ONIRIS_CHECK_ARG(b.nsplit_cap >= 1 && b.taps_total >= b.taps + b.tap0 && b.tap0 >= 0,
+                     "conv_wgrad: bad slab description (group %d)", g);
+    ONIRIS_CHECK_ARG(b.B > 0 && b.T > 0, "conv_wgrad: empty group %d", g);
+    ONIRIS_CHECK_ARG(b.H == a.H && b.W == a.W && b.Cin == a.Cin && b.CinP == a.CinP && b.Cout == a.Cout &&
+                     b.CoutP == a.CoutP && b.taps == a.taps, "conv_wgrad: groups must share H, W, channels and taps");
+  }
   ONIRIS_CHECK_ARG(a.taps == 9 || a.taps == 1, "conv_wgrad: taps must be 1 or 9 (got %d)", a.taps);
   ONIRIS_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv_wgrad: Cin/Cout must be multiples of 8");
   ONIRIS_CHECK_ARG(a.CoutP % 32 == 0 && a.CinP % 64 == 0 && a.CoutP >= a.Cout && a.CinP >= a.Cin,
                    "conv_wgrad: bad padded sizes");
-  if (a.taps == 1) return wgrad_pick_tile<1, 16>(a, stream);
+  if (a.taps == 1) return wgrad_pick_tile<1, 16>(args, ngroups, stream);
   const int W = a.W, H = a.H;
-  if (W >= 16 && W % 16 == 0 && H % 8 == 0) return wgrad_pick_tile<9, 16>(a, stream);
-  if (W == 8 && H % 8 == 0) return wgrad_pick_tile<9, 8>(a, stream);
-  if (W == 4 && H % 4 == 0) return wgrad_pick_tile<9, 4>(a, stream);
-  if (W == 2 && H % 2 == 0) return wgrad_pick_tile<9, 2>(a, stream);
+  if (W >= 16 && W % 16 == 0 && H % 8 == 0) return wgrad_pick_tile<9, 16>(args, ngroups, stream);
+  if (W == 8 && H % 8 == 0) return wgrad_pick_tile<9, 8>(args, ngroups, stream);
+  if (W == 4 && H % 4 == 0) return wgrad_pick_tile<9, 4>(args, ngroups, stream);
+  if (W == 2 && H % 2 == 0) return wgrad_pick_tile<9, 2>(args, ngroups, stream);
   oniris_set_error("conv_wgrad: unsupported image size %dx%d", H, W);
   return ONIRIS_EUNSUPPORTED;
+}
+
+extern "C" int oniris_conv_wgrad(const OnirisWgradArgs* args, oniris_stream_t stream) {
+  return oniris_conv_wgrad_group(args, 1, stream);
 }

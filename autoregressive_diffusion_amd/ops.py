@@ -273,27 +273,40 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
 
 
-def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
+def _wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
     """pw: PackedWeight whose slabs receive the partial sums (taps [tap0, tap0+taps) of its pw.taps-deep slabs)."""
-    if KernelProfile.enabled:
-        tile = 2 if (Cin > 32 and Cout > 32) else 1
-        key = f"conv_wgrad_kernel<TAPS={taps},PW={_patch_w(W)},CT={tile},IT={tile}>"
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        KernelProfile.enabled = False
-        try:
-            _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0)
-        finally:
-            KernelProfile.enabled = True
-        e1.record()
-        KernelProfile.records.append((key, 2.0 * B * T * H * W * Cout * Cin * taps, e0, e1))
-        return
     a = _lib.WgradArgs()
     a.x, a.dy, a.dwp, a.scale = _p(x), _p(dy), _p(pw.dwp), _p(scale)
     a.nsplit_cap, a.taps_total, a.tap0, a.nsplit_out = pw.nsplit_cap, pw.taps, tap0, _p(pw.nsplit)
     a.B, a.T, a.H, a.W, a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = B, T, H, W, Cin, CinP, Cout, CoutP, taps
     a.xb_stride, a.x_T, a.coff, a.fill = xb_stride, x_T, coff, fill
-    check(lib.oniris_conv_wgrad(ctypes.byref(a), _stream()), "conv_wgrad")
+    return a
+
+
+def _wgrad_launch_group(arglist):
+    """One launch for 1..3 weight-gradient problems of the same geometry (oniris_conv_wgrad_group)."""
+    if KernelProfile.enabled:
+        a0 = arglist[0]
+        tile = 2 if (a0.Cin > 32 and a0.Cout > 32) else 1
+        key = f"conv_wgrad_kernel<TAPS={a0.taps},PW={_patch_w(a0.W)},CT={tile},IT={tile}>"
+        flops = sum(2.0 * a.B * a.T * a.H * a.W * a.Cout * a.Cin * a.taps for a in arglist)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        KernelProfile.enabled = False
+        try:
+            _wgrad_launch_group(arglist)
+        finally:
+            KernelProfile.enabled = True
+        e1.record()
+        KernelProfile.records.append((key, flops, e0, e1))
+        return
+    arr = (_lib.WgradArgs * len(arglist))(*arglist)
+    check(lib.oniris_conv_wgrad_group(arr, len(arglist), _stream()), "conv_wgrad")
+
+
+def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
+    _wgrad_launch_group([_wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff,
+                                     fill, tap0)])
 
 
 class ConvCfg:
@@ -404,12 +417,15 @@ class _ConvOp(torch.autograd.Function):
                 sel = _clean_selector(B, T, dev)               # the context gradient only reaches the clean slot
                 _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca, sel, B, 2, T, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb, 9,
                              ctx_bstride=T, ctx_T=T, coff=(2, 1), ctx_fill=0.0)
+            grp = []                                 # own-frame weight + the two context taps: ONE split-K launch
             if pw2.param.requires_grad:
-                _wgrad_launch(x, dout, pw2, ca, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0)
+                grp.append(_wgrad_args(x, dout, pw2, ca, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0))
             if pw3.param.requires_grad:
                 for j, coff in enumerate((-2, -1)):
-                    _wgrad_launch(x, dy3, pw3, None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T, coff, 1.0,
-                                  tap0=9 * j)
+                    grp.append(_wgrad_args(x, dy3, pw3, None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T, coff,
+                                           1.0, tap0=9 * j))
+            if grp:
+                _wgrad_launch_group(grp)
         else:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)

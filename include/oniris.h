@@ -137,6 +137,12 @@ typedef struct OnirisWgradArgs {
 } OnirisWgradArgs;
 
 int oniris_conv_wgrad(const OnirisWgradArgs* args /* [host] */, oniris_stream_t stream);
+/* 1..3 weight-gradient problems of identical geometry (H, W, channels, taps) in ONE launch -- the own-frame weight and
+ * the two context taps of a gated conv.  The split-K workgroup columns are shared out in proportion to the groups'
+ * position counts, so the launch writes (and oniris_weight_bwd later reads) a third of the slab bytes of three
+ * separate launches.  Groups that address the same weight must use disjoint tap ranges (tap0).                    */
+int oniris_conv_wgrad_group(const OnirisWgradArgs* args /* [host], ngroups entries */, int ngroups,
+                            oniris_stream_t stream);
 
 /* Backward pre-pass of the gated conv (autograd of edm2/conv.py:90-95): one pass over dout computing, per
  * frame-slot n, d_coef_own[n] = sum(dout*y2) (recovered as (sum(dout*out) - coef_ctx*sum(dout*y3)) / coef_own),
