@@ -17,12 +17,17 @@ _tls = threading.local()
 def _bank_of(root):
     bank = root.__dict__.get("_oniris_bank")
     mods = [m for m in root.modules() if isinstance(m, NormalizedWeight)]
-    if bank is None or bank._n_mods != len(mods) or any(m.pw is None or m.pw.param is not m.weight for m in mods):
+    if bank is None or bank._n_mods != len(mods) or any(m.pw is None or m.pw.param is not m.weight or m.pw.bank is not bank
+                                                        for m in mods):
         bank = ops.WeightBank()
         for m in mods:
             m.pw = bank.add(m.weight, perm3=m.perm3)
             m.pw.bank = bank
         bank._n_mods = len(mods)
+        # 1x1 weights that read the same input (UNet: the emb_linear of every Block) become one row-concatenated GEMM
+        for sub in root.modules():
+            if hasattr(sub, "_oniris_weight_groups"):
+                sub.__dict__["_oniris_groups"] = [bank.add_group([m.pw for m in grp]) for grp in sub._oniris_weight_groups()]
         root.__dict__["_oniris_bank"] = bank
     return bank
 

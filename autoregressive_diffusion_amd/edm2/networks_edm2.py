@@ -36,7 +36,8 @@ class Block(nn.Module):
         else:
             self.attn = FrameAttention(out_channels, self.num_heads, attn_balance)
 
-    def _cl(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False, skip=None, cat_w=None):
+    def _cl(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False, skip=None, cat_w=None,
+            c=None):
         """x (N,H,W,C) bf16, emb (N,1,1,cemb) bf16; skip/cat_w: the decoder's mp_cat operand, fused into the first
         activation kernel.  Elementwise chains of the reference's Block.forward (:62-94) run as fused HIP kernels:
         [mp_cat | pixel norm] + mp_silu -> act;  *c + mp_silu -> conv_res0 epilogue;  mp_sum (+clip) -> conv_res1 /
@@ -53,7 +54,8 @@ class Block(nn.Module):
         else:
             a = ops.act(x)
         N = x.shape[0]
-        c = (self.emb_linear._cl(emb).reshape(N, -1).float() * self.emb_gain + 1)      # (N, Cout) fp32
+        if c is None:          # (the UNet hands in all of its blocks' scales from one grouped GEMM: ops.emb_scales)
+            c = (self.emb_linear._cl(emb).reshape(N, -1).float() * self.emb_gain + 1)      # (N, Cout) fp32
         y, cache["conv_res0"] = self.conv_res0._cl(a, batch_size, c_noise, cache.get("conv_res0"), update_cache,
                                                    just_2d, cscale=c)    # y = mp_silu(conv(a) * c)
         if self.training and self.dropout != 0:
@@ -158,10 +160,14 @@ class UNet(BetterModule):
             xcl = to_cl(xc, pad_to=-(-xc.shape[1] // 16) * 16)
             if not just_2d:
                 self._prime_gates(c_noise, cache)
+            blocks = self._emb_blocks()
+            cs = dict(zip(map(id, blocks), ops.emb_scales(emb, self.__dict__["_oniris_groups"][0],
+                                                          [b.emb_gain for b in blocks])))
             skips = []
             for name, block in self.enc.items():
                 if isinstance(block, Block):
-                    xcl, cache["enc", name] = block._cl(xcl, emb, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
+                    xcl, cache["enc", name] = block._cl(xcl, emb, B, c_noise, cache.get(("enc", name)), update_cache, just_2d,
+                                                        c=cs[id(block)])
                 else:
                     xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
                 skips.append(xcl)
@@ -173,11 +179,18 @@ class UNet(BetterModule):
                     Cn = math.sqrt((Na + Nb) / ((1 - t) ** 2 + t ** 2))
                     cat_w = (Cn / math.sqrt(Na) * (1 - t), Cn / math.sqrt(Nb) * t)
                 xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d,
-                                                    skip=skip, cat_w=cat_w)
+                                                    skip=skip, cat_w=cat_w, c=cs[id(block)])
             xcl, cache["out_conv"] = self.out_conv._cl(xcl, B, c_noise, cache.get("out_conv"), update_cache, just_2d)
             out = from_cl(xcl[..., :self.img_channels], torch.float32)
             out = out.reshape(B, tt, *out.shape[1:]) * self.out_gain
             return out, cache
+
+    def _emb_blocks(self):
+        return [b for b in list(self.enc.values()) + list(self.dec.values()) if isinstance(b, Block)]
+
+    def _oniris_weight_groups(self):
+        """Weights packed row-concatenated (one GEMM for all): every Block's emb_linear reads the same embedding."""
+        return [[b.emb_linear.weight for b in self._emb_blocks()]]
 
     def _prime_gates(self, c_noise, cache):
         """Evaluate the gates of all gated convs at once and hand each layer its (ca, cb, counter)."""

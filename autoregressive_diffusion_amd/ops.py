@@ -97,7 +97,7 @@ def device_tables(kind, n_frames, image_size, device):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp", "bank", "nsplit_cap", "nsplit")
+                 "wf", "wb", "dwp", "bank", "nsplit_cap", "nsplit", "group", "goff", "members")
 
 
 class WeightBank:
@@ -108,6 +108,7 @@ class WeightBank:
         self.total_rows = 0
         self._finish_queued = False
         self.post_backward_hooks = []      # callables run after the weight gradients are final (DDP all-reduce)
+        self.groups = []                   # PackedWeight views over row-concatenated 1x1 weights (add_group)
 
     def add(self, param, perm3=False, gain=1.0, need_dgrad=True):
         w = PackedWeight()
@@ -120,6 +121,7 @@ class WeightBank:
         w.CoutPb, w.CinPb = roundup(w.cin, 32), roundup(w.cout, 64)
         w.perm3, w.gain = bool(perm3), float(gain)
         w.wf = w.wb = w.dwp = w.nsplit = None
+        w.group, w.goff, w.members = None, 0, None
         # split-K slabs of the weight-gradient kernel: same bound as launch_wgrad() in csrc/conv_wgrad.hip
         tile = 2 if (w.cin > 32 and w.cout > 32) else 1
         gy = -(-roundup(w.cin, 16) // (32 * tile)) * -(-roundup(w.cout, 8) // (32 * tile))
@@ -128,6 +130,33 @@ class WeightBank:
         self.items.append((w, need_dgrad))
         return w
 
+    def add_group(self, members):
+        """Row-concatenate 1x1 weights that share their input (the emb_linear of every Block reads the same
+        embedding, networks_edm2.py:78): ONE GEMM / dgrad / wgrad launch serves all of them.  `members` are
+        PackedWeights of this bank with taps == 1 and equal cin; each keeps its own descriptor (normalisation and
+        gradient are per weight) but its packed buffers become slices of the group's matrices: rows
+        [off, off+cout) of wf [Ctot][CinP], columns of wb [CoutPb][Ctot], rows of every dwp slab -- which the
+        descriptor expresses as CoutP = CinPb = Ctot plus a pointer offset.  Member k is padded to roundup(cout,64)
+        rows (zero weights).  Returns the group PackedWeight; member.goff / member.gpad locate its columns."""
+        assert members and all(m.taps == 1 and m.cin == members[0].cin and not m.perm3 for m in members)
+        g = PackedWeight()
+        g.members = list(members)
+        off = 0
+        for m in g.members:
+            m.group, m.goff = g, off
+            off += roundup(m.cout, 64)
+        g.cout = g.CoutP = g.CinPb = off
+        g.cin, g.taps, g.kt = members[0].cin, 1, 1
+        g.CinP, g.CoutPb = roundup(g.cin, 64), roundup(g.cin, 32)
+        g.perm3, g.gain, g.param, g.bank = False, 1.0, members[0].param, self
+        g.wf = g.wb = g.dwp = g.nsplit = None
+        tile = 2 if (g.cin > 32 and g.cout > 32) else 1
+        gy = -(-roundup(g.cin, 16) // (32 * tile)) * -(-g.cout // (32 * tile))
+        g.nsplit_cap = max(1, (256 if tile == 2 else 512) // gy)
+        self.groups.append(g)
+        self._dev_table = None
+        return g
+
     def _signature(self):
         return tuple((w.param.data_ptr(), w.param.grad.data_ptr() if w.param.grad is not None else 0)
                      for w, _ in self.items)
@@ -135,15 +164,29 @@ class WeightBank:
     def _build(self, device):
         descs = (_lib.WeightDesc * len(self.items))()
         row = 0
-        if getattr(self, "nsplit_all", None) is None or self.nsplit_all.device != device:
-            self.nsplit_all = torch.zeros(len(self.items), dtype=torch.int32, device=device)
+        nslots = len(self.items) + len(self.groups)
+        if getattr(self, "nsplit_all", None) is None or self.nsplit_all.device != device or self.nsplit_all.numel() != nslots:
+            self.nsplit_all = torch.zeros(nslots, dtype=torch.int32, device=device)
         for i, (w, _) in enumerate(self.items):
             w.nsplit = self.nsplit_all[i:i + 1]
+        for j, g in enumerate(self.groups):                     # group buffers; members become slices of them
+            k = len(self.items) + j
+            g.nsplit = self.nsplit_all[k:k + 1]
+            if g.wf is None or g.wf.device != device:
+                g.wf = torch.zeros(g.cout * g.CinP, dtype=BF16, device=device)
+                g.wb = torch.zeros(g.CoutPb * g.cout, dtype=BF16, device=device)
+                g.dwp = torch.empty(g.nsplit_cap * g.cout * g.CinP, dtype=torch.float32, device=device)
+            for m in g.members:
+                m.nsplit, m.nsplit_cap = g.nsplit, g.nsplit_cap
+                m.wf = g.wf[m.goff * g.CinP:]
+                m.wb = g.wb[m.goff:]
+                m.dwp = g.dwp[m.goff * g.CinP:]
         for i, (w, need_dgrad) in enumerate(self.items):
             p = w.param
             if p.dtype != torch.float32 or not p.is_contiguous():
                 raise RuntimeError("weights must be contiguous fp32")
-            if w.wf is None or w.wf.device != p.device:
+            grouped = getattr(w, "group", None) is not None
+            if not grouped and (w.wf is None or w.wf.device != p.device):
                 w.wf = torch.zeros(w.taps * w.CoutP * w.CinP, dtype=BF16, device=device)
                 w.wb = torch.zeros(w.taps * w.CoutPb * w.CinPb, dtype=BF16, device=device) if need_dgrad else None
                 w.dwp = torch.empty(w.nsplit_cap * w.taps * w.CoutP * w.CinP, dtype=torch.float32, device=device)
@@ -157,6 +200,8 @@ class WeightBank:
             d.dwp = w.dwp.data_ptr()
             d.cout, d.cin, d.taps, d.kt = w.cout, w.cin, w.taps, w.kt
             d.CoutP, d.CinP, d.CoutPb, d.CinPb = w.CoutP, w.CinP, w.CoutPb, w.CinPb
+            if grouped:                                         # slice of the group's matrices (see add_group)
+                d.CoutP = d.CinPb = w.group.cout
             d.row_start, d.perm3, d.gain = row, int(w.perm3), w.gain
             d.nsplit_cap, d.nsplit = w.nsplit_cap, w.nsplit.data_ptr()
             row += w.cout
@@ -570,6 +615,60 @@ def resample(x, mode):
     if mode == "keep":
         return x
     return _ResampleFn.apply(x, 0 if mode == "down" else 1)
+
+
+class _SplitCols(torch.autograd.Function):
+    """x (N, sum(sizes)) -> contiguous column blocks (one fused copy); backward = one concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, sizes):
+        ctx.sizes, ctx.n = tuple(sizes), x.shape[0]
+        return tuple(torch.split_with_sizes_copy(x, list(sizes), dim=1))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        zeros = None
+        parts = []
+        for g, sz in zip(grads, ctx.sizes):
+            if g is None:
+                if zeros is None:
+                    zeros = ref.new_zeros((ctx.n, max(ctx.sizes)))
+                g = zeros[:, :sz]
+            parts.append(g)
+        return torch.cat(parts, dim=1), None
+
+
+def emb_scales(emb, gpw, gains):
+    """All `c = emb_linear(emb) * emb_gain + 1` of a UNet (networks_edm2.py:78 in every Block) at once:
+    emb (N,1,1,Cemb) bf16, gpw the row-concatenated emb_linear group (WeightBank.add_group), gains the emb_gain
+    parameters in member order.  Returns one contiguous (N, cout_k) fp32 tensor per member."""
+    N = emb.shape[0]
+    c_all = conv(emb, gpw).reshape(N, gpw.cout)
+    dev = emb.device
+    sizes, seg = [], []
+    for k, m in enumerate(gpw.members):
+        sizes.append(m.cout)
+        seg += [k] * m.cout
+        pad = roundup(m.cout, 64) - m.cout
+        if pad:
+            sizes.append(pad)
+            seg += [k] * pad
+    cache = _emb_idx_cache.get((id(gpw), str(dev)))
+    if cache is None:
+        cache = torch.tensor(seg, dtype=torch.int64, device=dev)
+        _emb_idx_cache[(id(gpw), str(dev))] = cache
+    g_col = torch.stack(list(gains)).float().index_select(0, cache)                 # (Ctot,)
+    c = torch.addcmul(torch.ones((), dtype=torch.float32, device=dev), c_all.float(), g_col)
+    outs = _SplitCols.apply(c, tuple(sizes))
+    res, j = [], 0
+    for m in gpw.members:
+        res.append(outs[j])
+        j += 2 if roundup(m.cout, 64) != m.cout else 1
+    return res
+
+
+_emb_idx_cache = {}
 
 
 # ------------------------------------------------------------------------------------------------------------------
