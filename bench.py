@@ -22,6 +22,29 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 GYM_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=32, channel_mult=[1, 2, 4, 8],
                channel_mult_noise=None, channel_mult_emb=None, num_blocks=2, video_attn_resolutions=[8],
                frame_attn_resolutions=[16])
+def _pmc_traffic(key):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench, summarised by
+    scratch/pmc_traffic.py with the gfx950 correction 2*FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be collected
+    from inside the timed process, so the number is only as fresh as that file; None when the kernel is not in it."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    name = key.split("<")[0]
+    want = [int(v) for v in re.findall(r"=(\d+)", key)]          # template arguments in KernelProfile's key order
+    for k, v in table.items():
+        if name in k:
+            have = [int(x) if x.isdigit() else (1 if x == "true" else 0) for x in re.findall(r"[<,]\s*(\d+|true|false)", k)]
+            if have[:len(want)] == want:
+                return v["hbm_bytes_per_launch"]
+    return None
+
+
 MFMA_BF16_PEAK = 2.5e15          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
 # algorithmic forward FLOPs per sample of the 3-D step at T=64 (BASELINE.md section 4): 1.82 TFLOP; x3 fwd+bwd
 
@@ -218,7 +241,7 @@ def main():
         achieved = v["flops"] / (v["ms"] * 1e-3)
         roof = dict(bound="mfma", kernel=dom, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
                     flops_per_launch=v["flops"] / v["launches"], achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12,
-                    unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=None)
+                    unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=_pmc_traffic(dom))
     elif world > 1:
         for i in range(4):
             step(i, profile=True)                                 # keep collectives matched across ranks
