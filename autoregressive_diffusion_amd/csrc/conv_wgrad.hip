@@ -31,6 +31,8 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base0, const unsi
   return __builtin_bit_cast(bf16x8, v);
 }
 
+#include "conv_wgrad_glds.h"
+
 template <int TAPS, int PW, int CT, int IT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
   using P = Patch<PW>;
@@ -279,6 +281,23 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
     gx_tot += gx;
   }
   for (int g = ng; g <= WGRAD_MAXG; ++g) d.gstart[g] = gx_tot;      // empty groups
+  if constexpr (TAPS == 9 && PW == 16 && CT == 2 && IT == 2) {
+    if (a.pad_ >= 0 && wgrad_glds_ok(args, ng)) {                    // LDS-DMA variant (pad_ < 0 forces the register-staged one)
+      constexpr int NG = 2, LDSB = NG * 2 * (128 * 128 + P::HALO * 128);
+      auto kern = conv_wgrad_glds_kernel<NG>;
+      static bool attr_done = false;
+      if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) {
+          oniris_set_error("conv_wgrad: cannot raise dynamic LDS to %d", LDSB);
+          return ONIRIS_ELAUNCH;
+        }
+        attr_done = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256 * NG), LDSB, stream, d);
+      ONIRIS_LAUNCH_CHECK();
+      return ONIRIS_OK;
+    }
+  }
   constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
   constexpr int LDS = 128 * ((CT == 1) ? 64 : 192) + XROWS * ((IT == 1) ? 64 : 192);
   auto kern = conv_wgrad_kernel<TAPS, PW, CT, IT>;

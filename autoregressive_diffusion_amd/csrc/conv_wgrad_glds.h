@@ -1,0 +1,229 @@
+// Weight gradient of the 3x3 (gated) convolutions on images >= 16 pixels wide, 64x64-channel output tiles:
+// LDS-DMA variant of conv_wgrad_kernel<9,16,2,2> (same math, same slabs, bit-identical partial sums per tile order).
+//
+// Why: the register-staged kernel spends as many cycles on VALU (address math of the loads, the dy*scale pass, ~620
+// VALU instructions per position tile and wave) as on its 72 MFMAs, with ONE wave per SIMD (144 accumulators + the
+// staging registers) and a prefetch distance of one tile.  Here
+//   * dy tile [128 positions][64 co] and x halo [180 rows][64 ci] (128-byte rows) go global -> LDS by
+//     `buffer_load ... lds`; per-lane offsets are tile-invariant (dy) or one compare-select per piece (x halo), the
+//     tile origin / frame / fill choice is the uniform soffset / resource;
+//   * the 16-byte pieces of a row are XOR-swizzled (piece ^ 4*bit1(row)) on the SOURCE side, which makes the four
+//     rows a transposing read touches land on disjoint banks without padding;
+//   * a workgroup has NG = 2 K-groups of 4 waves (two waves per SIMD: 144 AGPR + < 110 VGPR), each with its own two
+//     LDS buffers (2 x 2 x 38.5 KB), one barrier per tile; the groups' partial sums meet in LDS at the end, so the
+//     slab count stays one per workgroup;
+//   * the per-frame dy coefficient is applied to the A fragment in registers (same bf16 rounding as before).
+#pragma once
+#include "lds_dma.h"
+
+template <int NG>
+__global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const WgradDev d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using P = Patch<16>;                                  // 8 x 16 pixel tiles of one frame (128 positions)
+  constexpr int TAPS = 9, ROWB = 128;
+  constexpr int DY_BYTES = 128 * ROWB, X_BYTES = P::HALO * ROWB, BUFB = DY_BYTES + X_BYTES;
+  static_assert(P::FT == 1 && P::HALO == 180, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  int gsel = 0;
+  if ((int)blockIdx.x >= d.gstart[1]) gsel = 1;
+  if ((int)blockIdx.x >= d.gstart[2]) gsel = 2;
+  const OnirisWgradArgs& a = d.a[gsel];
+  const int bx = blockIdx.x - d.gstart[gsel], gxg = d.gstart[gsel + 1] - d.gstart[gsel];
+  const int g_ntiles = d.ntiles[gsel], g_ntt = d.ntt[gsel];
+  const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 8, gtid = tid & 255, wave4 = (tid >> 6) & 3;
+  const int H = a.H, W = a.W, HWp = H * W, Cin = a.Cin, Cout = a.Cout;
+  const int ct = wave4 & 1, it = wave4 >> 1;
+  const int cib = blockIdx.y % d.ncib, cob = blockIdx.y / d.ncib;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  unsigned char* gbase = smem + kg * 2 * BUFB;          // this K-group's two buffers
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // ---- DMA descriptors
+  constexpr int OOB = (int)0x80000000;
+  constexpr int DNI = 128 * 8 / 256, XNI = (P::HALO * 8 + 255) / 256;
+  int dvoff[DNI], xrel[XNI], xhyx[XNI];
+#pragma unroll
+  for (int i = 0; i < DNI; ++i) {
+    const int e = i * 256 + gtid;
+    const int row = e >> 3, gp = (e & 7) ^ (4 * ((row >> 1) & 1));
+    const int co = co0 + gp * 8;
+    dvoff[i] = (co < Cout) ? (((row >> 4) * W + (row & 15)) * Cout + co) * 2 : OOB;
+  }
+#pragma unroll
+  for (int i = 0; i < XNI; ++i) {
+    const int e = i * 256 + gtid;
+    const int row = e >> 3, gp = (e & 7) ^ (4 * ((row >> 1) & 1));
+    const int hy = row / P::HW, hx = row % P::HW;
+    const int ci = ci0 + gp * 8;
+    xhyx[i] = (e < P::HALO * 8 && ci < Cin) ? ((hy << 8) | hx) : -1;
+    xrel[i] = (((hy - 1) * W + (hx - 1)) * Cin + ci) * 2;
+  }
+  const i32x4 rs_dy = make_rsrc(a.dy, a.B * a.T * HWp * Cout * 2);
+  const i32x4 rs_x = make_rsrc(a.x, a.B * a.xb_stride * HWp * Cin * 2);
+  const i32x4 rs_f = make_rsrc(oniris_fill_rows, 128);
+  const int fillsel = (a.fill != 0.f) ? 64 : 0;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+
+  struct Tile { int b, t, y0, x0; };
+  auto decode = [&](int id) __attribute__((always_inline)) {
+    Tile tl;
+    tl.x0 = (id % d.ntx) * P::PW; id /= d.ntx;
+    tl.y0 = (id % d.nty) * P::PH; id /= d.nty;
+    tl.t = id % g_ntt; tl.b = id / g_ntt;
+    return tl;
+  };
+  auto issue = [&](const Tile& tl, int bsel) __attribute__((always_inline)) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (kg * 2 + bsel) * BUFB + wave4 * 1024);
+    const int so_dy = (((tl.b * a.T + tl.t) * HWp + tl.y0 * W + tl.x0) * Cout) * 2;
+#pragma unroll
+    for (int i = 0; i < DNI; ++i) dma16(rs_dy, dvoff[i], so_dy, dst + i * 4096);
+    const int f = tl.t + a.coff;
+    const bool real = f >= 0 && f < a.x_T;
+    const int origin = (tl.y0 * W + tl.x0) * Cin * 2;
+    const int so_x = real ? ((tl.b * a.xb_stride + f) * HWp * Cin) * 2 : 0;
+#pragma unroll
+    for (int i = 0; i < XNI; ++i) {
+      if (i * 256 + gtid < P::HALO * 8) {
+        const int hy = xhyx[i] >> 8, hx = xhyx[i] & 255;
+        const bool ok = xhyx[i] >= 0 && (unsigned)(tl.y0 + hy - 1) < (unsigned)H && (unsigned)(tl.x0 + hx - 1) < (unsigned)W;
+        if (real) dma16(rs_x, ok ? xrel[i] + origin : OOB, so_x, dst + DY_BYTES + i * 4096);
+        else dma16(rs_f, ok ? fillsel : OOB, 0, dst + DY_BYTES + i * 4096);
+      }
+    }
+  };
+
+  // ---- fragment addresses (transposing reads: lane -> (row q, 8-byte column slot); see conv_wgrad.hip)
+  const int hh = lane >> 5, q = (lane & 15) >> 2;
+  const int cslot = (lane & 3) * 8 + 32 * ((lane >> 4) & 1);
+  const int dya = (8 * hh + q) * ROWB + ((ct * 64 + cslot) ^ (64 * ((q >> 1) & 1)));          // + ks*16*ROWB (+512: rows +4)
+  int xa[3][2];                                            // [kx][parity of (ks+ky)]
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int par = 0; par < 2; ++par)
+      xa[kx][par] = DY_BYTES + (8 * hh + q + kx) * ROWB + ((it * 64 + cslot) ^ (64 * (par ^ (((q + kx) >> 1) & 1))));
+
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto trf = [&](const unsigned char* p0) __attribute__((always_inline)) {       // rows r..r+3 and r+4..r+7
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * ROWB));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  // ---- tile loop: K-group kg takes tiles (bx + j*gxg)*NG + kg
+  const int tstep = gxg * NG;
+  int tile = bx * NG + kg;
+  int bsel = 0;
+  float sc_next = 1.f;
+  Tile cur = decode(tile < g_ntiles ? tile : 0);
+  if (tile < g_ntiles) {
+    if (a.scale) sc_next = a.scale[cur.b * a.T + cur.t];
+    issue(cur, 0);
+  }
+#pragma unroll 1
+  for (int t0 = bx * NG; t0 < g_ntiles; t0 += tstep) {
+    const bool have = tile < g_ntiles;
+    dma_wait();
+    __syncthreads();                       // this tile has landed for everybody; buffer bsel^1 is free again
+    float sc = sc_next;
+    asm volatile("" : "+v"(sc));          // consume the coefficient before the next DMA goes out (see conv_glds.h)
+    const int ntile = tile + tstep;
+    if (ntile < g_ntiles) {
+      const Tile nx = decode(ntile);
+      if (a.scale) sc_next = a.scale[nx.b * a.T + nx.t];
+      issue(nx, bsel ^ 1);
+    }
+    if (have) {
+      const unsigned char* buf = gbase + bsel * BUFB;
+      constexpr int NSTEP = 8 * TAPS, LA = 3;
+      bf16x8 af[2], bfm[4];
+      auto ld_a = [&](int kb, int ks) __attribute__((always_inline)) {
+        bf16x8 v = trf(buf + dya + ks * 16 * ROWB);
+        if (a.scale) {                    // per-frame coefficient folded into dy (bf16 rounding, like a dy2 tensor)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) * sc);
+        }
+        af[kb] = v;
+      };
+      auto ld_b = [&](int fb, int st) __attribute__((always_inline)) {
+        const int ks = st / TAPS, tap = st % TAPS, ky = tap / 3, kx = tap % 3;
+        bfm[fb] = trf(buf + xa[kx][(ks + ky) & 1] + (ks + ky) * P::HW * ROWB);
+      };
+      ld_a(0, 0);
+#pragma unroll
+      for (int j = 0; j < LA; ++j) ld_b(j, j);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * LA, 0);
+#pragma unroll
+      for (int st = 0; st < NSTEP; ++st) {
+        const int ks = st / TAPS, tap = st % TAPS;
+        const int nxs = st + LA;
+        if (nxs < NSTEP) {
+          if (nxs % TAPS == 0) ld_a((nxs / TAPS) & 1, nxs / TAPS);
+          ld_b(nxs & 3, nxs);
+        }
+        acc[tap] = mfma32(af[ks & 1], bfm[st & 3], acc[tap]);
+        if (nxs < NSTEP) {
+          if (nxs % TAPS == 0) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
+    }
+    tile = ntile;
+    bsel ^= 1;
+  }
+
+  // ---- K-groups meet in LDS (tap by tap, 16 KB), then K-group 0 writes the workgroup's slab
+  if (bx == 0 && blockIdx.y == 0 && tid == 0 && a.nsplit_out) *a.nsplit_out = gxg;
+  if constexpr (NG > 1) {
+    float* red = (float*)smem;                             // [4 waves][16][64] floats
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      __syncthreads();
+      if (kg == 1) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) red[(wave4 * 16 + rr) * 64 + lane] = acc[tap][rr];
+      }
+      __syncthreads();
+      if (kg == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc[tap][rr] += red[(wave4 * 16 + rr) * 64 + lane];
+      }
+    }
+    if (kg != 0) return;
+  }
+  const int cj = ci0 + it * 32 + (lane & 31);
+  float* slab = a.dwp + (size_t)bx * a.taps_total * a.CoutP * a.CinP;
+#pragma unroll
+  for (int tap = 0; tap < TAPS; ++tap) {
+    float* base = slab + (size_t)(a.tap0 + tap) * a.CoutP * a.CinP;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const int co = co0 + ct * 32 + mfma_row(rr, lane);
+      if (co < a.CoutP && cj < a.CinP) base[(size_t)co * a.CinP + cj] = acc[tap][rr];
+    }
+  }
+#endif
+}
+
+// true when every group of the launch can take the LDS-DMA kernel
+static inline bool wgrad_glds_ok(const OnirisWgradArgs* args, int ng) {
+  for (int g = 0; g < ng; ++g) {
+    const OnirisWgradArgs& a = args[g];
+    if (a.taps != 9 || a.W % 16 != 0 || a.H % 8 != 0 || !(a.Cin > 32 && a.Cout > 32)) return false;
+    if (!(a.fill == 0.f || a.fill == 1.f)) return false;
+    if ((long long)a.B * a.T * a.H * a.W * a.Cout * 2 >= (1LL << 31)) return false;
+    if ((long long)a.B * a.xb_stride * a.H * a.W * a.Cin * 2 >= (1LL << 31)) return false;
+  }
+  return true;
+}

@@ -251,6 +251,7 @@ class WeightBank:
 # convolution
 
 import os as _os
+WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
 BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (see OnirisConvArgs.big_tile)
 
 
@@ -325,6 +326,7 @@ def _wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_s
     a.nsplit_cap, a.taps_total, a.tap0, a.nsplit_out = pw.nsplit_cap, pw.taps, tap0, _p(pw.nsplit)
     a.B, a.T, a.H, a.W, a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = B, T, H, W, Cin, CinP, Cout, CoutP, taps
     a.xb_stride, a.x_T, a.coff, a.fill = xb_stride, x_T, coff, fill
+    a.pad_ = WGRAD_VARIANT
     return a
 
 
@@ -333,7 +335,11 @@ def _wgrad_launch_group(arglist):
     if KernelProfile.enabled:
         a0 = arglist[0]
         tile = 2 if (a0.Cin > 32 and a0.Cout > 32) else 1
-        key = f"conv_wgrad_kernel<TAPS={a0.taps},PW={_patch_w(a0.W)},CT={tile},IT={tile}>"
+        if (WGRAD_VARIANT >= 0 and tile == 2 and all(a.taps == 9 and a.W % 16 == 0 and a.H % 8 == 0 and a.fill in (0.0, 1.0)
+                                                      for a in arglist)):     # mirrors wgrad_glds_ok() in csrc
+            key = "conv_wgrad_glds_kernel<NG=2>"
+        else:
+            key = f"conv_wgrad_kernel<TAPS={a0.taps},PW={_patch_w(a0.W)},CT={tile},IT={tile}>"
         flops = sum(2.0 * a.B * a.T * a.H * a.W * a.Cout * a.Cin * a.taps for a in arglist)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -132,7 +132,8 @@ typedef struct OnirisWgradArgs {
   int32_t B, T, H, W, Cin, CinP, Cout, CoutP, taps;
   int32_t xb_stride, x_T, coff;   /* xframe(b,t) = x[b*xb_stride + t + coff] if 0 <= t+coff < x_T else fill       */
   float fill;
-  int32_t nsplit_cap, taps_total, tap0, pad_;
+  int32_t nsplit_cap, taps_total, tap0;
+  int32_t pad_;           /* variant: >= 0 LDS-DMA kernel where the shape allows it, < 0 register-staged kernel only        */
   int32_t* nsplit_out;    /* device int receiving the number of slabs written (= OnirisWeightDesc.nsplit)          */
 } OnirisWgradArgs;
 
