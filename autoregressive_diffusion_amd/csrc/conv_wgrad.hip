@@ -281,10 +281,10 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
     gx_tot += gx;
   }
   for (int g = ng; g <= WGRAD_MAXG; ++g) d.gstart[g] = gx_tot;      // empty groups
-  if constexpr (TAPS == 9 && PW == 16 && CT == 2 && IT == 2) {
+  if constexpr (TAPS == 9 && PW == 16) {
     if (a.pad_ >= 0 && wgrad_glds_ok(args, ng)) {                    // LDS-DMA variant (pad_ < 0 forces the register-staged one)
-      constexpr int NG = 2, LDSB = NG * 2 * (128 * 128 + P::HALO * 128);
-      auto kern = conv_wgrad_glds_kernel<NG>;
+      constexpr int NG = 2, LDSB = NG * 2 * (128 * CT * 64 + P::HALO * IT * 64);
+      auto kern = conv_wgrad_glds_kernel<CT, IT, NG>;
       static bool attr_done = false;
       if (!attr_done) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) {

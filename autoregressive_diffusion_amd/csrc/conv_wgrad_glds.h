@@ -16,12 +16,13 @@
 #pragma once
 #include "lds_dma.h"
 
-template <int NG>
+template <int CT, int IT, int NG>
 __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const WgradDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using P = Patch<16>;                                  // 8 x 16 pixel tiles of one frame (128 positions)
-  constexpr int TAPS = 9, ROWB = 128;
-  constexpr int DY_BYTES = 128 * ROWB, X_BYTES = P::HALO * ROWB, BUFB = DY_BYTES + X_BYTES;
+  constexpr int TAPS = 9, DROWB = CT * 64, XROWB = IT * 64, DPP = CT * 4, XPP = IT * 4;     // row bytes, 16-B pieces per row
+  constexpr int NTILE = CT * IT, NKS = 4 / NTILE;      // waves of a K-group sharing one 32x32 tile split its k-steps
+  constexpr int DY_BYTES = 128 * DROWB, X_BYTES = P::HALO * XROWB, BUFB = DY_BYTES + X_BYTES;
   static_assert(P::FT == 1 && P::HALO == 180, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -33,9 +34,10 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
   const int g_ntiles = d.ntiles[gsel], g_ntt = d.ntt[gsel];
   const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 8, gtid = tid & 255, wave4 = (tid >> 6) & 3;
   const int H = a.H, W = a.W, HWp = H * W, Cin = a.Cin, Cout = a.Cout;
-  const int ct = wave4 & 1, it = wave4 >> 1;
+  const int my_tile = wave4 % NTILE, my_ks = wave4 / NTILE;
+  const int ct = my_tile % CT, it = my_tile / CT;
   const int cib = blockIdx.y % d.ncib, cob = blockIdx.y / d.ncib;
-  const int co0 = cob * 64, ci0 = cib * 64;
+  const int co0 = cob * 32 * CT, ci0 = cib * 32 * IT;
   unsigned char* gbase = smem + kg * 2 * BUFB;          // this K-group's two buffers
 
   f32x16 acc[TAPS];
@@ -46,22 +48,22 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
 
   // ---- DMA descriptors
   constexpr int OOB = (int)0x80000000;
-  constexpr int DNI = 128 * 8 / 256, XNI = (P::HALO * 8 + 255) / 256;
+  constexpr int DNI = 128 * DPP / 256, XTOT = P::HALO * XPP, XNI = (XTOT + 255) / 256;
   int dvoff[DNI], xrel[XNI], xhyx[XNI];
 #pragma unroll
   for (int i = 0; i < DNI; ++i) {
     const int e = i * 256 + gtid;
-    const int row = e >> 3, gp = (e & 7) ^ (4 * ((row >> 1) & 1));
+    const int row = e / DPP, gp = (CT == 2) ? ((e % DPP) ^ (4 * ((row >> 1) & 1))) : (e % DPP);   // 128-B rows are swizzled
     const int co = co0 + gp * 8;
     dvoff[i] = (co < Cout) ? (((row >> 4) * W + (row & 15)) * Cout + co) * 2 : OOB;
   }
 #pragma unroll
   for (int i = 0; i < XNI; ++i) {
     const int e = i * 256 + gtid;
-    const int row = e >> 3, gp = (e & 7) ^ (4 * ((row >> 1) & 1));
+    const int row = e / XPP, gp = (IT == 2) ? ((e % XPP) ^ (4 * ((row >> 1) & 1))) : (e % XPP);
     const int hy = row / P::HW, hx = row % P::HW;
     const int ci = ci0 + gp * 8;
-    xhyx[i] = (e < P::HALO * 8 && ci < Cin) ? ((hy << 8) | hx) : -1;
+    xhyx[i] = (e < XTOT && ci < Cin) ? ((hy << 8) | hx) : -1;
     xrel[i] = (((hy - 1) * W + (hx - 1)) * Cin + ci) * 2;
   }
   const i32x4 rs_dy = make_rsrc(a.dy, a.B * a.T * HWp * Cout * 2);
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
     const int so_x = real ? ((tl.b * a.xb_stride + f) * HWp * Cin) * 2 : 0;
 #pragma unroll
     for (int i = 0; i < XNI; ++i) {
-      if (i * 256 + gtid < P::HALO * 8) {
+      if (i * 256 + gtid < XTOT) {
         const int hy = xhyx[i] >> 8, hx = xhyx[i] & 255;
         const bool ok = xhyx[i] >= 0 && (unsigned)(tl.y0 + hy - 1) < (unsigned)H && (unsigned)(tl.x0 + hx - 1) < (unsigned)W;
         if (real) dma16(rs_x, ok ? xrel[i] + origin : OOB, so_x, dst + DY_BYTES + i * 4096);
@@ -99,21 +101,25 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
   };
 
   // ---- fragment addresses (transposing reads: lane -> (row q, 8-byte column slot); see conv_wgrad.hip)
+  // k-step of this wave: ks = ksi*NKS + my_ks; the my_ks part of every row offset / swizzle parity lives in the bases
   const int hh = lane >> 5, q = (lane & 15) >> 2;
   const int cslot = (lane & 3) * 8 + 32 * ((lane >> 4) & 1);
-  const int dya = (8 * hh + q) * ROWB + ((ct * 64 + cslot) ^ (64 * ((q >> 1) & 1)));          // + ks*16*ROWB (+512: rows +4)
-  int xa[3][2];                                            // [kx][parity of (ks+ky)]
+  const int dsw = (CT == 2) ? 64 * ((q >> 1) & 1) : 0;
+  const int dya = (my_ks * 16 + 8 * hh + q) * DROWB + ((ct * 64 + cslot) ^ dsw);          // + ksi*NKS*16*DROWB (+4 rows)
+  int xa[3][2];                                            // [kx][parity of (ksi*NKS + ky)]
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
-    for (int par = 0; par < 2; ++par)
-      xa[kx][par] = DY_BYTES + (8 * hh + q + kx) * ROWB + ((it * 64 + cslot) ^ (64 * (par ^ (((q + kx) >> 1) & 1))));
+    for (int par = 0; par < 2; ++par) {
+      const int xsw = (IT == 2) ? 64 * ((par ^ my_ks ^ ((q + kx) >> 1)) & 1) : 0;
+      xa[kx][par] = DY_BYTES + (my_ks * P::HW + 8 * hh + q + kx) * XROWB + ((it * 64 + cslot) ^ xsw);
+    }
 
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
-  auto trf = [&](const unsigned char* p0) __attribute__((always_inline)) {       // rows r..r+3 and r+4..r+7
+  auto trf = [&](const unsigned char* p0, int rowb) __attribute__((always_inline)) {       // rows r..r+3 and r+4..r+7
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * ROWB));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 4 * rowb));
     s16x8 v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
     v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -145,10 +151,10 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
     }
     if (have) {
       const unsigned char* buf = gbase + bsel * BUFB;
-      constexpr int NSTEP = 8 * TAPS, LA = 3;
+      constexpr int NK = 8 / NKS, NSTEP = NK * TAPS, LA = 3;
       bf16x8 af[2], bfm[4];
-      auto ld_a = [&](int kb, int ks) __attribute__((always_inline)) {
-        bf16x8 v = trf(buf + dya + ks * 16 * ROWB);
+      auto ld_a = [&](int kb, int ksi) __attribute__((always_inline)) {
+        bf16x8 v = trf(buf + dya + ksi * NKS * 16 * DROWB, DROWB);
         if (a.scale) {                    // per-frame coefficient folded into dy (bf16 rounding, like a dy2 tensor)
 #pragma unroll
           for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) * sc);
@@ -156,8 +162,8 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
         af[kb] = v;
       };
       auto ld_b = [&](int fb, int st) __attribute__((always_inline)) {
-        const int ks = st / TAPS, tap = st % TAPS, ky = tap / 3, kx = tap % 3;
-        bfm[fb] = trf(buf + xa[kx][(ks + ky) & 1] + (ks + ky) * P::HW * ROWB);
+        const int ksi = st / TAPS, tap = st % TAPS, ky = tap / 3, kx = tap % 3;
+        bfm[fb] = trf(buf + xa[kx][(ksi * NKS + ky) & 1] + (ksi * NKS + ky) * P::HW * XROWB, XROWB);
       };
       ld_a(0, 0);
 #pragma unroll
@@ -183,24 +189,31 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
     bsel ^= 1;
   }
 
-  // ---- K-groups meet in LDS (tap by tap, 16 KB), then K-group 0 writes the workgroup's slab
+  // ---- the NKS*NG waves that worked on the same 32x32 tile meet in LDS (tap by tap), then one of them writes the slab
   if (bx == 0 && blockIdx.y == 0 && tid == 0 && a.nsplit_out) *a.nsplit_out = gxg;
-  if constexpr (NG > 1) {
-    float* red = (float*)smem;                             // [4 waves][16][64] floats
+  constexpr int NPART = NKS * NG;
+  if constexpr (NPART > 1) {
+    const int part = kg * NKS + my_ks;                      // 0 = the wave that keeps the sum
+    float* red = (float*)smem;                             // [NPART-1][NTILE][16][64] floats
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
       __syncthreads();
-      if (kg == 1) {
+      if (part > 0) {
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) red[(wave4 * 16 + rr) * 64 + lane] = acc[tap][rr];
+        for (int rr = 0; rr < 16; ++rr) red[(((part - 1) * NTILE + my_tile) * 16 + rr) * 64 + lane] = acc[tap][rr];
       }
       __syncthreads();
-      if (kg == 0) {
+      if (part == 0) {
 #pragma unroll
-        for (int rr = 0; rr < 16; ++rr) acc[tap][rr] += red[(wave4 * 16 + rr) * 64 + lane];
+        for (int rr = 0; rr < 16; ++rr) {
+          float v = acc[tap][rr];
+#pragma unroll
+          for (int w = 0; w < NPART - 1; ++w) v += red[((w * NTILE + my_tile) * 16 + rr) * 64 + lane];
+          acc[tap][rr] = v;
+        }
       }
     }
-    if (kg != 0) return;
+    if (part != 0) return;
   }
   const int cj = ci0 + it * 32 + (lane & 31);
   float* slab = a.dwp + (size_t)bx * a.taps_total * a.CoutP * a.CinP;
@@ -220,7 +233,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
 static inline bool wgrad_glds_ok(const OnirisWgradArgs* args, int ng) {
   for (int g = 0; g < ng; ++g) {
     const OnirisWgradArgs& a = args[g];
-    if (a.taps != 9 || a.W % 16 != 0 || a.H % 8 != 0 || !(a.Cin > 32 && a.Cout > 32)) return false;
+    if (a.taps != 9 || a.W % 16 != 0 || a.H % 8 != 0) return false;
     if (!(a.fill == 0.f || a.fill == 1.f)) return false;
     if ((long long)a.B * a.T * a.H * a.W * a.Cout * 2 >= (1LL << 31)) return false;
     if ((long long)a.B * a.xb_stride * a.H * a.W * a.Cin * 2 >= (1LL << 31)) return false;

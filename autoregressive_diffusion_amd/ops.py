@@ -335,9 +335,9 @@ def _wgrad_launch_group(arglist):
     if KernelProfile.enabled:
         a0 = arglist[0]
         tile = 2 if (a0.Cin > 32 and a0.Cout > 32) else 1
-        if (WGRAD_VARIANT >= 0 and tile == 2 and all(a.taps == 9 and a.W % 16 == 0 and a.H % 8 == 0 and a.fill in (0.0, 1.0)
-                                                      for a in arglist)):     # mirrors wgrad_glds_ok() in csrc
-            key = "conv_wgrad_glds_kernel<NG=2>"
+        if WGRAD_VARIANT >= 0 and all(a.taps == 9 and a.W % 16 == 0 and a.H % 8 == 0 and a.fill in (0.0, 1.0)
+                                      for a in arglist):                      # mirrors wgrad_glds_ok() in csrc
+            key = f"conv_wgrad_glds_kernel<CT={tile},IT={tile},NG=2>"
         else:
             key = f"conv_wgrad_kernel<TAPS={a0.taps},PW={_patch_w(a0.W)},CT={tile},IT={tile}>"
         flops = sum(2.0 * a.B * a.T * a.H * a.W * a.Cout * a.Cin * a.taps for a in arglist)
