@@ -57,7 +57,8 @@ class AttnArgs(C.Structure):
                 ("B", c_int32), ("heads", c_int32), ("Lq", c_int32), ("Lk", c_int32), ("C", c_int32),
                 ("mask_mode", c_int32), ("P", c_int32), ("T", c_int32), ("tab_block", c_int32),
                 ("dout", c_void_p), ("doutt", c_void_p), ("delta", c_void_p),
-                ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p)]
+                ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+                ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("pad_", c_int32)]
 
 
 EPI_NONE, EPI_EMB_SILU, EPI_MPSUM = 0, 1, 2

@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
   float* del_lds = lse_lds + 64;
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
-  const int kb = blockIdx.x, head = blockIdx.y, b = blockIdx.z;
+  const int nch = a.dkv_chunks > 1 ? a.dkv_chunks : 1;      // query-list chunks per key block (see OnirisAttnArgs)
+  const int kb = blockIdx.x / nch, chunk = blockIdx.x % nch, head = blockIdx.y, b = blockIdx.z;
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
   const int kw0 = kb * 128 + wave * 32;
   const int krow = kw0 + r;
@@ -387,16 +388,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
     if (tid < 64) { if (q0 + tid < Lq) rstat = lseg[q0 + tid]; }
     else if (tid < 128) { if (q0 + tid - 64 < Lq) rstat = delg[q0 + tid - 64]; }
   };
-  if (nsub > 0) load_sub(q_start(0));
+  const int i0 = (int)((long long)nsub * chunk / nch), i1 = (int)((long long)nsub * (chunk + 1) / nch);
+  if (i0 < i1) load_sub(q_start(i0));
 #pragma unroll 1
-  for (int idx = 0; idx < nsub; ++idx) {
+  for (int idx = i0; idx < i1; ++idx) {
     const int q0 = q_start(idx);
     __syncthreads();
     tile_store(Q_lds, rq, tid);
     tile_store(dO_lds, rdo, tid);
     if (tid < 128) lse_lds[tid] = rstat;            // lse_lds[0..63] | del_lds[0..63] are contiguous
     __syncthreads();
-    if (idx + 1 < nsub) load_sub(q_start(idx + 1));
+    if (idx + 1 < i1) load_sub(q_start(idx + 1));
     if (kw0 >= Lk || q0 >= Lq) continue;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -441,6 +443,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
     }
   }
   if (krow >= Lk) return;
+  if (nch > 1) {                                     // fp32 partial sums of this chunk (added by attn_dkv_reduce_kernel)
+    const size_t plane = (size_t)nch * a.B * Lk * C;
+    float* pk = a.dkv_part + (((size_t)chunk * a.B + b) * Lk + krow) * C + head * 64;
+    float* pv = pk + plane;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        *(float4*)(pk + dt * 32 + 8 * g + 4 * h) = make_float4(dk[dt][4 * g], dk[dt][4 * g + 1], dk[dt][4 * g + 2], dk[dt][4 * g + 3]);
+        *(float4*)(pv + dt * 32 + 8 * g + 4 * h) = make_float4(dv[dt][4 * g], dv[dt][4 * g + 1], dv[dt][4 * g + 2], dv[dt][4 * g + 3]);
+      }
+    return;
+  }
   bf16* dkg = (bf16*)a.dk + ((size_t)b * Lk + krow) * C + head * 64;
   bf16* dvg = (bf16*)a.dv + ((size_t)b * Lk + krow) * C + head * 64;
 #pragma unroll
@@ -453,6 +468,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
       *(bf16x4*)(dkg + dt * 32 + 8 * g + 4 * h) = o1;
       *(bf16x4*)(dvg + dt * 32 + 8 * g + 4 * h) = o2;
     }
+}
+
+// dk|dv = sum over the chunks (in chunk order) of the fp32 partials; 8 elements per thread
+__global__ void attn_dkv_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ dk, bf16* __restrict__ dv,
+                                       size_t n8, int nch) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 2 * n8) return;
+  const int which = i >= n8;
+  const size_t e = (which ? i - n8 : i) * 8;
+  const size_t n = n8 * 8;
+  const float* p = part + (size_t)which * nch * n + e;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int c = 0; c < nch; ++c) {
+    const float4 u = *(const float4*)(p + (size_t)c * n), w = *(const float4*)(p + (size_t)c * n + 4);
+    acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
+    acc[4] += w.x; acc[5] += w.y; acc[6] += w.z; acc[7] += w.w;
+  }
+  bf16x8 o;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k]);
+  *(bf16x8*)((which ? dv : dk) + e) = o;
 }
 
 // ================================================================================================================
@@ -683,9 +721,18 @@ extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t s
   if (rc) return rc;
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.dout && d.a.lse && d.a.delta && d.a.dk && d.a.dv,
                    "attn_bwd_dkv: null pointer");
-  const dim3 grid(cdiv(d.a.Lk, 128), d.a.heads, d.a.B);
+  const int nch = d.a.dkv_chunks > 1 ? d.a.dkv_chunks : 1;
+  ONIRIS_CHECK_ARG(nch == 1 || d.a.dkv_part, "attn_bwd_dkv: dkv_chunks > 1 needs the dkv_part scratch");
+  ONIRIS_CHECK_ARG(nch <= 64, "attn_bwd_dkv: at most 64 chunks");
+  const dim3 grid(cdiv(d.a.Lk, 128) * nch, d.a.heads, d.a.B);
   ATTN_DISPATCH(attn_bwd_dkv_kernel, grid);
   ONIRIS_LAUNCH_CHECK();
+  if (nch > 1) {
+    const size_t n8 = (size_t)d.a.B * d.a.Lk * d.a.C / 8;
+    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((2 * n8 + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)d.a.dkv_part, (bf16*)d.a.dk, (bf16*)d.a.dv, n8, nch);
+    ONIRIS_LAUNCH_CHECK();
+  }
   return ONIRIS_OK;
 }
 

@@ -251,6 +251,8 @@ class WeightBank:
 # convolution
 
 import os as _os
+ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
+ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
 WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
 BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (see OnirisConvArgs.big_tile)
 
@@ -769,6 +771,11 @@ class _AttentionFn(torch.autograd.Function):
         a = _attn_args(qr, kr, v, None, None, None, out, lse, ctx.tabs, Bq, heads, L, L, C, mask_mode, P, T)
         a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
         check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq")
+        # causal tables: split every key block's query list so that no workgroup walks more than ~32 sub-tiles
+        nch = max(1, min(ATTN_DKV_CHUNKS, L // ATTN_DKV_MIN_L)) if mask_mode == 2 else 1
+        if nch > 1:
+            part = torch.empty((2, nch, Bq, L, C), dtype=torch.float32, device=dev)
+            a.dkv_part, a.dkv_chunks = _p(part), nch
         check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv")
         if kind == "video":
             dqn, dkn = torch.empty_like(dq), torch.empty_like(dk)

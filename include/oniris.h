@@ -227,6 +227,13 @@ typedef struct OnirisAttnArgs {
   const void *dout, *doutt;               /* bf16 [B][Lq][C], [B][heads][64][Lq]                                  */
   const float* delta;                     /* [B][heads][Lq]                                                       */
   void *dq, *dk, *dv;                     /* bf16 [B][L][C]                                                       */
+  /* dK/dV load balancing (oniris_attn_bwd_dkv): with a causal table the first key blocks are attended by every later
+   * query, the last by almost none, and a key block is one workgroup -- the launch takes as long as its longest
+   * query list.  dkv_chunks > 1 splits every list into that many contiguous chunks, one workgroup each, which write
+   * fp32 partial sums to dkv_part [2 (dk|dv)][chunks][B][Lk][C]; a second kernel adds them in chunk order
+   * (deterministic, no atomics) and writes the bf16 dk, dv.  0 / 1: one workgroup per key block, no scratch.       */
+  float* dkv_part;
+  int32_t dkv_chunks, pad_;
 } OnirisAttnArgs;
 
 int oniris_attn_fwd(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);

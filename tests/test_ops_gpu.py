@@ -197,10 +197,14 @@ def _attn_ref(x0, wq, wp, B, m, training, just_2d=False, rope=True):
     return p
 
 
-@pytest.mark.parametrize("B,T,H,m", [(2, 4, 8, 1), (1, 8, 4, 2), (1, 2, 16, 1), (1, 16, 8, 2)])
-def test_video_attention_core_train(B, T, H, m):
+@pytest.mark.parametrize("B,T,H,m,chunks", [(2, 4, 8, 1, 1), (1, 8, 4, 2, 1), (1, 2, 16, 1, 1), (1, 16, 8, 2, 1),
+                                            # dK/dV with every key block's query list split over 3 workgroups
+                                            (1, 16, 8, 2, 3), (2, 4, 8, 1, 3)])
+def test_video_attention_core_train(B, T, H, m, chunks, monkeypatch):
     """qkv -> attention output (the part between the qkv conv and the proj conv), forward + backward."""
     from autoregressive_diffusion_amd import ops
+    monkeypatch.setattr(ops, "ATTN_DKV_CHUNKS", chunks)
+    monkeypatch.setattr(ops, "ATTN_DKV_MIN_L", 128)
     torch.manual_seed(5)
     C, P, N = 64 * m, H * H, B * 2 * T
     qkv0 = bfr(torch.randn(N, 3 * C, H, H))            # reference channel order (m c s)
