@@ -32,6 +32,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base0, const unsi
 }
 
 #include "conv_wgrad_glds.h"
+#include "wgrad1x1_glds.h"
 
 template <int TAPS, int PW, int CT, int IT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
@@ -339,7 +340,10 @@ extern "C" int oniris_conv_wgrad_group(const OnirisWgradArgs* args, int ngroups,
   ONIRIS_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv_wgrad: Cin/Cout must be multiples of 8");
   ONIRIS_CHECK_ARG(a.CoutP % 32 == 0 && a.CinP % 64 == 0 && a.CoutP >= a.Cout && a.CinP >= a.Cin,
                    "conv_wgrad: bad padded sizes");
-  if (a.taps == 1) return wgrad_pick_tile<1, 16>(args, ngroups, stream);
+  if (a.taps == 1) {
+    if (ngroups == 1 && a.pad_ >= 0 && wgrad1x1_glds_ok(a)) return launch_wgrad1x1_glds(a, stream);
+    return wgrad_pick_tile<1, 16>(args, ngroups, stream);
+  }
   const int W = a.W, H = a.H;
   if (W >= 16 && W % 16 == 0 && H % 8 == 0) return wgrad_pick_tile<9, 16>(args, ngroups, stream);
   if (W == 8 && H % 8 == 0) return wgrad_pick_tile<9, 8>(args, ngroups, stream);

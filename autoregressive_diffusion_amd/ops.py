@@ -100,6 +100,17 @@ class PackedWeight:
                  "wf", "wb", "dwp", "bank", "nsplit_cap", "nsplit", "group", "goff", "members")
 
 
+def _nsplit_cap(cin, cout, taps):
+    """Upper bound of the split-K columns (= slabs) the wgrad launchers use for a weight: launch_wgrad() in
+    csrc/conv_wgrad.hip (64x64 or 32x32 output tiles) and launch_wgrad1x1_glds() (128x128 tiles, 1x1 weights)."""
+    tile = 2 if (cin > 32 and cout > 32) else 1
+    gy = -(-roundup(cin, 16) // (32 * tile)) * -(-roundup(cout, 8) // (32 * tile))
+    cap = max(1, (256 if tile == 2 else 512) // gy)
+    if taps == 1 and cin >= 64 and cout >= 64:
+        cap = max(cap, 256 // (-(-cin // 128) * -(-cout // 128)))
+    return cap
+
+
 class WeightBank:
     def __init__(self):
         self.items = []
@@ -123,9 +134,7 @@ class WeightBank:
         w.wf = w.wb = w.dwp = w.nsplit = None
         w.group, w.goff, w.members = None, 0, None
         # split-K slabs of the weight-gradient kernel: same bound as launch_wgrad() in csrc/conv_wgrad.hip
-        tile = 2 if (w.cin > 32 and w.cout > 32) else 1
-        gy = -(-roundup(w.cin, 16) // (32 * tile)) * -(-roundup(w.cout, 8) // (32 * tile))
-        w.nsplit_cap = max(1, (256 if tile == 2 else 512) // gy)
+        w.nsplit_cap = _nsplit_cap(w.cin, w.cout, w.taps)
         w.bank = self
         self.items.append((w, need_dgrad))
         return w
@@ -150,9 +159,7 @@ class WeightBank:
         g.CinP, g.CoutPb = roundup(g.cin, 64), roundup(g.cin, 32)
         g.perm3, g.gain, g.param, g.bank = False, 1.0, members[0].param, self
         g.wf = g.wb = g.dwp = g.nsplit = None
-        tile = 2 if (g.cin > 32 and g.cout > 32) else 1
-        gy = -(-roundup(g.cin, 16) // (32 * tile)) * -(-g.cout // (32 * tile))
-        g.nsplit_cap = max(1, (256 if tile == 2 else 512) // gy)
+        g.nsplit_cap = _nsplit_cap(g.cin, g.cout, 1)
         self.groups.append(g)
         self._dev_table = None
         return g
@@ -340,6 +347,9 @@ def _wgrad_launch_group(arglist):
         if WGRAD_VARIANT >= 0 and all(a.taps == 9 and a.W % 16 == 0 and a.H % 8 == 0 and a.fill in (0.0, 1.0)
                                       for a in arglist):                      # mirrors wgrad_glds_ok() in csrc
             key = f"conv_wgrad_glds_kernel<CT={tile},IT={tile},NG=2>"
+        elif (WGRAD_VARIANT >= 0 and len(arglist) == 1 and a0.taps == 1 and a0.Cin >= 64 and a0.Cout >= 64 and not a0.scale
+              and a0.coff == 0):                                               # mirrors wgrad1x1_glds_ok()
+            key = "wgrad1x1_glds_kernel<NG=2>"
         else:
             key = f"conv_wgrad_kernel<TAPS={a0.taps},PW={_patch_w(a0.W)},CT={tile},IT={tile}>"
         flops = sum(2.0 * a.B * a.T * a.H * a.W * a.Cout * a.Cin * a.taps for a in arglist)
