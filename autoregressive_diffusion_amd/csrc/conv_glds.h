@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   using P = typename Cfg::P;
   constexpr int S = 2, TAPS = 9, CK = 32, KS = CK / 16;
   constexpr int BN = Cfg::BN, NTHR = Cfg::NTHR, AROWS = Cfg::AROWS, BUF = Cfg::BUF;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::LDS_BYTES];     // static: see conv_kernels.h
 
   const OnirisConvArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -405,15 +405,7 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
   }
   const long long nblk = ntiles < ncu ? ntiles : ncu;
   auto kern = conv_glds_kernel<NT, PW, NW, MT>;
-  static bool attr_done = false;   // per instantiation
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) != hipSuccess) {
-      oniris_set_error("conv_fwd: cannot raise dynamic LDS to %d", Cfg::LDS_BYTES);
-      return ONIRIS_ELAUNCH;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), Cfg::LDS_BYTES, stream, d);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -40,7 +40,8 @@ struct ConvCfg {
   static constexpr int AROWS = (TAPS == 9) ? S * P::HALO : S * NPOS;
   static constexpr int CROWS = (TAPS == 9) ? P::HALO : NPOS;
   static constexpr int WROWS = TAPS * BN;
-  static constexpr int LDS_BYTES = (AROWS + WROWS) * ROWB;
+  static constexpr int EPI_BYTES = NW * 32 * (BN * 2 + 16);        // wave-private transpose tiles of the epilogue
+  static constexpr int LDS_BYTES = ((AROWS + WROWS) * ROWB > EPI_BYTES) ? (AROWS + WROWS) * ROWB : EPI_BYTES;
 };
 
 template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW, int NW = 4>
@@ -49,7 +50,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
   using P = typename Cfg::P;
   constexpr int BN = Cfg::BN, ROWB = Cfg::ROWB, PARTS = Cfg::PARTS;
   constexpr int NTHR = Cfg::NTHR, NPOS = Cfg::NPOS;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // static LDS (up to 160 KB on gfx950): no hipFuncSetAttribute, and hipGraph kernel nodes carry the size themselves
+  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::LDS_BYTES];
   unsigned char* A_lds = smem;
   unsigned char* W_lds = smem + Cfg::AROWS * ROWB;
 
@@ -392,18 +394,7 @@ static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
   const long long nblk = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { oniris_set_error("conv_fwd: bad grid %lld", nblk); return ONIRIS_EINVAL; }
   auto kern = conv_fwd_kernel<S, TAPS, CK, NT, HAS_CTX, PW, NW>;
-  if (Cfg::LDS_BYTES > 64 * 1024) {
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES) !=
-          hipSuccess) {
-        oniris_set_error("conv_fwd: cannot raise dynamic LDS to %d", Cfg::LDS_BYTES);
-        return ONIRIS_ELAUNCH;
-      }
-      attr_done = true;
-    }
-  }
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), Cfg::LDS_BYTES, stream, d);
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

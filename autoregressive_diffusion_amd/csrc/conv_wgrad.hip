@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
   constexpr int DY_ROWB = (CT == 1) ? 64 : 192;
   constexpr int X_ROWB = (IT == 1) ? 64 : 192;
   constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[128 * DY_ROWB + XROWS * X_ROWB];
   unsigned char* dy_lds = smem;
   unsigned char* x_lds = smem + 128 * DY_ROWB;
 
@@ -284,35 +284,15 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
   for (int g = ng; g <= WGRAD_MAXG; ++g) d.gstart[g] = gx_tot;      // empty groups
   if constexpr (TAPS == 9 && PW == 16) {
     if (a.pad_ >= 0 && wgrad_glds_ok(args, ng)) {                    // LDS-DMA variant (pad_ < 0 forces the register-staged one)
-      constexpr int NG = 2, LDSB = NG * 2 * (128 * CT * 64 + P::HALO * IT * 64);
+      constexpr int NG = 2;
       auto kern = conv_wgrad_glds_kernel<CT, IT, NG>;
-      static bool attr_done = false;
-      if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) {
-          oniris_set_error("conv_wgrad: cannot raise dynamic LDS to %d", LDSB);
-          return ONIRIS_ELAUNCH;
-        }
-        attr_done = true;
-      }
-      hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256 * NG), LDSB, stream, d);
+      hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256 * NG), 0, stream, d);
       ONIRIS_LAUNCH_CHECK();
       return ONIRIS_OK;
     }
   }
-  constexpr int XROWS = (TAPS == 9) ? P::HALO : 128;
-  constexpr int LDS = 128 * ((CT == 1) ? 64 : 192) + XROWS * ((IT == 1) ? 64 : 192);
   auto kern = conv_wgrad_kernel<TAPS, PW, CT, IT>;
-  if (LDS > 64 * 1024) {
-    static bool attr_done = false;
-    if (!attr_done) {
-      if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) {
-        oniris_set_error("conv_wgrad: cannot raise dynamic LDS to %d", LDS);
-        return ONIRIS_ELAUNCH;
-      }
-      attr_done = true;
-    }
-  }
-  hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256), LDS, stream, d);
+  hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256), 0, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
   constexpr int NTILE = CT * IT, NKS = 4 / NTILE;      // waves of a K-group sharing one 32x32 tile split its k-steps
   constexpr int DY_BYTES = 128 * DROWB, X_BYTES = P::HALO * XROWB, BUFB = DY_BYTES + X_BYTES;
   static_assert(P::FT == 1 && P::HALO == 180, "tile geometry");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NG * 2 * BUFB];
 
   int gsel = 0;
   if ((int)blockIdx.x >= d.gstart[1]) gsel = 1;

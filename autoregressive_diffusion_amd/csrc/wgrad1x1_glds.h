@@ -13,7 +13,7 @@ template <int NG>
 __global__ __launch_bounds__(256 * NG, NG) void wgrad1x1_glds_kernel(const WgradDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KT = 64, ROWB = 256, TILEB = KT * ROWB, BUFB = 2 * TILEB;       // dy tile | x tile
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NG * 2 * BUFB];
   const OnirisWgradArgs& a = d.a[0];
   const int tid = threadIdx.x, lane = tid & 63, kg = tid >> 8, gtid = tid & 255, wave4 = (tid >> 6) & 3;
   const int wr = wave4 & 1, wc = wave4 >> 1;
@@ -156,7 +156,7 @@ static inline bool wgrad1x1_glds_ok(const OnirisWgradArgs& a) {
 }
 
 static int launch_wgrad1x1_glds(const OnirisWgradArgs& a, hipStream_t stream) {
-  constexpr int NG = 2, LDSB = NG * 2 * 2 * 64 * 256;
+  constexpr int NG = 2;
   WgradDev d;
   memset(&d, 0, sizeof(d));
   d.a[0] = a;
@@ -169,15 +169,7 @@ static int launch_wgrad1x1_glds(const OnirisWgradArgs& a, hipStream_t stream) {
   if (gx * NG > ntiles) gx = (ntiles + NG - 1) / NG;
   if (gx < 1) gx = 1;
   auto kern = wgrad1x1_glds_kernel<NG>;
-  static bool attr_done = false;
-  if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB) != hipSuccess) {
-      oniris_set_error("conv_wgrad: cannot raise dynamic LDS to %d", LDSB);
-      return ONIRIS_ELAUNCH;
-    }
-    attr_done = true;
-  }
-  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256 * NG), LDSB, stream, d);
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256 * NG), 0, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
