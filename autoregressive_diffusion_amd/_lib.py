@@ -25,7 +25,7 @@ class WeightDesc(C.Structure):
                 ("cout", c_int32), ("cin", c_int32), ("taps", c_int32), ("kt", c_int32),
                 ("CoutP", c_int32), ("CinP", c_int32), ("CoutPb", c_int32), ("CinPb", c_int32),
                 ("row_start", c_int32), ("perm3", c_int32), ("gain", c_float), ("nsplit_cap", c_int32),
-                ("nsplit", c_void_p)]
+                ("nsplit", c_void_p), ("tile_start", c_int32), ("pad_", c_int32)]
 
 
 class ConvArgs(C.Structure):
@@ -71,7 +71,7 @@ _SIGS = {
     "oniris_train_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_infer_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_mask_transpose": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
-    "oniris_weight_prep": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p]),
+    "oniris_weight_prep": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_weight_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "oniris_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,
                              c_float, c_int, c_float, c_void_p]),

@@ -23,6 +23,18 @@ __device__ __forceinline__ int perm_row(const OnirisWeightDesc* d, int co) {
   return (co % 3) * C + co / 3;
 }
 
+__device__ __forceinline__ const OnirisWeightDesc* find_desc_tile(const OnirisWeightDesc* d, int n, int tile) {
+  int lo = 0, hi = n - 1;                     // last desc with tile_start <= tile
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (d[mid].tile_start <= tile) lo = mid; else hi = mid - 1;
+  }
+  return d + lo;
+}
+
+// Pass 1: one workgroup per output-channel row: the two normalisations (training: the first is written back) and the
+// forward packing wf[tap][co][ci] -- written tap by tap with ci along the lanes (128-byte runs; the first version
+// walked the parameter order and wrote 2-byte elements with a stride of CoutP*CinP).
 __global__ __launch_bounds__(256) void weight_prep_kernel(const OnirisWeightDesc* descs, int ndesc, int training) {
   __shared__ float red[16];
   const int row = blockIdx.x;
@@ -45,23 +57,50 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const OnirisWeightDesc
     if (training) w[e] = v;
     ss2 += v * v;
   }
-  ss2 = block_sum(ss2, red);
-  const float scale = d->gain * rs / (W_EPS + sqrtf(ss2) * rs);   // second normalise * gain/sqrt(fan_in)
+  ss2 = block_sum(ss2, red);          // (its barriers also order the write-back before the re-reads below)
+  const float scale = d->gain * rs / (W_EPS + sqrtf(ss2) * rs) * (training ? 1.f : inv1);   // second normalise * gain/sqrt(fan_in)
 
   const int cop = perm_row(d, co);
-  bf16* wf = (bf16*)d->wf;
-  bf16* wb = (bf16*)d->wb;
-  const int per_t = d->kt > 0 ? taps / d->kt : taps;              // spatial taps per temporal slice (9 or 1)
-  for (int e = threadIdx.x; e < fan; e += 256) {
-    const int ci = e / taps, tap = e - ci * taps;
-    const float v = w[e] * (training ? 1.f : inv1) * scale;       // w already overwritten when training
-    const bf16 b = f2bf(v);
-    if (wf) wf[((size_t)tap * d->CoutP + cop) * d->CinP + ci] = b;
-    if (wb) {
-      const int j = tap / per_t, k = tap - j * per_t;
-      const int tb = j * per_t + (per_t - 1 - k);                 // spatially flipped tap, same temporal slice
-      wb[((size_t)tb * d->CoutPb + ci) * d->CinPb + cop] = b;
+  unsigned short* wf = (unsigned short*)d->wf;
+  if (!wf) return;
+  for (int q = threadIdx.x; q < fan; q += 256) {                  // q = tap*cin + ci: ci contiguous across the lanes
+    const int tap = q / cin, ci = q - tap * cin;
+    wf[((size_t)tap * d->CoutP + cop) * d->CinP + ci] = __builtin_bit_cast(unsigned short, f2bf(w[ci * taps + tap] * scale));
+  }
+}
+
+// Pass 2: the dgrad packing wb[flipped tap][ci][co] is the transpose of wf: one workgroup per (32 packed rows, tap),
+// 32 x 64 tiles through LDS, 128-byte reads and 64-byte writes.
+__global__ __launch_bounds__(256) void weight_wb_kernel(const OnirisWeightDesc* descs, int ndesc) {
+  __shared__ __attribute__((aligned(16))) unsigned short t_lds[32 * 72];
+  const OnirisWeightDesc* d = find_desc_tile(descs, ndesc, blockIdx.x);
+  const int tap = blockIdx.y;
+  if (tap >= d->taps || d->wb == nullptr || d->wf == nullptr) return;
+  const int cop0 = (blockIdx.x - d->tile_start) * 32;
+  const int nrow = min(32, d->cout - cop0);
+  const int per_t = d->kt > 0 ? d->taps / d->kt : d->taps;        // spatial taps per temporal slice (9 or 1)
+  const int j = tap / per_t, k = tap - j * per_t;
+  const int tb = j * per_t + (per_t - 1 - k);                     // spatially flipped tap, same temporal slice
+  const unsigned short* wf = (const unsigned short*)d->wf + ((size_t)tap * d->CoutP + cop0) * d->CinP;
+  unsigned short* wb = (unsigned short*)d->wb + (size_t)tb * d->CoutPb * d->CinPb + cop0;
+  const int tid = threadIdx.x;
+  const int lr = tid >> 3, lp = tid & 7;                          // load: 32 rows x 8 parts of 8 ci
+  const int sc_ = tid >> 2, sp = tid & 3;                         // store: 64 ci x 4 parts of 8 rows
+  for (int c0 = 0; c0 < d->cin; c0 += 64) {
+    u32x4 v = u32x4{0u, 0u, 0u, 0u};
+    if (lr < nrow && c0 + lp * 8 < d->CinP) v = *(const u32x4*)(wf + (size_t)lr * d->CinP + c0 + lp * 8);
+    *(u32x4*)(t_lds + lr * 72 + lp * 8) = v;
+    __syncthreads();
+    if (c0 + sc_ < d->cin) {
+      unsigned short o[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) o[r] = t_lds[(sp * 8 + r) * 72 + sc_];
+      unsigned short* dst = wb + (size_t)(c0 + sc_) * d->CinPb + sp * 8;
+      if (sp * 8 + 7 < nrow) *(u32x4*)dst = *(const u32x4*)o;
+      else
+        for (int r = 0; r < 8; ++r) if (sp * 8 + r < nrow) dst[r] = o[r];
     }
+    __syncthreads();
   }
 }
 
@@ -115,11 +154,13 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
   }
 }
 
-extern "C" int oniris_weight_prep(const OnirisWeightDesc* descs_dev, int ndesc, int total_rows, int training,
-                                  oniris_stream_t stream_) {
+extern "C" int oniris_weight_prep(const OnirisWeightDesc* descs_dev, int ndesc, int total_rows, int total_tiles,
+                                  int training, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ONIRIS_CHECK_ARG(descs_dev && ndesc > 0 && total_rows > 0, "weight_prep: bad arguments");
+  ONIRIS_CHECK_ARG(descs_dev && ndesc > 0 && total_rows > 0 && total_tiles > 0, "weight_prep: bad arguments");
   hipLaunchKernelGGL(weight_prep_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc, training);
+  ONIRIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(weight_wb_kernel, dim3(total_tiles, 18), dim3(256), 0, stream, descs_dev, ndesc);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -170,7 +170,7 @@ class WeightBank:
 
     def _build(self, device):
         descs = (_lib.WeightDesc * len(self.items))()
-        row = 0
+        row = tile = 0
         nslots = len(self.items) + len(self.groups)
         if getattr(self, "nsplit_all", None) is None or self.nsplit_all.device != device or self.nsplit_all.numel() != nslots:
             self.nsplit_all = torch.zeros(nslots, dtype=torch.int32, device=device)
@@ -211,8 +211,10 @@ class WeightBank:
                 d.CoutP = d.CinPb = w.group.cout
             d.row_start, d.perm3, d.gain = row, int(w.perm3), w.gain
             d.nsplit_cap, d.nsplit = w.nsplit_cap, w.nsplit.data_ptr()
+            d.tile_start = tile
             row += w.cout
-        self.total_rows = row
+            tile += -(-w.cout // 32)
+        self.total_rows, self.total_tiles = row, tile
         raw = np.frombuffer(bytes(descs), dtype=np.uint8).copy()
         self._dev_table = torch.from_numpy(raw).to(device)
         self._sig = self._signature()
@@ -229,7 +231,8 @@ class WeightBank:
     def prepare(self, training):
         """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
         self._ensure()
-        check(lib.oniris_weight_prep(_p(self._dev_table), len(self.items), self.total_rows, int(training), _stream()),
+        check(lib.oniris_weight_prep(_p(self._dev_table), len(self.items), self.total_rows, self.total_tiles, int(training),
+                                     _stream()),
               "weight_prep")
 
     def backward(self):

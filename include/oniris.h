@@ -65,9 +65,15 @@ typedef struct OnirisWeightDesc {
   int32_t nsplit_cap;              /* slabs allocated behind dwp                                                 */
   int32_t* nsplit;                 /* device int: slabs written since the last oniris_weight_prep (which resets  *
                                     * it to 0); set by oniris_conv_wgrad, read by oniris_weight_bwd              */
+  int32_t tile_start;              /* prefix sum of ceil(cout/32) over the table (oniris_weight_prep: one         *
+                                    * workgroup per 32 packed rows)                                               */
+  int32_t pad_;
 } OnirisWeightDesc;
 
-int oniris_weight_prep(const OnirisWeightDesc* descs, int ndesc, int total_rows, int training, oniris_stream_t stream);
+/* total_rows = sum of cout, total_tiles = sum of ceil(cout/32) over the table (two kernels: normalise + forward
+ * packing per row, then the transposed dgrad packing per 32-row tile)                                             */
+int oniris_weight_prep(const OnirisWeightDesc* descs, int ndesc, int total_rows, int total_tiles, int training,
+                       oniris_stream_t stream);
 int oniris_weight_bwd(const OnirisWeightDesc* descs, int ndesc, int total_rows, oniris_stream_t stream);
 
 /* Fused AdamW over flat fp32 buffers (the optimizer step of gym_train.py:105-106 / cs_train.py:117-118).       */
