@@ -17,7 +17,12 @@ from torch import nn
 class FlatParams:
     """Re-homes every trainable parameter of `module` (and its .grad) as a view into one flat fp32 buffer."""
 
-    def __init__(self, module):
+    def __init__(self, module, lazy_small=False):
+        """lazy_small: gradients of the parameters autograd itself accumulates (everything except the conv weights,
+        whose .grad the HIP weight_bwd kernel writes through a raw pointer) are NOT accumulated into their flat slice
+        one tiny `add_` kernel per parameter (~190 launches per step for the gym net); their .grad is None during
+        backward, so autograd just hands the tensor over, and `gather()` adds all of them into the flat buffer with one
+        multi-tensor call (called by OnirisDDP at the end of backward and by FlatAdamW.step)."""
         self.params = [p for p in module.parameters() if p.requires_grad]
         assert self.params, "no trainable parameters"
         dev, dt = self.params[0].device, self.params[0].dtype
@@ -36,15 +41,37 @@ class FlatParams:
                 v.copy_(p.data)
                 p.data = v
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+        self._lazy = []
+        if lazy_small:
+            from .edm2.conv import NormalizedWeight
+            kernel_owned = {id(m.weight) for m in module.modules() if isinstance(m, NormalizedWeight)}
+            self._lazy = [(p, p.grad) for p in self.params if id(p) not in kernel_owned]
+            for p, _ in self._lazy:
+                p.grad = None
 
     def zero_grad(self):
         self.grad.zero_()
+        for p, _ in self._lazy:
+            p.grad = None
+
+    def gather(self):
+        """Add the autograd-owned gradients into their flat slices (one multi-tensor add) and re-alias .grad."""
+        src, dst = [], []
+        for p, view in self._lazy:
+            g = p.grad
+            if g is not None and g.data_ptr() != view.data_ptr():
+                src.append(g.reshape(view.shape)); dst.append(view)
+            p.grad = view
+        if src:
+            with torch.no_grad():
+                torch._foreach_add_(dst, src)
 
     def check(self):
         """True while every parameter still aliases the flat buffers (a .to()/deepcopy breaks the aliasing)."""
         base = self.flat.data_ptr()
-        return all(p.data_ptr() == base + 4 * o and p.grad is not None and
-                   p.grad.data_ptr() == self.grad.data_ptr() + 4 * o for p, o in zip(self.params, self.offsets))
+        lazy = {id(p) for p, _ in self._lazy}
+        return all(p.data_ptr() == base + 4 * o and (id(p) in lazy and p.grad is None or p.grad is not None and
+                   p.grad.data_ptr() == self.grad.data_ptr() + 4 * o) for p, o in zip(self.params, self.offsets))
 
 
 class OnirisDDP(nn.Module):
@@ -91,6 +118,7 @@ class OnirisDDP(nn.Module):
         bank = self.module.__dict__.get("_oniris_bank")
         if bank is not None:
             bank._finish()                               # weight gradients must be final before the exchange
+        self.flat.gather()
         self.allreduce_grads()
 
     def allreduce_grads(self):
@@ -132,6 +160,7 @@ class FlatAdamW:
     def step(self, grad_scale=1.0):
         self.steps += 1
         f = self.flat
+        f.gather()
         if f.flat.is_cuda:
             from . import ops
             ops.adamw_(f.flat, f.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,

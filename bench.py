@@ -148,7 +148,7 @@ def main():
         if hasattr(m, "emb_gain"):
             torch.nn.init.constant_(m.emb_gain, 0.3)
     torch.nn.init.constant_(unet.out_gain, 1.0)
-    flat = FlatParams(unet)
+    flat = FlatParams(unet, lazy_small=True)
     model = OnirisDDP(unet, flat=flat) if world > 1 else unet
     net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
     opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
@@ -212,6 +212,7 @@ def main():
             print("timed", i, float(last.item()), file=sys.stderr)
         if dbg == "3":
             hist.append(last.detach().clone())
+    t_enq = time.perf_counter() - t0                               # host time to ENQUEUE the K steps (before the fence)
     fence()
     if dbg == "3":
         print("timed losses", [round(float(h.item()), 4) for h in hist], file=sys.stderr)
@@ -221,6 +222,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(last.item())
+    if os.environ.get("ONIRIS_HOST_TIMING"):
+        print(f"host enqueue {t_enq / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr)
 
     # per-mode step times (one 3-D and one 2-D step, timed separately, not part of `value`)
     per_mode = {}
