@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m, mx);
     const float m_use = (m_new == NEG_BIG) ? 0.f : m_new;
-    const float alpha = exp2f(m - m_use);
+    const float alpha = __builtin_amdgcn_exp2f(m - m_use);
     float rs = 0.f;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
-        const float p = exp2f(s[kt][rr] - m_use);
+        const float p = __builtin_amdgcn_exp2f(s[kt][rr] - m_use);
         s[kt][rr] = p;
         rs += p;
       }
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
       }
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
-        float p = exp2f(s[rr] * SCALE_LOG2 - lse);
+        float p = __builtin_amdgcn_exp2f(s[rr] * SCALE_LOG2 - lse);
         if (cls == 1) {
           const int key = key0 + kt * 32 + mfma_row(rr, lane);
           if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int ql = qt * 32 + mfma_row(rr, lane);
-        float p = exp2f(s[rr] * SCALE_LOG2 - lse_lds[ql]);
+        float p = __builtin_amdgcn_exp2f(s[rr] * SCALE_LOG2 - lse_lds[ql]);
         if (cls == 1) {
           const int qtok = q0 + ql;
           if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
