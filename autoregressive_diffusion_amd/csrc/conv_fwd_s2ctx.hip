@@ -5,11 +5,15 @@
 // (conv_glds.h: 8 waves, 16x16-pixel workgroup tiles) wherever the shape allows it.
 template <int NT>
 static int glds_pick(const OnirisConvArgs& a, hipStream_t st) {
+  if (NT == 2 && a.big_tile == 5 && a.H % 8 == 0) return launch_conv_glds<1, 16, 8, 1, 2>(a, st);   // A/B: 16x8 tiles
   return launch_conv_glds<NT, 16, 8, 1>(a, st);
 }
 
 int conv_dispatch_s2ctx(const OnirisConvArgs& a, hipStream_t st) {
   if (a.big_tile >= 3 && conv_glds_ok(a, 16, 16, (a.CoutP % 64 == 0) ? 64 : 32))
     return (a.CoutP % 64 == 0) ? glds_pick<2>(a, st) : glds_pick<1>(a, st);
+  // 8x8 images: two whole frames per workgroup, 4 position waves x 2 channel waves (32 channels each)
+  if (a.big_tile >= 3 && a.W == 8 && a.H == 8 && a.CoutP % 64 == 0 && conv_glds_ok(a, 8, 8, 64))
+    return launch_conv_glds<1, 8, 8, 1, 2>(a, st);
   return conv3x3_pick<2, true>(a, st);
 }

@@ -24,32 +24,40 @@
 
 #include "lds_dma.h"
 
-template <int NT, int PW, int NW, int MT>
+// NT: 32-channel tiles per wave; WC: channel groups of waves (a workgroup covers 32*NT*WC channels and
+// 32*(NW/WC)*MT positions).  PW = 16: one 16x16 tile of one frame; PW = 8: two whole 8x8 frames, and the halo rows are
+// 12 entries wide (2 unused) so that the patch rows py and py+2 a 16-lane read group takes are 24 = 8 (mod 16) rows apart.
+template <int NT, int PW, int NW, int MT, int WC = 1>
 struct GldsCfg {
-  static constexpr int NPOS = 32 * NW * MT, NTHR = 64 * NW, BN = 32 * NT;
+  static constexpr int NWP = NW / WC;
+  static constexpr int NPOS = 32 * NWP * MT, NTHR = 64 * NW, BN = 32 * NT * WC;
   using P = Patch<PW, NPOS>;
-  static constexpr int SROWS = (P::HALO + 15) / 16 * 16;      // slot stride in rows: a multiple of 16 keeps the swizzle
-  static constexpr int AROWS = 2 * SROWS, CROWS = P::HALO, WROWS = 9 * BN;   // phase of slot 1 equal to slot 0's
+  static constexpr int HW = (PW == 8) ? 12 : PW + 2, HH = P::PH + 2, FT = P::FT;
+  static constexpr int HALO = FT * HH * HW;
+  static constexpr int SROWS = (HALO + 15) / 16 * 16;         // slot stride in rows: a multiple of 16 keeps the swizzle
+  static constexpr int AROWS = 2 * SROWS, CROWS = HALO, WROWS = 9 * BN;      // phase of slot 1 equal to slot 0's
   static constexpr int BUF = (AROWS + WROWS) * 64;
-  static constexpr int EROW = BN * 2 + 16;
+  static constexpr int EROW = NT * 32 * 2 + 16;              // a wave stages its own 32 x (32*NT) bf16 tile
   static constexpr int EPI = NW * 32 * EROW;
+  static_assert(PW == 16 || PW == 8, "tile geometries of the LDS-DMA kernel");
   static constexpr int LDS_BYTES = (2 * BUF > EPI) ? 2 * BUF : EPI;
   static_assert(LDS_BYTES <= 160 * 1024, "two staging buffers must fit the 160 KB LDS");
-  static_assert(2 * BN * 4 + EPI <= BUF, "the epilogue stages through ONE of the two buffers");
-  static_assert((NW * 2 * P::HW) % 16 == 0 || MT == 1, "position tiles of a wave must be 16-row aligned apart");
+  static_assert(2 * FT * BN * 4 + EPI <= BUF, "the epilogue stages through ONE of the two buffers");
+  static_assert((NWP * 2 * HW) % 16 == 0 || MT == 1, "position tiles of a wave must be 16-row aligned apart");
 };
 
-template <int NT, int PW, int NW, int MT>
+template <int NT, int PW, int NW, int MT, int WC = 1>
 __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(const ConvDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (the stub needs no body)
-  using Cfg = GldsCfg<NT, PW, NW, MT>;
+  using Cfg = GldsCfg<NT, PW, NW, MT, WC>;
   using P = typename Cfg::P;
-  constexpr int S = 2, TAPS = 9, CK = 32, KS = CK / 16;
+  constexpr int S = 2, TAPS = 9, CK = 32, KS = CK / 16, HW_ = Cfg::HW, HH_ = Cfg::HH, FT = Cfg::FT, NWP = Cfg::NWP;
   constexpr int BN = Cfg::BN, NTHR = Cfg::NTHR, AROWS = Cfg::AROWS, BUF = Cfg::BUF;
   __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::LDS_BYTES];     // static: see conv_kernels.h
 
   const OnirisConvArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int wp = wave % NWP, wc = wave / NWP;             // position group / channel group of this wave
   const int H = a.H, W = a.W, T = a.T, Cin = a.Cin, HWp = a.H * a.W;
 
   // ---- this workgroup's run of tiles.  Workgroup ids go round-robin over the 8 XCDs; XCD k owns the CONTIGUOUS tile
@@ -84,20 +92,23 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     const bool ga = (r < 4) || (r >= 12 && r < 16) || (r >= 20 && r < 28);
     const int k = ga ? ((r < 4) ? r : (r < 16) ? r - 8 : r - 12) : ((r < 12) ? r - 4 : (r < 20) ? r - 8 : r - 16);
     pr = (ga ? 0 : 16) + k;
+  } else {                                                // PW == 8: a read group takes patch rows (0,2) resp. (1,3)
+    const bool ga = (r < 4) || (r >= 12 && r < 16) || (r >= 20 && r < 28);
+    const int k = ga ? ((r < 4) ? r : (r < 16) ? r - 8 : r - 12) : ((r < 12) ? r - 4 : (r < 20) ? r - 8 : r - 16);
+    pr = ((k >> 3) * 2 + (ga ? 0 : 1)) * 8 + (k & 7);
   }
   int arow[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
-    const int p = (wave + NW * m) * 32 + pr;     // tile m of a wave sits NW*32 positions (a multiple of 16 halo rows) on
+    const int p = (wp + NWP * m) * 32 + pr;      // tile m of a wave sits NWP*32 positions (a multiple of 16 halo rows) on
     const int ft = p / (P::PH * P::PW), py = (p / P::PW) % P::PH, px = p % P::PW;
-    arow[m] = (ft * P::HH + py) * P::HW + px;
+    arow[m] = (ft * HH_ + py) * HW_ + px;
   }
 
   // ---- DMA descriptors (one 16-byte piece per lane per instruction; piece e of a region lands at region + 16*e).
   // All per-lane byte offsets are phase-invariant (`buffer_load ... offen lds`: the phase / chunk / frame part of the
   // address is the uniform soffset), and out-of-image halo pixels use an offset beyond num_records: the buffer range
   // check then writes zeros, so spatial padding costs neither branches nor address math.
-  static_assert(P::FT == 1, "one frame per workgroup tile (the padded-frame test below is uniform)");
   constexpr int TOTA = AROWS * 4, TOTC = Cfg::CROWS * 4, TOTW = Cfg::WROWS * 4;
   constexpr int NIA = (TOTA + NTHR - 1) / NTHR, NIC = (TOTC + NTHR - 1) / NTHR, NIW = (TOTW + NTHR - 1) / NTHR;
   constexpr int OOB = (int)0x80000000;
@@ -111,10 +122,12 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       const int e = i * NTHR + tid_;
       const int row = e >> 2, gp = (e & 3) ^ ((row >> 2) & 3);
       const int s = row / Cfg::SROWS, rem = row % Cfg::SROWS;
-      const int y = t.y0 + rem / P::HW - 1, x = t.x0 + rem % P::HW - 1;
-      adesc[i] = OOB;
-      if (e < TOTA && rem < P::HALO && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
-        adesc[i] = (s * T * frame_elems + (y * W + x) * Cin + gp * 8) * 2;
+      const int f_ = rem / (HH_ * HW_), hr = rem % (HH_ * HW_);          // frame inside the tile, halo pixel
+      const int y = t.y0 + hr / HW_ - 1, x = t.x0 + hr % HW_ - 1;
+      adesc[i] = OOB;                                                    // (for FT > 1 the frame is kept in bits 28..30
+      if (e < TOTA && rem < Cfg::HALO && hr % HW_ < P::PW + 2 && t.t0 + f_ < T && (unsigned)y < (unsigned)H &&
+          (unsigned)x < (unsigned)W)                                     //  of nothing: it is re-derived where needed)
+        adesc[i] = ((s * T + f_) * frame_elems + (y * W + x) * Cin + gp * 8) * 2;
     }
   };
 #pragma unroll
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 #pragma unroll
       for (int i = 0; i < NIA; ++i)
         if ((i * NW + wave) * 64 + lane < TOTA) dma16(rs_x, adesc[i], so, dst + i * NW * 1024);
-    } else {
+    } else if constexpr (FT == 1) {
       const int f = t.t0 + ((ph == 1) ? a.coff0 : a.coff1);
       if (f >= 0 && f < a.ctx_T) {
         const bf16* cb_ = (const bf16*)a.ctx + (size_t)t.b * a.ctx_bstride * frame_elems;
@@ -153,6 +166,20 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 #pragma unroll
         for (int i = 0; i < NIC; ++i)
           if ((i * NW + wave) * 64 + lane < TOTC) dma16(rs_f, (adesc[i] < 0) ? OOB : fillsel, 0, dst + i * NW * 1024);
+      }
+    } else {                                                 // several frames per tile: real / padded is per row
+      const int coff = (ph == 1) ? a.coff0 : a.coff1;
+      const bf16* cb_ = (const bf16*)a.ctx + (size_t)t.b * a.ctx_bstride * frame_elems;
+      const i32x4 rs_c = make_rsrc(cb_, a.ctx_T * frame_elems * 2);
+      const int shift = (t.t0 + coff) * frame_elems * 2;     // may be negative; voffset + shift >= 0 on the real rows
+#pragma unroll
+      for (int i = 0; i < NIC; ++i) {
+        const int e = (i * NW + wave) * 64 + lane;
+        if (e < TOTC) {
+          const int f = t.t0 + coff + ((e >> 2) % Cfg::SROWS) / (HH_ * HW_);
+          if (f >= 0 && f < a.ctx_T) dma16(rs_c, (adesc[i] < 0) ? OOB : adesc[i] + shift, c0 * 2, dst + i * NW * 1024);
+          else dma16(rs_f, (adesc[i] < 0) ? OOB : fillsel, 0, dst + i * NW * 1024);
+        }
       }
     }
     const int sw = ((t.co0 * a.CinP + c0) + ((ph == 2) ? TAPS * a.CoutP * a.CinP : 0)) * 2;
@@ -168,12 +195,12 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   };
 
   // ---- fragment addresses (k-step 0; k-step 1 is the same address ^ 32)
-  const int wa0 = r * 64 + ((h ^ ((r >> 2) & 3)) << 4) + AROWS * 64;
+  const int wa0 = (wc * NT * 32 + r) * 64 + ((h ^ ((r >> 2) & 3)) << 4) + AROWS * 64;
   // slot 1 and the wave's further position tiles are whole multiples of 16 rows away: same swizzle, constant offset
   int xa0[TAPS];
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap) {
-    const int R = arow[0] + (tap / 3) * P::HW + (tap % 3);
+    const int R = arow[0] + (tap / 3) * HW_ + (tap % 3);
     xa0[tap] = R * 64 + ((h ^ ((R >> 2) & 3)) << 4);
   }
 
@@ -195,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       for (int s = 0; s < NX; ++s)
 #pragma unroll
         for (int m = 0; m < MT; ++m)
-          xf[fb][s][m] = *(const bf16x8*)(base + ((xa0[tap] ^ (ks * 32)) + (s * Cfg::SROWS + m * (NW * 2 * P::HW)) * 64));
+          xf[fb][s][m] = *(const bf16x8*)(base + ((xa0[tap] ^ (ks * 32)) + (s * Cfg::SROWS + m * (NWP * 2 * HW_)) * 64));
     };
     ld(0, 0);
 #pragma unroll
@@ -219,7 +246,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   };
 
   constexpr int EROW = Cfg::EROW;
-  constexpr int ESC = 2 * BN * 4;                       // emb-scale vectors of the two slots, in front of the staging tiles
+  constexpr int ESC = 2 * FT * BN * 4;                  // emb-scale vectors [slot][frame][BN], in front of the staging tiles
   const int nphase = (Cin / CK) * 3;
   Tile cur = decode(tl);
   set_adesc(cur);
@@ -237,13 +264,17 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
         for (int i = 0; i < 16; ++i) { acc[0][m][n][i] = 0.f; acc[1][m][n][i] = 0.f; accc[m][n][i] = 0.f; }
       }
     float esc_v = 0.f;
-    const int n0 = (cur.b * S) * T + cur.t0, n1 = n0 + T;        // frame index of slot 0 / slot 1 (uniform: FT == 1)
-    // gate coefficients: fetched now (nothing in flight) so that no wait on them can fall behind a later LDS-DMA
+    // gate coefficients of this lane's frame: fetched now (nothing in flight) so that no wait on them can fall behind
+    // a later LDS-DMA
+    const int lft = ((wp * 32 + pr) / (P::PH * P::PW)) % FT;     // frame of this lane's position inside the tile (MT == 1 when FT > 1)
+    const bool lvalid = cur.t0 + lft < T;
+    const int n0 = (cur.b * S) * T + (lvalid ? cur.t0 + lft : 0), n1 = n0 + T;       // slot 0 / slot 1
     const float cown0 = a.coef_own ? a.coef_own[n0] : 1.f, cown1 = a.coef_own ? a.coef_own[n1] : 1.f;
     const float cctx0 = a.coef_ctx ? a.coef_ctx[n0] : 1.f, cctx1 = a.coef_ctx ? a.coef_ctx[n1] : 1.f;
-    if (a.epi == ONIRIS_EPI_EMB_SILU && tid < 2 * BN) {          // emb-scale vector element of this thread (parked in LDS later)
-      const int co = cur.co0 + tid % BN;
-      if (co < a.Cout) esc_v = ((const float*)a.escale)[(size_t)((tid / BN) ? n1 : n0) * a.Cout + co];
+    if (a.epi == ONIRIS_EPI_EMB_SILU && tid < 2 * FT * BN) {     // emb-scale element [slot][frame][co] of this thread (parked in LDS later)
+      const int co = cur.co0 + tid % BN, f_ = (tid / BN) % FT, s_ = tid / (FT * BN);
+      if (co < a.Cout && cur.t0 + f_ < T)
+        esc_v = ((const float*)a.escale)[(size_t)((cur.b * S + s_) * T + cur.t0 + f_) * a.Cout + co];
     }
 #pragma unroll 1
     for (int itp = 0; itp < nphase; ++itp) {
@@ -264,7 +295,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     // first use of an ordinary load issued while DMA is in flight): gate coefficients and emb-scale were fetched at
     // the top of the tile; the emb-scale vectors are parked in LDS now
     if (a.epi == ONIRIS_EPI_EMB_SILU) {
-      if (tid < 2 * BN) *(float*)(stg + tid * 4) = esc_v;
+      if (tid < 2 * FT * BN) *(float*)(stg + tid * 4) = esc_v;
       __syncthreads();
     }
     asm volatile("" ::"v"(cown0), "v"(cown1), "v"(cctx0), "v"(cctx1));   // consume here: nothing is in flight at this point
@@ -283,18 +314,20 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     bf16* og = (bf16*)a.out;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-      const int ptile = (wave + NW * m) * 32;             // first position of this tile inside the workgroup tile
+      const int ptile = (wp + NWP * m) * 32;              // first position of this tile inside the workgroup tile
+      const int cow = cur.co0 + wc * NT * 32;              // first channel of this wave
       auto flush = [&](bf16* dst, size_t blk) __attribute__((always_inline)) {
-        constexpr int PO = BN / 8;
+        constexpr int PO = NT * 32 / 8;
 #pragma unroll
         for (int it = 0; it < 32 * PO / 64; ++it) {
           const int id = it * 64 + lane;
           const int row = id / PO, part = id % PO;
           const int q = ptile + row;
-          const int yy = (q / P::PW) % P::PH, xx = q % P::PW;
-          const size_t px_ = (size_t)cur.t0 * HWp + (cur.y0 + yy) * W + (cur.x0 + xx);
-          const int co = cur.co0 + part * 8;
-          if (co < a.Cout) *(uint4*)(dst + (blk + px_) * a.Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
+          const int f_ = q / (P::PH * P::PW), yy = (q / P::PW) % P::PH, xx = q % P::PW;
+          const size_t px_ = (size_t)(cur.t0 + f_) * HWp + (cur.y0 + yy) * W + (cur.x0 + xx);
+          const int co = cow + part * 8;
+          if (co < a.Cout && cur.t0 + f_ < T)
+            *(uint4*)(dst + (blk + px_) * a.Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
         }
       };
 #pragma unroll
@@ -324,17 +357,17 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
             flush((bf16*)a.out2, blk);
           }
           const int p = ptile + pr;
-          const size_t obase = (blk + (size_t)cur.t0 * HWp + (cur.y0 + (p / P::PW) % P::PH) * W + cur.x0 + p % P::PW) * a.Cout;
+          const size_t obase = (blk + (size_t)(cur.t0 + lft) * HWp + (cur.y0 + (p / P::PW) % P::PH) * W + cur.x0 + p % P::PW) * a.Cout;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
             raw(nt, v);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const int co = cur.co0 + nt * 32 + 8 * g + 4 * h;
+              const int co = cow + nt * 32 + 8 * g + 4 * h;
               bf16x4 rv;
 #pragma unroll
               for (int k = 0; k < 4; ++k) rv[k] = f2bf(0.f);
-              if (co < a.Cout) rv = *(const bf16x4*)((const bf16*)a.res + obase + co);
+              if (co < a.Cout && lvalid) rv = *(const bf16x4*)((const bf16*)a.res + obase + co);
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 float o = a.ta * bf2f(rv[k]) + a.tb * v[4 * g + k];
@@ -355,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
               raw(nt, v);
 #pragma unroll
               for (int g = 0; g < 4; ++g) {
-                const float4 ev = *(const float4*)(stg + (s * BN + nt * 32 + 8 * g + 4 * h) * 4);
+                const float4 ev = *(const float4*)(stg + ((s * FT + lft) * BN + wc * NT * 32 + nt * 32 + 8 * g + 4 * h) * 4);
                 const float cvv[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -386,9 +419,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 #endif
 }
 
-template <int NT, int PW, int NW, int MT>
+template <int NT, int PW, int NW, int MT, int WC = 1>
 static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
-  using Cfg = GldsCfg<NT, PW, NW, MT>;
+  using Cfg = GldsCfg<NT, PW, NW, MT, WC>;
   using P = typename Cfg::P;
   ConvDev d;
   d.a = a;
@@ -404,7 +437,7 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
       ncu = 256;
   }
   const long long nblk = ntiles < ncu ? ntiles : ncu;
-  auto kern = conv_glds_kernel<NT, PW, NW, MT>;
+  auto kern = conv_glds_kernel<NT, PW, NW, MT, WC>;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;

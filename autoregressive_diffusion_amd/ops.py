@@ -306,6 +306,9 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         if (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H % 16 == 0 and W % 16 == 0
                 and ctx_fill in (0.0, 1.0)):          # mirrors conv_glds_ok() in csrc/conv_glds.h
             key = f"conv_glds_kernel<NT={nt},PW=16,NW=8,MT=1>"
+        elif (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H == 8 and W == 8
+              and CoutP % 64 == 0 and ctx_fill in (0.0, 1.0)):
+            key = "conv_glds_kernel<NT=1,PW=8,NW=8,MT=1,WC=2>"
         else:
             key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

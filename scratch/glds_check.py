@@ -43,6 +43,7 @@ def run(B, T, H, C, Cout, variants, iters=10, dgrad=False, epi=0):
 
 if __name__ == "__main__":
     variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1,3,4").split(",")]
-    for shp in [(2, 64, 32, 64, 64), (2, 64, 16, 128, 128), (2, 64, 64, 32, 32), (1, 5, 16, 64, 96)]:
+    for shp in [(2, 64, 32, 64, 64), (2, 64, 16, 128, 128), (2, 64, 64, 32, 32), (1, 5, 16, 64, 96), (2, 64, 8, 256, 256),
+                (1, 5, 8, 64, 128), (3, 1, 8, 32, 64)]:
         run(*shp, variants)
         run(*shp, variants, dgrad=True)

@@ -125,7 +125,9 @@ def test_conv_plain(N, H, cin, cout, k):
                                             (1, 2, 32, 16, 32),
                                             # shapes the persistent LDS-DMA kernel takes (16x16 tiles, Cin % 32 == 0):
                                             # several tiles per frame / per workgroup, 1..4 channel chunks, ragged Cout
-                                            (2, 5, 32, 32, 96), (1, 3, 16, 128, 64), (3, 7, 16, 32, 32)])
+                                            (2, 5, 32, 32, 96), (1, 3, 16, 128, 64), (3, 7, 16, 32, 32),
+                                            # 8x8 images: two frames per workgroup tile (odd T: a ragged last tile)
+                                            (2, 3, 8, 64, 128), (1, 5, 8, 32, 64)])
 def test_gated_conv_train(B, T, H, cin, cout):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(3)
