@@ -5,7 +5,6 @@
 // (conv_glds.h: 8 waves, 16x16-pixel workgroup tiles) wherever the shape allows it.
 template <int NT>
 static int glds_pick(const OnirisConvArgs& a, hipStream_t st) {
-  if (NT == 2 && a.big_tile == 5 && a.H % 8 == 0) return launch_conv_glds<1, 16, 8, 1, 2>(a, st);   // A/B: 16x8 tiles
   return launch_conv_glds<NT, 16, 8, 1>(a, st);
 }
 

@@ -263,9 +263,12 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
   const int ncob = cdiv(a.Cout, 32 * CT);
   const int gy = d.ncib * ncob;
   long long tot = 0;
+  bool use_glds = false;                                             // LDS-DMA variant (pad_ < 0 forces the register-staged one)
+  if constexpr (TAPS == 9 && (PW == 16 || PW == 8)) use_glds = a.pad_ >= 0 && wgrad_glds_ok(args, ng);
+  const int ft = (use_glds && PW == 8) ? 1 : P::FT;                  // the LDS-DMA kernel takes 8x8 images one frame at a time
   for (int g = 0; g < ng; ++g) {
     d.a[g] = args[g];
-    d.ntt[g] = (TAPS == 9) ? cdiv(args[g].T, P::FT) : cdiv(args[g].T * a.H * a.W, 128);
+    d.ntt[g] = (TAPS == 9) ? cdiv(args[g].T, ft) : cdiv(args[g].T * a.H * a.W, 128);
     d.ntiles[g] = d.ntx * d.nty * d.ntt[g] * args[g].B;
     tot += d.ntiles[g];
   }
@@ -282,10 +285,10 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
     gx_tot += gx;
   }
   for (int g = ng; g <= WGRAD_MAXG; ++g) d.gstart[g] = gx_tot;      // empty groups
-  if constexpr (TAPS == 9 && PW == 16) {
-    if (a.pad_ >= 0 && wgrad_glds_ok(args, ng)) {                    // LDS-DMA variant (pad_ < 0 forces the register-staged one)
+  if constexpr (TAPS == 9 && (PW == 16 || PW == 8)) {
+    if (use_glds) {
       constexpr int NG = 2;
-      auto kern = conv_wgrad_glds_kernel<CT, IT, NG>;
+      auto kern = conv_wgrad_glds_kernel<CT, IT, NG, PW>;
       hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256 * NG), 0, stream, d);
       ONIRIS_LAUNCH_CHECK();
       return ONIRIS_OK;

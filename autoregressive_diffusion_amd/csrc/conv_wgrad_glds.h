@@ -16,14 +16,22 @@
 #pragma once
 #include "lds_dma.h"
 
-template <int CT, int IT, int NG>
+// PW = 16: 8 x 16 pixel tiles of one frame (128 positions); PW = 8: one whole 8x8 frame (64 positions: four buffers of
+// a 128-position tile of two frames would need 166 KB of LDS)
+template <int CT, int IT, int NG, int PW = 16>
 __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const WgradDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  using P = Patch<16>;                                  // 8 x 16 pixel tiles of one frame (128 positions)
+  constexpr int NPOS = (PW == 16) ? 128 : 64, NKT = NPOS / 16;         // positions and 16-position k-steps per tile
+  using P = Patch<PW, NPOS>;
+  constexpr int FT = P::FT, HHW = P::HH * P::HW;
   constexpr int TAPS = 9, DROWB = CT * 64, XROWB = IT * 64, DPP = CT * 4, XPP = IT * 4;     // row bytes, 16-B pieces per row
   constexpr int NTILE = CT * IT, NKS = 4 / NTILE;      // waves of a K-group sharing one 32x32 tile split its k-steps
-  constexpr int DY_BYTES = 128 * DROWB, X_BYTES = P::HALO * XROWB, BUFB = DY_BYTES + X_BYTES;
-  static_assert(P::FT == 1 && P::HALO == 180, "tile geometry");
+  constexpr int DY_BYTES = NPOS * DROWB, X_BYTES = P::HALO * XROWB, BUFB = DY_BYTES + X_BYTES;
+  static_assert((PW == 16 && P::HALO == 180) || (PW == 8 && P::HALO == 100), "tile geometry");
+  static_assert(FT == 1 && NKT % NKS == 0, "one frame per tile");
+  auto pos_pix = [&](int p, int& f_, int& py, int& px) __attribute__((always_inline)) {     // position in tile -> frame, pixel
+    if constexpr (PW == 16) { f_ = 0; py = p >> 4; px = p & 15; } else { f_ = p >> 6; py = (p >> 3) & 7; px = p & 7; }   // (p < 64: f_ = 0)
+  };
   __shared__ __attribute__((aligned(16))) unsigned char smem[NG * 2 * BUFB];
 
   int gsel = 0;
@@ -48,23 +56,25 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
 
   // ---- DMA descriptors
   constexpr int OOB = (int)0x80000000;
-  constexpr int DNI = 128 * DPP / 256, XTOT = P::HALO * XPP, XNI = (XTOT + 255) / 256;
+  constexpr int DTOT = NPOS * DPP, DNI = (DTOT + 255) / 256, XTOT = P::HALO * XPP, XNI = (XTOT + 255) / 256;
   int dvoff[DNI], xrel[XNI], xhyx[XNI];
 #pragma unroll
   for (int i = 0; i < DNI; ++i) {
     const int e = i * 256 + gtid;
     const int row = e / DPP, gp = (CT == 2) ? ((e % DPP) ^ (4 * ((row >> 1) & 1))) : (e % DPP);   // 128-B rows are swizzled
     const int co = co0 + gp * 8;
-    dvoff[i] = (co < Cout) ? (((row >> 4) * W + (row & 15)) * Cout + co) * 2 : OOB;
+    int f_, py, px;
+    pos_pix(row, f_, py, px);
+    dvoff[i] = (e < DTOT && co < Cout) ? ((f_ * HWp + py * W + px) * Cout + co) * 2 : OOB;
   }
 #pragma unroll
   for (int i = 0; i < XNI; ++i) {
     const int e = i * 256 + gtid;
     const int row = e / XPP, gp = (IT == 2) ? ((e % XPP) ^ (4 * ((row >> 1) & 1))) : (e % XPP);
-    const int hy = row / P::HW, hx = row % P::HW;
+    const int f_ = row / HHW, hy = (row % HHW) / P::HW, hx = row % P::HW;
     const int ci = ci0 + gp * 8;
-    xhyx[i] = (e < XTOT && ci < Cin) ? ((hy << 8) | hx) : -1;
-    xrel[i] = (((hy - 1) * W + (hx - 1)) * Cin + ci) * 2;
+    xhyx[i] = (e < XTOT && ci < Cin) ? ((f_ << 16) | (hy << 8) | hx) : -1;
+    xrel[i] = ((f_ * HWp + (hy - 1) * W + (hx - 1)) * Cin + ci) * 2;
   }
   const i32x4 rs_dy = make_rsrc(a.dy, a.B * a.T * HWp * Cout * 2);
   const i32x4 rs_x = make_rsrc(a.x, a.B * a.xb_stride * HWp * Cin * 2);
@@ -77,25 +87,43 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
     Tile tl;
     tl.x0 = (id % d.ntx) * P::PW; id /= d.ntx;
     tl.y0 = (id % d.nty) * P::PH; id /= d.nty;
-    tl.t = id % g_ntt; tl.b = id / g_ntt;
+    tl.t = (id % g_ntt) * FT; tl.b = id / g_ntt;
     return tl;
   };
   auto issue = [&](const Tile& tl, int bsel) __attribute__((always_inline)) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (kg * 2 + bsel) * BUFB + wave4 * 1024);
     const int so_dy = (((tl.b * a.T + tl.t) * HWp + tl.y0 * W + tl.x0) * Cout) * 2;
 #pragma unroll
-    for (int i = 0; i < DNI; ++i) dma16(rs_dy, dvoff[i], so_dy, dst + i * 4096);
-    const int f = tl.t + a.coff;
-    const bool real = f >= 0 && f < a.x_T;
+    for (int i = 0; i < DNI; ++i) {
+      int v = dvoff[i];
+      if constexpr (FT > 1) { if (tl.t + ((i * 256 + gtid) / DPP >> 6) >= a.T) v = OOB; }     // ragged last tile
+      if (i * 256 + gtid < DTOT) dma16(rs_dy, v, so_dy, dst + i * 4096);
+    }
     const int origin = (tl.y0 * W + tl.x0) * Cin * 2;
-    const int so_x = real ? ((tl.b * a.xb_stride + f) * HWp * Cin) * 2 : 0;
+    if constexpr (FT == 1) {
+      const int f = tl.t + a.coff;
+      const bool real = f >= 0 && f < a.x_T;
+      const int so_x = real ? ((tl.b * a.xb_stride + f) * HWp * Cin) * 2 : 0;
 #pragma unroll
-    for (int i = 0; i < XNI; ++i) {
-      if (i * 256 + gtid < XTOT) {
-        const int hy = xhyx[i] >> 8, hx = xhyx[i] & 255;
-        const bool ok = xhyx[i] >= 0 && (unsigned)(tl.y0 + hy - 1) < (unsigned)H && (unsigned)(tl.x0 + hx - 1) < (unsigned)W;
-        if (real) dma16(rs_x, ok ? xrel[i] + origin : OOB, so_x, dst + DY_BYTES + i * 4096);
-        else dma16(rs_f, ok ? fillsel : OOB, 0, dst + DY_BYTES + i * 4096);
+      for (int i = 0; i < XNI; ++i) {
+        if (i * 256 + gtid < XTOT) {
+          const int hy = (xhyx[i] >> 8) & 255, hx = xhyx[i] & 255;
+          const bool ok = xhyx[i] >= 0 && (unsigned)(tl.y0 + hy - 1) < (unsigned)H && (unsigned)(tl.x0 + hx - 1) < (unsigned)W;
+          if (real) dma16(rs_x, ok ? xrel[i] + origin : OOB, so_x, dst + DY_BYTES + i * 4096);
+          else dma16(rs_f, ok ? fillsel : OOB, 0, dst + DY_BYTES + i * 4096);
+        }
+      }
+    } else {                                               // the frame (real / padded) is a per-row property
+      const int so_x = (tl.b * a.xb_stride * HWp * Cin) * 2;
+      const int shift = (tl.t + a.coff) * HWp * Cin * 2;   // may be negative; voffset + shift >= 0 on the real rows
+#pragma unroll
+      for (int i = 0; i < XNI; ++i) {
+        if (i * 256 + gtid < XTOT) {
+          const int hy = (xhyx[i] >> 8) & 255, hx = xhyx[i] & 255, f = tl.t + a.coff + (xhyx[i] >> 16);
+          const bool ok = xhyx[i] >= 0 && (unsigned)(tl.y0 + hy - 1) < (unsigned)H && (unsigned)(tl.x0 + hx - 1) < (unsigned)W;
+          if (f >= 0 && f < a.x_T) dma16(rs_x, ok ? xrel[i] + origin + shift : OOB, so_x, dst + DY_BYTES + i * 4096);
+          else dma16(rs_f, ok ? fillsel : OOB, 0, dst + DY_BYTES + i * 4096);
+        }
       }
     }
   };
@@ -106,13 +134,18 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
   const int cslot = (lane & 3) * 8 + 32 * ((lane >> 4) & 1);
   const int dsw = (CT == 2) ? 64 * ((q >> 1) & 1) : 0;
   const int dya = (my_ks * 16 + 8 * hh + q) * DROWB + ((ct * 64 + cslot) ^ dsw);          // + ksi*NKS*16*DROWB (+4 rows)
-  int xa[3][2];                                            // [kx][parity of (ksi*NKS + ky)]
+  // halo row of position p0 = ks*16 + 8*hh + q under tap (ky,kx):
+  //   PW 16: (ks + ky)*18 + 8*hh + q + kx            swizzle parity = (ks + ky + ((q+kx)>>1)) & 1
+  //   PW  8: 100*(ks>>2) + 10*(2*(ks&3) + hh + ky) + q + kx      parity = (hh + ky + ((q+kx)>>1)) & 1
+  int xa[3][2];                                            // [kx][parity of the compile-time part]
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
     for (int par = 0; par < 2; ++par) {
-      const int xsw = (IT == 2) ? 64 * ((par ^ my_ks ^ ((q + kx) >> 1)) & 1) : 0;
-      xa[kx][par] = DY_BYTES + (my_ks * P::HW + 8 * hh + q + kx) * XROWB + ((it * 64 + cslot) ^ xsw);
+      const int lanepar = (PW == 16) ? my_ks : hh;
+      const int xsw = (IT == 2) ? 64 * ((par ^ lanepar ^ ((q + kx) >> 1)) & 1) : 0;
+      const int rbase = (PW == 16) ? my_ks * P::HW + 8 * hh + q + kx : 20 * my_ks + 10 * hh + q + kx;
+      xa[kx][par] = DY_BYTES + rbase * XROWB + ((it * 64 + cslot) ^ xsw);
     }
 
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -130,10 +163,17 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
   const int tstep = gxg * NG;
   int tile = bx * NG + kg;
   int bsel = 0;
-  float sc_next = 1.f;
+  float sc_next[FT];
+#pragma unroll
+  for (int f_ = 0; f_ < FT; ++f_) sc_next[f_] = 1.f;
+  auto load_scale = [&](const Tile& tl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int f_ = 0; f_ < FT; ++f_)
+      if (a.scale) sc_next[f_] = a.scale[tl.b * a.T + min(tl.t + f_, a.T - 1)];
+  };
   Tile cur = decode(tile < g_ntiles ? tile : 0);
   if (tile < g_ntiles) {
-    if (a.scale) sc_next = a.scale[cur.b * a.T + cur.t];
+    load_scale(cur);
     issue(cur, 0);
   }
 #pragma unroll 1
@@ -141,29 +181,38 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
     const bool have = tile < g_ntiles;
     dma_wait();
     __syncthreads();                       // this tile has landed for everybody; buffer bsel^1 is free again
-    float sc = sc_next;
-    asm volatile("" : "+v"(sc));          // consume the coefficient before the next DMA goes out (see conv_glds.h)
+    float sc[FT];
+#pragma unroll
+    for (int f_ = 0; f_ < FT; ++f_) {
+      sc[f_] = sc_next[f_];
+      asm volatile("" : "+v"(sc[f_]));    // consume the coefficient before the next DMA goes out (see conv_glds.h)
+    }
     const int ntile = tile + tstep;
     if (ntile < g_ntiles) {
       const Tile nx = decode(ntile);
-      if (a.scale) sc_next = a.scale[nx.b * a.T + nx.t];
+      load_scale(nx);
       issue(nx, bsel ^ 1);
     }
     if (have) {
       const unsigned char* buf = gbase + bsel * BUFB;
-      constexpr int NK = 8 / NKS, NSTEP = NK * TAPS, LA = 3;
+      constexpr int NK = NKT / NKS, NSTEP = NK * TAPS, LA = 3;
       bf16x8 af[2], bfm[4];
       auto ld_a = [&](int kb, int ksi) __attribute__((always_inline)) {
         bf16x8 v = trf(buf + dya + ksi * NKS * 16 * DROWB, DROWB);
         if (a.scale) {                    // per-frame coefficient folded into dy (bf16 rounding, like a dy2 tensor)
+          const float scf = sc[(FT > 1) ? ((ksi * NKS) >> 2) : 0];       // a k-step never straddles frames
 #pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) * sc);
+          for (int k = 0; k < 8; ++k) v[k] = f2bf(bf2f(v[k]) * scf);
         }
         af[kb] = v;
       };
       auto ld_b = [&](int fb, int st) __attribute__((always_inline)) {
         const int ksi = st / TAPS, tap = st % TAPS, ky = tap / 3, kx = tap % 3;
-        bfm[fb] = trf(buf + xa[kx][(ksi * NKS + ky) & 1] + (ksi * NKS + ky) * P::HW * XROWB, XROWB);
+        constexpr int dummy = 0; (void)dummy;
+        const int ksc = ksi * NKS;                                          // compile-time part of the k-step
+        const int par = (PW == 16) ? ((ksc + ky) & 1) : (ky & 1);
+        const int rimm = (PW == 16) ? (ksc + ky) * P::HW : 100 * (ksc >> 2) + 20 * (ksc & 3) + 10 * ky;
+        bfm[fb] = trf(buf + xa[kx][par] + rimm * XROWB, XROWB);
       };
       ld_a(0, 0);
 #pragma unroll
@@ -233,7 +282,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
 static inline bool wgrad_glds_ok(const OnirisWgradArgs* args, int ng) {
   for (int g = 0; g < ng; ++g) {
     const OnirisWgradArgs& a = args[g];
-    if (a.taps != 9 || a.W % 16 != 0 || a.H % 8 != 0) return false;
+    if (a.taps != 9 || !((a.W % 16 == 0 && a.H % 8 == 0) || (a.W == 8 && a.H == 8))) return false;
     if (!(a.fill == 0.f || a.fill == 1.f)) return false;
     if ((long long)a.B * a.T * a.H * a.W * a.Cout * 2 >= (1LL << 31)) return false;
     if ((long long)a.B * a.xb_stride * a.H * a.W * a.Cin * 2 >= (1LL << 31)) return false;

@@ -350,9 +350,9 @@ def _wgrad_launch_group(arglist):
     if KernelProfile.enabled:
         a0 = arglist[0]
         tile = 2 if (a0.Cin > 32 and a0.Cout > 32) else 1
-        if WGRAD_VARIANT >= 0 and all(a.taps == 9 and a.W % 16 == 0 and a.H % 8 == 0 and a.fill in (0.0, 1.0)
-                                      for a in arglist):                      # mirrors wgrad_glds_ok() in csrc
-            key = f"conv_wgrad_glds_kernel<CT={tile},IT={tile},NG=2>"
+        if WGRAD_VARIANT >= 0 and all(a.taps == 9 and ((a.W % 16 == 0 and a.H % 8 == 0) or (a.W == 8 and a.H == 8))
+                                      and a.fill in (0.0, 1.0) for a in arglist):     # mirrors wgrad_glds_ok() in csrc
+            key = f"conv_wgrad_glds_kernel<CT={tile},IT={tile},NG=2,PW={_patch_w(a0.W)}>"
         elif (WGRAD_VARIANT >= 0 and len(arglist) == 1 and a0.taps == 1 and a0.Cin >= 64 and a0.Cout >= 64 and not a0.scale
               and a0.coff == 0):                                               # mirrors wgrad1x1_glds_ok()
             key = "wgrad1x1_glds_kernel<NG=2>"
