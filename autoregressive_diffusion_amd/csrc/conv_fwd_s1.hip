@@ -1,5 +1,20 @@
 #include "conv_fwd_common.h"
-int conv_dispatch_s1(const OnirisConvArgs& a, hipStream_t st) { return conv3x3_pick<1, false>(a, st); }
+#include "conv_glds.h"
+
+// Plain 3x3 convs (the 2-D training steps, stem / non-gated layers): with big_tile >= 3 and an even frame count they
+// run on the persistent LDS-DMA kernel as "two slots of T/2 frames, no context phases".
+int conv_dispatch_s1(const OnirisConvArgs& a, hipStream_t st) {
+  if (a.big_tile >= 3) {
+    OnirisConvArgs b = a;
+    b.S = 2; b.T = a.T / 2;
+    b.ctx_T = 0; b.ctx_bstride = 0;
+    if (conv_glds_ok(a, 16, 16, (a.CoutP % 64 == 0) ? 64 : 32, true))
+      return (a.CoutP % 64 == 0) ? launch_conv_glds<2, 16, 8, 1, 1, false>(b, st) : launch_conv_glds<1, 16, 8, 1, 1, false>(b, st);
+    if (a.W == 8 && a.H == 8 && a.CoutP % 64 == 0 && conv_glds_ok(a, 8, 8, 64, true))
+      return launch_conv_glds<1, 8, 8, 1, 2, false>(b, st);
+  }
+  return conv3x3_pick<1, false>(a, st);
+}
 int conv_dispatch_1x1(const OnirisConvArgs& a, hipStream_t st) {
   if (a.CoutP % 64 == 0) return launch_conv_fwd<1, 1, 64, 2, false, 16>(a, st);
   return launch_conv_fwd<1, 1, 64, 1, false, 16>(a, st);

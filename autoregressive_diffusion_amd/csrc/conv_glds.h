@@ -46,12 +46,15 @@ struct GldsCfg {
   static_assert((NWP * 2 * HW) % 16 == 0 || MT == 1, "position tiles of a wave must be 16-row aligned apart");
 };
 
-template <int NT, int PW, int NW, int MT, int WC = 1>
+// CTX = false: plain 3x3 convolution of an even number of frames, run as "two slots, no context phases" (the 2-D
+// training steps and every non-gated 3x3 conv): same tiles, one phase per 32-channel chunk.
+template <int NT, int PW, int NW, int MT, int WC = 1, bool CTX = true>
 __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(const ConvDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (the stub needs no body)
   using Cfg = GldsCfg<NT, PW, NW, MT, WC>;
   using P = typename Cfg::P;
   constexpr int S = 2, TAPS = 9, CK = 32, KS = CK / 16, HW_ = Cfg::HW, HH_ = Cfg::HH, FT = Cfg::FT, NWP = Cfg::NWP;
+  constexpr int NPH = CTX ? 3 : 1;                         // phases per channel chunk
   constexpr int BN = Cfg::BN, NTHR = Cfg::NTHR, AROWS = Cfg::AROWS, BUF = Cfg::BUF;
   __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::LDS_BYTES];     // static: see conv_kernels.h
 
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   }
   const int wbytes = TAPS * a.CoutP * a.CinP * 2;
   const i32x4 rs_f = make_rsrc(oniris_fill_rows, 128);
-  const i32x4 rs_wo = make_rsrc(a.w_own, wbytes), rs_wc = make_rsrc(a.w_ctx, 2 * wbytes);
+  const i32x4 rs_wo = make_rsrc(a.w_own, wbytes), rs_wc = make_rsrc(CTX ? a.w_ctx : a.w_own, CTX ? 2 * wbytes : wbytes);
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
   const int fillsel = (a.ctx_fill != 0.f) ? 64 : 0;
 
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 
   constexpr int EROW = Cfg::EROW;
   constexpr int ESC = 2 * FT * BN * 4;                  // emb-scale vectors [slot][frame][BN], in front of the staging tiles
-  const int nphase = (Cin / CK) * 3;
+  const int nphase = (Cin / CK) * NPH;
   Tile cur = decode(tl);
   set_adesc(cur);
   int bsel = 0;
@@ -278,9 +281,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     }
 #pragma unroll 1
     for (int itp = 0; itp < nphase; ++itp) {
-      const int ph = itp % 3;
-      if (itp + 1 < nphase) issue(cur, (itp + 1) / 3, (itp + 1) % 3, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
-      if (ph == 0) mfma_steps(std::true_type{}, bsel);
+      const int ph = itp % NPH;
+      if (itp + 1 < nphase) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
+      if (!CTX || ph == 0) mfma_steps(std::true_type{}, bsel);
       else mfma_steps(std::false_type{}, bsel);
       dma_wait();                        // this wave's share of the next phase has landed ...
       __syncthreads();                   // ... everybody's has; and everybody is done reading buffer bsel
@@ -338,7 +341,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
         // sum is simply recomputed from the accumulators for every output that needs it
         auto raw = [&](int nt, float (&v)[16]) __attribute__((always_inline)) {
 #pragma unroll
-          for (int i = 0; i < 16; ++i) v[i] = __builtin_fmaf(cctx, accc[m][nt][i], cown * acc[s][m][nt][i]);
+          for (int i = 0; i < 16; ++i) v[i] = CTX ? __builtin_fmaf(cctx, accc[m][nt][i], cown * acc[s][m][nt][i]) : cown * acc[s][m][nt][i];
         };
         auto put = [&](int nt, const float (&v)[16]) __attribute__((always_inline)) {
 #pragma unroll
@@ -401,7 +404,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
             flush((bf16*)a.out2, blk);
           }
         }
-        if (a.ctx_out && s == 0) {          // unscaled context product y3 (shared by both slots), kept for d(gate)
+        if (CTX && a.ctx_out && s == 0) {   // unscaled context product y3 (shared by both slots), kept for d(gate)
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -419,7 +422,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 #endif
 }
 
-template <int NT, int PW, int NW, int MT, int WC = 1>
+template <int NT, int PW, int NW, int MT, int WC = 1, bool CTX = true>
 static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
   using Cfg = GldsCfg<NT, PW, NW, MT, WC>;
   using P = typename Cfg::P;
@@ -437,15 +440,15 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
       ncu = 256;
   }
   const long long nblk = ntiles < ncu ? ntiles : ncu;
-  auto kern = conv_glds_kernel<NT, PW, NW, MT, WC>;
+  auto kern = conv_glds_kernel<NT, PW, NW, MT, WC, CTX>;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
 
-// true when the LDS-DMA variant can run this problem
-static inline bool conv_glds_ok(const OnirisConvArgs& a, int PH, int PW, int BN) {
-  return a.S == 2 && a.ctx && a.taps == 9 && a.Cin % 32 == 0 && a.CoutP % BN == 0 && a.H % PH == 0 && a.W % PW == 0 &&
+// true when the LDS-DMA variant can run this problem (plain: S == 1 without context, an even number of frames)
+static inline bool conv_glds_ok(const OnirisConvArgs& a, int PH, int PW, int BN, bool plain = false) {
+  return (plain ? (a.S == 1 && !a.ctx && a.T % 2 == 0) : (a.S == 2 && a.ctx != nullptr)) && a.taps == 9 && a.Cin % 32 == 0 && a.CoutP % BN == 0 && a.H % PH == 0 && a.W % PW == 0 &&
          (a.ctx_fill == 0.f || a.ctx_fill == 1.f) &&
          2LL * a.T * a.H * a.W * a.Cin * 2 < (1LL << 31) && (long long)a.ctx_T * a.H * a.W * a.Cin * 2 < (1LL << 31) &&
          18LL * a.CoutP * a.CinP * 2 < (1LL << 31);

@@ -309,6 +309,10 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         elif (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H == 8 and W == 8
               and CoutP % 64 == 0 and ctx_fill in (0.0, 1.0)):
             key = "conv_glds_kernel<NT=1,PW=8,NW=8,MT=1,WC=2>"
+        elif (BIG_TILE >= 3 and S == 1 and ctx is None and taps == 9 and Cin % 32 == 0 and T % 2 == 0
+              and ((H % 16 == 0 and W % 16 == 0) or (H == 8 and W == 8 and CoutP % 64 == 0))):   # conv_dispatch_s1()
+            key = (f"conv_glds_kernel<NT={nt},PW=16,NW=8,MT=1,WC=1,CTX=0>" if H % 16 == 0 else
+                   "conv_glds_kernel<NT=1,PW=8,NW=8,MT=1,WC=2,CTX=0>")
         else:
             key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

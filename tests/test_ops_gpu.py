@@ -96,7 +96,9 @@ def test_weight_perm3():
 
 
 @pytest.mark.parametrize("N,H,cin,cout,k", [(6, 16, 32, 64, 3), (5, 8, 96, 32, 3), (16, 4, 64, 64, 3), (3, 32, 16, 40, 3),
-                                            (7, 8, 64, 192, 1), (3, 16, 48, 32, 1), (130, 1, 64, 96, 1)])
+                                            (7, 8, 64, 192, 1), (3, 16, 48, 32, 1), (130, 1, 64, 96, 1),
+                                            # even frame counts on Cin % 32 == 0: the LDS-DMA kernel without context phases
+                                            (4, 8, 32, 128, 3), (2, 32, 32, 32, 3), (10, 16, 64, 96, 3)])
 def test_conv_plain(N, H, cin, cout, k):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(2)
