@@ -111,8 +111,32 @@ def _nsplit_cap(cin, cout, taps):
     return cap
 
 
+class _ZeroArena:
+    """Pre-zeroed fp32 scratch for the accumulators the backward kernels add into with atomics (gate / emb-scale
+    gradient sums): ONE fill per step (WeightBank.prepare) instead of one `torch.zeros` launch per conv."""
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def take(self, n, device):
+        n = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != device:
+            self.buf, self.off = torch.zeros(1 << 22, dtype=torch.float32, device=device), 0
+        if self.off + n > self.buf.numel():
+            return torch.zeros(n, dtype=torch.float32, device=device)
+        v = self.buf[self.off:self.off + n]
+        self.off += n
+        return v
+
+    def reset(self):
+        if self.buf is not None and self.off:
+            self.buf[:self.off].zero_()
+        self.off = 0
+
+
 class WeightBank:
     def __init__(self):
+        self.zero_arena = _ZeroArena()
         self.items = []
         self._dev_table = None
         self._sig = None
@@ -231,6 +255,7 @@ class WeightBank:
     def prepare(self, training):
         """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
         self._ensure()
+        self.zero_arena.reset()                        # (the previous step's backward is done with its accumulators)
         check(lib.oniris_weight_prep(_p(self._dev_table), len(self.items), self.total_rows, self.total_tiles, int(training),
                                      _stream()),
               "weight_prep")
@@ -458,10 +483,10 @@ class _ConvOp(torch.autograd.Function):
             B, T = cfg.B, cfg.T
             dout = torch.empty_like(g)
             dy3 = torch.empty_like(y3)
-            acc = torch.zeros(N * (2 + (Co if cfg.epi == "emb_silu" else 0)), dtype=torch.float32, device=dev)
+            acc = pw2.bank.zero_arena.take(N * (2 + (Co if cfg.epi == "emb_silu" else 0)), dev)
             dca, dcb = acc[:N], acc[N:2 * N]
             if cfg.epi == "emb_silu":
-                dcs = acc[2 * N:].view(N, Co)
+                dcs = acc[2 * N:2 * N + N * Co].view(N, Co)
             else:
                 dres = torch.empty_like(g)
             check(lib.oniris_gconv_bwd_fused(1 if cfg.epi == "emb_silu" else 2, _p(g), _p(raw), _p(y3), _p(ca), _p(cb),
