@@ -128,13 +128,16 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    force_dist = bool(os.environ.get("ONIRIS_FORCE_DIST"))          # debug: run the RCCL/DDP path with a single rank
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
                          f"--nproc-per-node {args.gpus} bench.py ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     from edm2.networks_edm2 import UNet, Precond
@@ -149,7 +152,9 @@ def main():
             torch.nn.init.constant_(m.emb_gain, 0.3)
     torch.nn.init.constant_(unet.out_gain, 1.0)
     flat = FlatParams(unet, lazy_small=True)
-    model = OnirisDDP(unet, flat=flat) if world > 1 else unet
+    model = OnirisDDP(unet, flat=flat) if (world > 1 or force_dist) else unet
+    if force_dist:
+        model.force_collectives = True
     net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
     opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
     loss_fn = EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5)   # gym_train.py:66-67
@@ -188,7 +193,7 @@ def main():
                 model.allreduce_grads()
         else:
             loss = fwd_bwd(just_2d)
-        if world > 1:
+        if world > 1 or force_dist:
             model.wait()
         opt.step()
         return loss
@@ -267,7 +272,7 @@ def main():
                           **{k: round(v, 2) for k, v in per_mode.items()}},
                "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "kernels": kernels}
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 
