@@ -263,6 +263,7 @@ class WeightBank:
     def backward(self):
         """Packed fp32 weight gradients (from the wgrad kernels) -> parameter .grad (accumulated); one launch."""
         self._ensure()
+        join_side_stream()                             # every wgrad kernel (possibly on the side stream) is ordered before
         check(lib.oniris_weight_bwd(_p(self._dev_table), len(self.items), self.total_rows, _stream()), "weight_bwd")
         self.nsplit_all.zero_()        # the slabs are consumed: a second backward() must not add them again
 
@@ -286,6 +287,7 @@ class WeightBank:
 # convolution
 
 import os as _os
+WGRAD_SIDE_STREAM = int(_os.environ.get("ONIRIS_WGRAD_STREAM", "0"))   # opt-in: weight-gradient kernels on a second HIP stream (measured: 1-2 % slower, the LDS-filling kernels cannot share a CU)
 ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
 ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
 WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
@@ -374,8 +376,9 @@ def _wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_s
     return a
 
 
-def _wgrad_launch_group(arglist):
-    """One launch for 1..3 weight-gradient problems of the same geometry (oniris_conv_wgrad_group)."""
+def _wgrad_launch_group(arglist, keep=None):
+    """One launch for 1..3 weight-gradient problems of the same geometry (oniris_conv_wgrad_group).
+    keep: the tensors the kernel reads (needed when it is queued on the side stream)."""
     if KernelProfile.enabled:
         a0 = arglist[0]
         tile = 2 if (a0.Cin > 32 and a0.Cout > 32) else 1
@@ -392,19 +395,48 @@ def _wgrad_launch_group(arglist):
         e0.record()
         KernelProfile.enabled = False
         try:
-            _wgrad_launch_group(arglist)
+            _wgrad_launch_group(arglist)          # (profiled launches stay on the main stream)
         finally:
             KernelProfile.enabled = True
         e1.record()
         KernelProfile.records.append((key, flops, e0, e1))
         return
     arr = (_lib.WgradArgs * len(arglist))(*arglist)
+    if WGRAD_SIDE_STREAM and keep is not None and not torch.cuda.is_current_stream_capturing():
+        # Weight gradients are off the critical path (only weight_bwd at the end of backward consumes the slabs): on
+        # a second HIP stream they fill the CUs that the dgrad / elementwise kernels of the main stream leave idle at
+        # their heads and tails (consecutive kernels of ONE stream never overlap).
+        main = torch.cuda.current_stream()
+        side = _side_stream(main.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            check(lib.oniris_conv_wgrad_group(arr, len(arglist), _stream()), "conv_wgrad")
+        for t in keep:
+            if t is not None:
+                t.record_stream(side)           # the caching allocator must not recycle it before the side kernel ran
+        return
     check(lib.oniris_conv_wgrad_group(arr, len(arglist), _stream()), "conv_wgrad")
+
+
+_side_streams = {}
+
+
+def _side_stream(device):
+    s = _side_streams.get(device)
+    if s is None:
+        s = _side_streams[device] = torch.cuda.Stream(device=device)
+    return s
+
+
+def join_side_stream():
+    """Make the current stream wait for everything queued on the weight-gradient stream."""
+    for dev, s in _side_streams.items():
+        torch.cuda.current_stream(dev).wait_stream(s)
 
 
 def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
     _wgrad_launch_group([_wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff,
-                                     fill, tap0)])
+                                     fill, tap0)], keep=(x, dy, scale))
 
 
 class ConvCfg:
@@ -523,7 +555,7 @@ class _ConvOp(torch.autograd.Function):
                     grp.append(_wgrad_args(x, dy3, pw3, None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T, coff,
                                            1.0, tap0=9 * j))
             if grp:
-                _wgrad_launch_group(grp)
+                _wgrad_launch_group(grp, keep=(x, dout, dy3, ca))
         else:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
