@@ -11,6 +11,7 @@
 // rows); row fragments are 16-byte reads, the transposed operands (V^T, K^T, Q^T, dO^T: MFMA k index = token) come
 // from the SAME tiles through the gfx950 transposing read ds_read_b64_tr_b16.  dK/dV: one workgroup = 128 keys,
 // lane = key, S = Q.K^T with queries on the rows, P and dS feed dV^T += dO^T.P and dK^T += Q^T.dS from registers.
+#include <type_traits>
 #include "common.h"
 #include "../../include/oniris.h"
 
@@ -173,18 +174,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
         s[kt] = mfma32(kf, qf[ks], s[kt]);
       }
     }
+    // two straight-line versions (one uniform branch per tile): fully allowed tiles carry no mask code at all
+    auto softmax = [&](auto masked_) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_)::value;
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+      for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][rr], SCALE_LOG2, -SOFTMAX_OFF));
-        if (cls == 1) {
-          const int key = key0 + kt * 32 + mfma_row(rr, lane);
-          if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
+        for (int rr = 0; rr < 16; ++rr) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][rr], SCALE_LOG2, -SOFTMAX_OFF));
+          if constexpr (MASKED) {
+            const int key = key0 + kt * 32 + mfma_row(rr, lane);
+            if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
+          }
+          s[kt][rr] = p;
+          l2[rr & 1] += p;
         }
-        s[kt][rr] = p;
-        l2[rr & 1] += p;
-      }
+    };
+    if (cls == 2) softmax(std::false_type{});
+    else softmax(std::true_type{});
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -288,15 +295,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
         const bf16x8 vf = *(const bf16x8*)(V_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
         dp = mfma32(vf, dof[ks], dp);
       }
+      auto dsoft = [&](auto masked_) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_)::value;
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        float p = __builtin_amdgcn_exp2f(s[rr] * SCALE_LOG2 - lse);
-        if (cls == 1) {
-          const int key = key0 + kt * 32 + mfma_row(rr, lane);
-          if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
+        for (int rr = 0; rr < 16; ++rr) {
+          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rr], SCALE_LOG2, -lse));
+          if constexpr (MASKED) {
+            const int key = key0 + kt * 32 + mfma_row(rr, lane);
+            if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
+          }
+          s[rr] = p * (dp[rr] - delta) * 0.125f;          // dS (scaled)
         }
-        s[rr] = p * (dp[rr] - delta) * 0.125f;          // dS (scaled)
-      }
+      };
+      if (cls == 2) dsoft(std::false_type{});
+      else dsoft(std::true_type{});
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 db = pack8(s, s2);
@@ -406,17 +418,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
         dp = mfma32(da, vf[ks], dp);                     // dP[q][key]
       }
       f32x16 pv;
+      auto dsoft = [&](auto masked_) __attribute__((always_inline)) {
+        constexpr bool MASKED = decltype(masked_)::value;
 #pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int ql = qt * 32 + mfma_row(rr, lane);
-        float p = __builtin_amdgcn_exp2f(s[rr] * SCALE_LOG2 - lse_lds[ql]);
-        if (cls == 1) {
-          const int qtok = q0 + ql;
-          if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int qb4 = qt * 32 + 8 * g4 + 4 * h;          // 4 consecutive query rows per accumulator group
+          const float4 ls = *(const float4*)(lse_lds + qb4), de = *(const float4*)(del_lds + qb4);
+          const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int rr = 4 * g4 + k;
+            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rr], SCALE_LOG2, -lsv[k]));
+            if constexpr (MASKED) {
+              const int qtok = q0 + qb4 + k;
+              if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
+            }
+            pv[rr] = p;
+            s[rr] = p * (dp[rr] - dev[k]) * 0.125f;          // dS (scaled)
+          }
         }
-        pv[rr] = p;
-        s[rr] = p * (dp[rr] - del_lds[ql]) * 0.125f;     // dS (scaled)
-      }
+      };
+      if (cls == 2) dsoft(std::false_type{});
+      else dsoft(std::true_type{});
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pb = pack8(pv, s2);
