@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   unsigned char* K_lds = smem;
   unsigned char* V_lds = smem + 64 * KROW;
   const OnirisAttnArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
   const int nqb = gridDim.x;
   const int qb = nqb - 1 - blockIdx.x;             // heaviest (latest) query blocks first
   const int head = blockIdx.y, b = blockIdx.z;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
   unsigned char* K_lds = smem;
   unsigned char* V_lds = smem + 64 * KROW;
   const OnirisAttnArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
   const int nqb = gridDim.x;
   const int qb = nqb - 1 - blockIdx.x;
   const int head = blockIdx.y, b = blockIdx.z;
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
   float* lse_lds = (float*)(smem + 2 * 64 * KROW);
   float* del_lds = lse_lds + 64;
   const OnirisAttnArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
   const int nch = a.dkv_chunks > 1 ? a.dkv_chunks : 1;      // query-list chunks per key block (see OnirisAttnArgs)
   const int kb = blockIdx.x / nch, chunk = blockIdx.x % nch, head = blockIdx.y, b = blockIdx.z;
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
