@@ -13,6 +13,7 @@
 // lane = key, S = Q.K^T with queries on the rows, P and dS feed dV^T += dO^T.P and dK^T += Q^T.dS from registers.
 #include <type_traits>
 #include "common.h"
+#include "lds_dma.h"
 #include "../../include/oniris.h"
 
 #define NEG_BIG (-1.0e30f)
@@ -109,26 +110,48 @@ __device__ __forceinline__ bf16x8 trfrag(const unsigned char* lds, int tokbase, 
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// XCD-aware workgroup order: hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each with its own
+// 4 MB L2).  All workgroups of one (batch, head) pair read the same K / V (1 MB each at L = 8192), so a pair is
+// pinned to ONE XCD whenever the number of pairs is a multiple of 8: x = position inside the pair's row of the grid,
+// bh = pair index.  (Measured: without it K/V stream from the Infinity Cache, ~1 us per tile.)
+__device__ __forceinline__ void attn_block_decode(int& x, int& head, int& b) {
+  const int nx = gridDim.x, nbh = gridDim.y * gridDim.z;
+  const int L = blockIdx.x + nx * (blockIdx.y + gridDim.y * blockIdx.z);
+  int bh;
+  if ((nbh & 7) == 0) {
+    const int xcd = L & 7, k = L >> 3;
+    bh = xcd + 8 * (k / nx);
+    x = k % nx;
+  } else {
+    bh = L / nx;
+    x = L % nx;
+  }
+  head = bh % gridDim.y;
+  b = bh / gridDim.y;
+}
+
 // ================================================================================================================
-// forward
+// forward.  K / V tiles (64 keys x 64 channels, 128-byte rows) go global -> LDS by LDS-DMA into two alternating
+// buffers: the copy of tile i+1 runs under the MFMA / softmax work of tile i, one barrier per tile, no staging
+// registers.  The rows are unpadded (the DMA image is lane-linear), so the 16-byte pieces are XOR-swizzled on the
+// source side: K (read row-wise, ds_read_b128, 16 rows per access group) with (row>>1)&7, V (read through the
+// transposing ds_read_b64_tr_b16, 4 rows x 64 bytes) with 4*bit1(row).
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW];
-  unsigned char* K_lds = smem;
-  unsigned char* V_lds = smem + 64 * KROW;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TB = 64 * 128;                     // bytes of one tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TB];          // [buffer][K | V]
   const OnirisAttnArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int nqb = gridDim.x;
-  const int qb = nqb - 1 - blockIdx.x;             // heaviest (latest) query blocks first
-  const int head = blockIdx.y, b = blockIdx.z;
+  int bx_, head, b;
+  attn_block_decode(bx_, head, b);
+  const int qb = nqb - 1 - bx_;                    // heaviest (latest) query blocks first
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
   const int qw0 = qb * 128 + wave * 32;
   const int qrow = qw0 + r;
 
   const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
-  const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
-  const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
-
   bf16x8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -149,30 +172,81 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
     const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
     return kb * 128 + (idx & 1) * 64;
   };
-  u32x4 rk[2], rv[2];
-  if (nsub > 0) { const int k0 = key_start(0); tile_load(rk, kg, k0, Lk, C, tid); tile_load(rv, vg, k0, Lk, C, tid); }
+
+  // DMA descriptors: two 16-byte pieces per thread and tile
+  constexpr int OOB = (int)0x80000000;
+  int kvo[2], vvo[2], prow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = i * 256 + tid, row = e >> 3, pp = e & 7;
+    prow[i] = row;
+    kvo[i] = (row * C + head * 64 + (pp ^ ((row >> 1) & 7)) * 8) * 2;
+    vvo[i] = (row * C + head * 64 + (pp ^ (4 * ((row >> 1) & 1))) * 8) * 2;
+  }
+  const i32x4 rs_k = make_rsrc((const bf16*)a.k + (size_t)b * Lk * C, Lk * C * 2);
+  const i32x4 rs_v = make_rsrc((const bf16*)a.v + (size_t)b * Lk * C, Lk * C * 2);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+  auto issue = [&](int key0, int bsel) __attribute__((always_inline)) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + bsel * 2 * TB + wave * 1024);
+    const int left = Lk - key0, so = key0 * C * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = prow[i] < left;
+      dma16(rs_k, ok ? kvo[i] : OOB, so, dst + i * 4096);
+      dma16(rs_v, ok ? vvo[i] : OOB, so, dst + TB + i * 4096);
+    }
+  };
+  // fragment addresses
+  const int kb0 = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);                 // K rows kt*32 + r, k-step ks: ^ (ks*32), + kt*4096
+  const int grp = lane >> 4, hh = grp >> 1, q4 = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
+  const int vb0 = (4 * hh + q4) * 128 + pcol * 2, vsw = (q4 >> 1) & 1;    // V^T: + tokbase*128 + ((dt ^ vsw)*64)
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto vtr = [&](const unsigned char* vt, int tokbase, int dt) __attribute__((always_inline)) {
+    const unsigned char* p0 = vt + vb0 + tokbase * 128 + ((dt ^ vsw) * 64);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 128));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  int bsel = 0;
+  if (nsub > 0) issue(key_start(0), 0);
 #pragma unroll 1
   for (int idx = 0; idx < nsub; ++idx) {
     const int key0 = key_start(idx);
-    __syncthreads();
-    tile_store(K_lds, rk, tid);
-    tile_store(V_lds, rv, tid);
-    __syncthreads();
-    if (idx + 1 < nsub) { const int k1 = key_start(idx + 1); tile_load(rk, kg, k1, Lk, C, tid); tile_load(rv, vg, k1, Lk, C, tid); }
+    dma_wait();
+    __syncthreads();                               // tile idx has landed for everybody; buffer bsel^1 is free again
+    if (idx + 1 < nsub) issue(key_start(idx + 1), bsel ^ 1);
+    const unsigned char* Kt = smem + bsel * 2 * TB;
+    const unsigned char* Vt = Kt + TB;
+    bsel ^= 1;
     int cls = (key0 >= Lk) ? 0 : classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
     if (key0 + 63 >= Lk && cls == 2) cls = 1;
     if (cls == 0 || qw0 >= Lq) continue;
 
+    // all fragment reads of the tile go out first (K row fragments, then the transposed V fragments): the V reads
+    // complete under the S MFMAs and the softmax, nothing in the chain below waits for LDS
+    bf16x8 kf[2][4], vf[2][2][2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) kf[kt][ks] = *(const bf16x8*)(Kt + ((kb0 ^ (ks * 32)) + kt * 4096));
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) vf[kt][s2][dt] = vtr(Vt, kt * 32 + 16 * s2, dt);
     f32x16 s[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kt][i] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
-        s[kt] = mfma32(kf, qf[ks], s[kt]);
-      }
+      for (int ks = 0; ks < 4; ++ks) s[kt] = mfma32(kf[kt][ks], qf[ks], s[kt]);
     }
     // two straight-line versions (one uniform branch per tile): fully allowed tiles carry no mask code at all
     auto softmax = [&](auto masked_) __attribute__((always_inline)) {
@@ -198,10 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 pb = pack8(s[kt], s2);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 vf = trfrag(V_lds, kt * 32 + 16 * s2, dt * 32, lane);
-          o[dt] = mfma32(vf, pb, o[dt]);                   // O^T[dv][q] += V^T[dv][key] P^T[key][q]
-        }
+        for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vf[kt][s2][dt], pb, o[dt]);     // O^T[dv][q] += V^T[dv][key] P^T[key][q]
       }
   }
   if (qrow >= Lq) return;
@@ -219,6 +290,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
       *(bf16x4*)(og + dt * 32 + 8 * g + 4 * h) = ov;
     }
   if (a.lse && h == 0) a.lse[(size_t)(b * a.heads + head) * Lq + qrow] = SOFTMAX_OFF + log2f(fmaxf(l, 1e-30f));
+#endif
 }
 
 // ================================================================================================================
@@ -231,8 +303,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
   const int nqb = gridDim.x;
-  const int qb = nqb - 1 - blockIdx.x;
-  const int head = blockIdx.y, b = blockIdx.z;
+  int bx_, head, b;
+  attn_block_decode(bx_, head, b);
+  const int qb = nqb - 1 - bx_;
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
   const int qw0 = qb * 128 + wave * 32;
   const int qrow = qw0 + r;
@@ -345,7 +418,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
   const int nch = a.dkv_chunks > 1 ? a.dkv_chunks : 1;      // query-list chunks per key block (see OnirisAttnArgs)
-  const int kb = blockIdx.x / nch, chunk = blockIdx.x % nch, head = blockIdx.y, b = blockIdx.z;
+  int bx_, head, b;
+  attn_block_decode(bx_, head, b);
+  const int kb = bx_ / nch, chunk = bx_ % nch;
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
   const int kw0 = kb * 128 + wave * 32;
   const int krow = kw0 + r;
