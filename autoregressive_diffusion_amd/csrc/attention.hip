@@ -136,20 +136,27 @@ __device__ __forceinline__ void attn_block_decode(int& x, int& head, int& b) {
 // registers.  The rows are unpadded (the DMA image is lane-linear), so the 16-byte pieces are XOR-swizzled on the
 // source side: K (read row-wise, ds_read_b128, 16 rows per access group) with (row>>1)&7, V (read through the
 // transposing ds_read_b64_tr_b16, 4 rows x 64 bytes) with 4*bit1(row).
-template <int MODE>
+// KS key streams per workgroup: the 4 waves are 4/KS query waves (32 rows each) x KS streams; stream j walks the key
+// tiles j, j+KS, ... of the block's list (own LDS buffers) and the streams' (O, l) partial results meet in LDS at the
+// end -- without a running max they simply add.  With a causal table the last query blocks have the longest lists
+// and set the launch time; KS = 2 halves that critical path.
+template <int MODE, int KS>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TB = 64 * 128;                     // bytes of one tile
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TB];          // [buffer][K | V]
+  constexpr int QW = 4 / KS, NTS = 64 * QW, NPC = 512 / NTS;      // query waves, threads per stream, pieces per thread and tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KS * 2 * 2 * TB];     // [stream][buffer][K | V]
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int qwv = wave % QW, st = wave / QW, tis = tid % NTS;
   const int nqb = gridDim.x;
   int bx_, head, b;
   attn_block_decode(bx_, head, b);
-  const int qb = nqb - 1 - bx_;                    // heaviest (latest) query blocks first
+  const int qbw = nqb - 1 - bx_;                   // heaviest (latest) query blocks first
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
-  const int qw0 = qb * 128 + wave * 32;
+  const int qw0 = qbw * (32 * QW) + qwv * 32;
   const int qrow = qw0 + r;
+  const int qb = (qbw * (32 * QW)) >> 7;           // 128-token block of the mask table
 
   const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
   bf16x8 qf[4];
@@ -173,12 +180,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
     return kb * 128 + (idx & 1) * 64;
   };
 
-  // DMA descriptors: two 16-byte pieces per thread and tile
+  // DMA descriptors: NPC 16-byte pieces per thread and tile
   constexpr int OOB = (int)0x80000000;
-  int kvo[2], vvo[2], prow[2];
+  int kvo[NPC], vvo[NPC], prow[NPC];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int e = i * 256 + tid, row = e >> 3, pp = e & 7;
+  for (int i = 0; i < NPC; ++i) {
+    const int e = i * NTS + tis, row = e >> 3, pp = e & 7;
     prow[i] = row;
     kvo[i] = (row * C + head * 64 + (pp ^ ((row >> 1) & 7)) * 8) * 2;
     vvo[i] = (row * C + head * 64 + (pp ^ (4 * ((row >> 1) & 1))) * 8) * 2;
@@ -187,13 +194,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   const i32x4 rs_v = make_rsrc((const bf16*)a.v + (size_t)b * Lk * C, Lk * C * 2);
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
   auto issue = [&](int key0, int bsel) __attribute__((always_inline)) {
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + bsel * 2 * TB + wave * 1024);
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (st * 2 + bsel) * 2 * TB + qwv * 1024);
     const int left = Lk - key0, so = key0 * C * 2;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NPC; ++i) {
       const bool ok = prow[i] < left;
-      dma16(rs_k, ok ? kvo[i] : OOB, so, dst + i * 4096);
-      dma16(rs_v, ok ? vvo[i] : OOB, so, dst + TB + i * 4096);
+      dma16(rs_k, ok ? kvo[i] : OOB, so, dst + i * (NTS * 16));
+      dma16(rs_v, ok ? vvo[i] : OOB, so, dst + TB + i * (NTS * 16));
     }
   };
   // fragment addresses
@@ -213,16 +220,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   };
 
   int bsel = 0;
-  if (nsub > 0) issue(key_start(0), 0);
+  if (st < nsub) issue(key_start(st), 0);
+  const int niter = (nsub + KS - 1) / KS;
 #pragma unroll 1
-  for (int idx = 0; idx < nsub; ++idx) {
-    const int key0 = key_start(idx);
+  for (int it = 0; it < niter; ++it) {
+    const int idx = it * KS + st;
+    const bool act = idx < nsub;
+    const int key0 = act ? key_start(idx) : 0;
     dma_wait();
     __syncthreads();                               // tile idx has landed for everybody; buffer bsel^1 is free again
-    if (idx + 1 < nsub) issue(key_start(idx + 1), bsel ^ 1);
-    const unsigned char* Kt = smem + bsel * 2 * TB;
+    if (idx + KS < nsub) issue(key_start(idx + KS), bsel ^ 1);
+    const unsigned char* Kt = smem + (st * 2 + bsel) * 2 * TB;
     const unsigned char* Vt = Kt + TB;
     bsel ^= 1;
+    if (!act) continue;
     int cls = (key0 >= Lk) ? 0 : classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
     if (key0 + 63 >= Lk && cls == 2) cls = 1;
     if (cls == 0 || qw0 >= Lq) continue;
@@ -275,8 +286,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
         for (int dt = 0; dt < 2; ++dt) o[dt] = mfma32(vf[kt][s2][dt], pb, o[dt]);     // O^T[dv][q] += V^T[dv][key] P^T[key][q]
       }
   }
-  if (qrow >= Lq) return;
   float l = l2[0] + l2[1];
+  if constexpr (KS > 1) {                          // stream 1 hands its partial (O, l) to stream 0 through LDS
+    float* red = (float*)smem;                     // [QW][33][64] floats
+    __syncthreads();
+    if (st == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { red[(qwv * 33 + i) * 64 + lane] = o[0][i]; red[(qwv * 33 + 16 + i) * 64 + lane] = o[1][i]; }
+      red[(qwv * 33 + 32) * 64 + lane] = l;
+    }
+    __syncthreads();
+    if (st != 0) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] += red[(qwv * 33 + i) * 64 + lane]; o[1][i] += red[(qwv * 33 + 16 + i) * 64 + lane]; }
+    l += red[(qwv * 33 + 32) * 64 + lane];
+  }
+  if (qrow >= Lq) return;
   l += __shfl_xor(l, 32);                          // the other half of the keys of every tile lives in lane ^ 32
   const float inv = (l > 0.f) ? 1.f / l : 0.f;
   bf16* og = (bf16*)a.out + ((size_t)b * Lq + qrow) * C + head * 64;
@@ -782,8 +807,19 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
   int rc = attn_prepare(args, d, "attn_fwd");
   if (rc) return rc;
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.out, "attn_fwd: null pointer");
-  const dim3 grid(cdiv(d.a.Lq, 128), d.a.heads, d.a.B);
-  ATTN_DISPATCH(attn_fwd_kernel, grid);
+  // two key streams per workgroup (64 query rows) when the key lists are long and causal, else one (128 rows)
+  const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048 && d.a.pad_ == 0;
+  const dim3 grid(cdiv(d.a.Lq, split ? 64 : 128), d.a.heads, d.a.B);
+  if (split) {
+    if (d.a.mask_mode == 1) hipLaunchKernelGGL((attn_fwd_kernel<1, 2>), grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), grid, dim3(256), 0, stream, d);
+  } else {
+    switch (d.a.mask_mode) {
+      case 0: hipLaunchKernelGGL((attn_fwd_kernel<0, 1>), grid, dim3(256), 0, stream, d); break;
+      case 1: hipLaunchKernelGGL((attn_fwd_kernel<1, 1>), grid, dim3(256), 0, stream, d); break;
+      default: hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), grid, dim3(256), 0, stream, d); break;
+    }
+  }
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
