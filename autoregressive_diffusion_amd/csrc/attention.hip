@@ -319,27 +319,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 }
 
 // ================================================================================================================
-// backward: dQ   (same loop structure as the forward, lane = query row)
-template <int MODE>
+// backward: dQ   (the forward's structure: lane = query row, LDS-DMA double-buffered K / V tiles, KS key streams
+// whose partial dQ add up in LDS).  K is read both row-wise (S^T = K.Q^T) and transposed (dQ^T += K^T.dS^T): it is
+// staged once, with the transposing-read swizzle (the row-wise 16-byte reads then take a 4-way bank conflict, which
+// is cheaper than a second copy: LDS is not the limiter here); V is only read row-wise (dP^T = V.dO^T).
+template <int MODE, int KS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW];
-  unsigned char* K_lds = smem;
-  unsigned char* V_lds = smem + 64 * KROW;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TB = 64 * 128;
+  constexpr int QW = 4 / KS, NTS = 64 * QW, NPC = 512 / NTS;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[KS * 2 * 2 * TB];     // [stream][buffer][K | V]
   const OnirisAttnArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const int qwv = wave % QW, st = wave / QW, tis = tid % NTS;
   const int nqb = gridDim.x;
   int bx_, head, b;
   attn_block_decode(bx_, head, b);
-  const int qb = nqb - 1 - bx_;
+  const int qbw = nqb - 1 - bx_;
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
-  const int qw0 = qb * 128 + wave * 32;
+  const int qw0 = qbw * (32 * QW) + qwv * 32;
   const int qrow = qw0 + r;
+  const int qb = (qbw * (32 * QW)) >> 7;
 
   const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
   const bf16* dog = (const bf16*)a.dout + (size_t)b * Lq * C + head * 64;
-  const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
-  const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
-
   bf16x8 qf[4], dof[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -356,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
     lse = a.lse[(size_t)(b * a.heads + head) * Lq + qrow];
     delta = a.delta[(size_t)(b * a.heads + head) * Lq + qrow];
   }
+  asm volatile("" ::"v"(lse), "v"(delta));         // consume the ordinary loads before any LDS-DMA is in flight
   f32x16 dq[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
@@ -368,30 +372,83 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
     const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
     return kb * 128 + (idx & 1) * 64;
   };
-  u32x4 rk[2], rv[2];
-  if (nsub > 0) { const int k0 = key_start(0); tile_load(rk, kg, k0, Lk, C, tid); tile_load(rv, vg, k0, Lk, C, tid); }
+
+  constexpr int OOB = (int)0x80000000;
+  int kvo[NPC], vvo[NPC], prow[NPC];
+#pragma unroll
+  for (int i = 0; i < NPC; ++i) {
+    const int e = i * NTS + tis, row = e >> 3, pp = e & 7;
+    prow[i] = row;
+    kvo[i] = (row * C + head * 64 + (pp ^ (4 * ((row >> 1) & 1))) * 8) * 2;      // K: transposing-read swizzle
+    vvo[i] = (row * C + head * 64 + (pp ^ ((row >> 1) & 7)) * 8) * 2;            // V: row-read swizzle
+  }
+  const i32x4 rs_k = make_rsrc((const bf16*)a.k + (size_t)b * Lk * C, Lk * C * 2);
+  const i32x4 rs_v = make_rsrc((const bf16*)a.v + (size_t)b * Lk * C, Lk * C * 2);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+  auto issue = [&](int key0, int bsel) __attribute__((always_inline)) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (st * 2 + bsel) * 2 * TB + qwv * 1024);
+    const int left = Lk - key0, so = key0 * C * 2;
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+      const bool ok = prow[i] < left;
+      dma16(rs_k, ok ? kvo[i] : OOB, so, dst + i * (NTS * 16));
+      dma16(rs_v, ok ? vvo[i] : OOB, so, dst + TB + i * (NTS * 16));
+    }
+  };
+  // fragment addresses: row reads of K (tr swizzle: piece ^ 4*bit1(row)) and V (piece ^ ((row>>1)&7)); rows kt*32 + r
+  const int kr0 = r * 128 + (((h ^ (4 * ((r >> 1) & 1)))) << 4);          // k-step ks: piece (2ks+h) ^ 4b = ((h ^ 4b) ^ 2ks)
+  const int vr0 = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
+  const int grp = lane >> 4, hh = grp >> 1, q4 = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
+  const int tb0 = (4 * hh + q4) * 128 + pcol * 2, tsw = (q4 >> 1) & 1;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto ktr = [&](const unsigned char* kt_, int tokbase, int dt) __attribute__((always_inline)) {
+    const unsigned char* p0 = kt_ + tb0 + tokbase * 128 + ((dt ^ tsw) * 64);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 128));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
+  int bsel = 0;
+  if (st < nsub) issue(key_start(st), 0);
+  const int niter = (nsub + KS - 1) / KS;
 #pragma unroll 1
-  for (int idx = 0; idx < nsub; ++idx) {
-    const int key0 = key_start(idx);
+  for (int it = 0; it < niter; ++it) {
+    const int idx = it * KS + st;
+    const bool act = idx < nsub;
+    const int key0 = act ? key_start(idx) : 0;
+    dma_wait();
     __syncthreads();
-    tile_store(K_lds, rk, tid);
-    tile_store(V_lds, rv, tid);
-    __syncthreads();
-    if (idx + 1 < nsub) { const int k1 = key_start(idx + 1); tile_load(rk, kg, k1, Lk, C, tid); tile_load(rv, vg, k1, Lk, C, tid); }
+    if (idx + KS < nsub) issue(key_start(idx + KS), bsel ^ 1);
+    const unsigned char* Kt = smem + (st * 2 + bsel) * 2 * TB;
+    const unsigned char* Vt = Kt + TB;
+    bsel ^= 1;
+    if (!act) continue;
     int cls = (key0 >= Lk) ? 0 : classify<MODE>(qw0, qw0 + 31, key0, key0 + 63, d.pshift, a.T, d.qf_off);
     if (key0 + 63 >= Lk && cls == 2) cls = 1;
     if (cls == 0 || qw0 >= Lq) continue;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
+      bf16x8 kf[4], vf[4], ktf[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *(const bf16x8*)(Kt + ((kr0 ^ (ks * 32)) + kt * 4096));
+        vf[ks] = *(const bf16x8*)(Vt + ((vr0 ^ (ks * 32)) + kt * 4096));
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) ktf[s2][dt] = ktr(Kt, kt * 32 + 16 * s2, dt);
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 kf = *(const bf16x8*)(K_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
-        s = mfma32(kf, qf[ks], s);
-        const bf16x8 vf = *(const bf16x8*)(V_lds + (kt * 32 + r) * KROW + ks * 32 + h * 16);
-        dp = mfma32(vf, dof[ks], dp);
+        s = mfma32(kf[ks], qf[ks], s);
+        dp = mfma32(vf[ks], dof[ks], dp);
       }
       auto dsoft = [&](auto masked_) __attribute__((always_inline)) {
         constexpr bool MASKED = decltype(masked_)::value;
@@ -411,12 +468,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
       for (int s2 = 0; s2 < 2; ++s2) {
         const bf16x8 db = pack8(s, s2);
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 ktf = trfrag(K_lds, kt * 32 + 16 * s2, dt * 32, lane);
-          dq[dt] = mfma32(ktf, db, dq[dt]);              // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
-        }
+        for (int dt = 0; dt < 2; ++dt) dq[dt] = mfma32(ktf[s2][dt], db, dq[dt]);     // dQ^T[d][q] += K^T[d][key] dS^T[key][q]
       }
     }
+  }
+  if constexpr (KS > 1) {
+    float* red = (float*)smem;                     // [QW][32][64] floats
+    __syncthreads();
+    if (st == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { red[(qwv * 32 + i) * 64 + lane] = dq[0][i]; red[(qwv * 32 + 16 + i) * 64 + lane] = dq[1][i]; }
+    }
+    __syncthreads();
+    if (st != 0) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dq[0][i] += red[(qwv * 32 + i) * 64 + lane]; dq[1][i] += red[(qwv * 32 + 16 + i) * 64 + lane]; }
   }
   if (qrow >= Lq) return;
   bf16* og = (bf16*)a.dq + ((size_t)b * Lq + qrow) * C + head * 64;
@@ -429,6 +495,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
       for (int k = 0; k < 4; ++k) ov[k] = f2bf(dq[dt][4 * g + k]);
       *(bf16x4*)(og + dt * 32 + 8 * g + 4 * h) = ov;
     }
+#endif
 }
 
 // ================================================================================================================
@@ -831,8 +898,18 @@ extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t st
   if (rc) return rc;
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.dout && d.a.lse && d.a.delta && d.a.dq,
                    "attn_bwd_dq: null pointer");
-  const dim3 grid(cdiv(d.a.Lq, 128), d.a.heads, d.a.B);
-  ATTN_DISPATCH(attn_bwd_dq_kernel, grid);
+  const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048;
+  const dim3 grid(cdiv(d.a.Lq, split ? 64 : 128), d.a.heads, d.a.B);
+  if (split) {
+    if (d.a.mask_mode == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 2>), grid, dim3(256), 0, stream, d);
+    else hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 2>), grid, dim3(256), 0, stream, d);
+  } else {
+    switch (d.a.mask_mode) {
+      case 0: hipLaunchKernelGGL((attn_bwd_dq_kernel<0, 1>), grid, dim3(256), 0, stream, d); break;
+      case 1: hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 1>), grid, dim3(256), 0, stream, d); break;
+      default: hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1>), grid, dim3(256), 0, stream, d); break;
+    }
+  }
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
