@@ -499,16 +499,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
 }
 
 // ================================================================================================================
-// backward: dK, dV   (lane = key)
+// backward: dK, dV   (lane = key).  Q / dO tiles (64 queries) and the tile's lse / delta go global -> LDS by LDS-DMA
+// into two alternating buffers (one barrier per tile); both tiles are read row-wise (S = Q.K^T, dP = dO.V^T) and
+// transposed (dK^T += Q^T.dS, dV^T += dO^T.P) and carry the transposing-read swizzle.
 template <int MODE>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 64 * KROW + 2 * 64 * 4];
-  unsigned char* Q_lds = smem;
-  unsigned char* dO_lds = smem + 64 * KROW;
-  float* lse_lds = (float*)(smem + 2 * 64 * KROW);
-  float* del_lds = lse_lds + 64;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TB = 64 * 128, BUFB = 2 * TB + 512;        // Q | dO | lse[64] delta[64]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUFB];
   const OnirisAttnArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;   // (wave as an SGPR: the tile classification and its branches are scalar)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int nch = a.dkv_chunks > 1 ? a.dkv_chunks : 1;      // query-list chunks per key block (see OnirisAttnArgs)
   int bx_, head, b;
   attn_block_decode(bx_, head, b);
@@ -517,13 +517,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
   const int kw0 = kb * 128 + wave * 32;
   const int krow = kw0 + r;
 
-  const bf16* qg = (const bf16*)a.q + (size_t)b * Lq * C + head * 64;
-  const bf16* dog = (const bf16*)a.dout + (size_t)b * Lq * C + head * 64;
   const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
   const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
-  const float* lseg = a.lse + (size_t)(b * a.heads + head) * Lq;
-  const float* delg = a.delta + (size_t)(b * a.heads + head) * Lq;
-
   bf16x8 kf[4], vf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
@@ -534,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
     }
     kf[ks] = __builtin_bit_cast(bf16x8, v);
     vf[ks] = __builtin_bit_cast(bf16x8, w);
+    asm volatile("" ::"v"(kf[ks]), "v"(vf[ks]));    // consume the ordinary loads before any LDS-DMA is in flight
   }
   f32x16 dk[2], dv[2];
 #pragma unroll
@@ -547,26 +543,67 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
     const int qblk = a.q_idx ? ((a.q_idx[(size_t)trow * a.qtab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
     return qblk * 128 + (idx & 1) * 64;
   };
-  u32x4 rq[2], rdo[2];
-  float rstat = 0.f;
-  auto load_sub = [&](int q0) __attribute__((always_inline)) {
-    tile_load(rq, qg, q0, Lq, C, tid);
-    tile_load(rdo, dog, q0, Lq, C, tid);
-    rstat = 0.f;
-    if (tid < 64) { if (q0 + tid < Lq) rstat = lseg[q0 + tid]; }
-    else if (tid < 128) { if (q0 + tid - 64 < Lq) rstat = delg[q0 + tid - 64]; }
+
+  constexpr int OOB = (int)0x80000000;
+  int tvo[2], prow[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int e = i * 256 + tid, row = e >> 3, pp = e & 7;
+    prow[i] = row;
+    tvo[i] = (row * C + head * 64 + (pp ^ (4 * ((row >> 1) & 1))) * 8) * 2;
+  }
+  const i32x4 rs_q = make_rsrc((const bf16*)a.q + (size_t)b * Lq * C, Lq * C * 2);
+  const i32x4 rs_do = make_rsrc((const bf16*)a.dout + (size_t)b * Lq * C, Lq * C * 2);
+  const i32x4 rs_l = make_rsrc(a.lse + (size_t)(b * a.heads + head) * Lq, Lq * 4);
+  const i32x4 rs_d = make_rsrc(a.delta + (size_t)(b * a.heads + head) * Lq, Lq * 4);
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+  auto issue = [&](int q0, int bsel) __attribute__((always_inline)) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + bsel * BUFB + wave * 1024);
+    const int left = Lq - q0, so = q0 * C * 2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool ok = prow[i] < left;
+      dma16(rs_q, ok ? tvo[i] : OOB, so, dst + i * 4096);
+      dma16(rs_do, ok ? tvo[i] : OOB, so, dst + TB + i * 4096);
+    }
+    if (wave == 0) {                               // lanes 0..15: lse[q0..q0+63], lanes 16..31: delta (16 B per lane)
+      const unsigned sdst = __builtin_amdgcn_readfirstlane(lds0 + bsel * BUFB + 2 * TB);
+      const int l16 = lane & 15;
+      const int vo = (l16 * 4 < left) ? l16 * 16 : OOB;
+      if (lane < 16) dma16(rs_l, vo, q0 * 4, sdst);
+      else if (lane < 32) dma16(rs_d, vo, q0 * 4, sdst);
+    }
   };
+  // row fragments (rows qt*32 + r, 4-way conflict with this swizzle) and transposed fragments
+  const int rr0 = r * 128 + ((h ^ (4 * ((r >> 1) & 1))) << 4);
+  const int grp = lane >> 4, hh = grp >> 1, q4 = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
+  const int tb0 = (4 * hh + q4) * 128 + pcol * 2, tsw = (q4 >> 1) & 1;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  auto ttr = [&](const unsigned char* t_, int tokbase, int dt) __attribute__((always_inline)) {
+    const unsigned char* p0 = t_ + tb0 + tokbase * 128 + ((dt ^ tsw) * 64);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 128));
+    s16x8 v;
+    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, v);
+  };
+
   const int i0 = (int)((long long)nsub * chunk / nch), i1 = (int)((long long)nsub * (chunk + 1) / nch);
-  if (i0 < i1) load_sub(q_start(i0));
+  int bsel = 0;
+  if (i0 < i1) issue(q_start(i0), 0);
 #pragma unroll 1
   for (int idx = i0; idx < i1; ++idx) {
     const int q0 = q_start(idx);
+    dma_wait();
     __syncthreads();
-    tile_store(Q_lds, rq, tid);
-    tile_store(dO_lds, rdo, tid);
-    if (tid < 128) lse_lds[tid] = rstat;            // lse_lds[0..63] | del_lds[0..63] are contiguous
-    __syncthreads();
-    if (idx + 1 < i1) load_sub(q_start(idx + 1));
+    if (idx + 1 < i1) issue(q_start(idx + 1), bsel ^ 1);
+    const unsigned char* Qt = smem + bsel * BUFB;
+    const unsigned char* dOt = Qt + TB;
+    const float* lse_lds = (const float*)(Qt + 2 * TB);
+    const float* del_lds = lse_lds + 64;
+    bsel ^= 1;
     if (kw0 >= Lk || q0 >= Lq) continue;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
@@ -574,15 +611,26 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
       int cls = classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off);
       if ((qq0 + 31 >= Lq || kw0 + 31 >= Lk) && cls == 2) cls = 1;
       if (cls == 0 || qq0 >= Lq) continue;
+      bf16x8 qa[4], da[4], dotf[2][2], qtf[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qa[ks] = *(const bf16x8*)(Qt + ((rr0 ^ (ks * 32)) + qt * 4096));
+        da[ks] = *(const bf16x8*)(dOt + ((rr0 ^ (ks * 32)) + qt * 4096));
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dotf[s2][dt] = ttr(dOt, qt * 32 + 16 * s2, dt);
+          qtf[s2][dt] = ttr(Qt, qt * 32 + 16 * s2, dt);
+        }
       f32x16 s, dp;
 #pragma unroll
       for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
-        const bf16x8 qa = *(const bf16x8*)(Q_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
-        s = mfma32(qa, kf[ks], s);                       // S[q][key]
-        const bf16x8 da = *(const bf16x8*)(dO_lds + (qt * 32 + r) * KROW + ks * 32 + h * 16);
-        dp = mfma32(da, vf[ks], dp);                     // dP[q][key]
+        s = mfma32(qa[ks], kf[ks], s);                   // S[q][key]
+        dp = mfma32(da[ks], vf[ks], dp);                 // dP[q][key]
       }
       f32x16 pv;
       auto dsoft = [&](auto masked_) __attribute__((always_inline)) {
@@ -613,10 +661,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
         const bf16x8 db = pack8(s, s2);
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          const bf16x8 dof = trfrag(dO_lds, qt * 32 + 16 * s2, dt * 32, lane);
-          dv[dt] = mfma32(dof, pb, dv[dt]);              // dV^T[dv][key] += dO^T[dv][q] P[q][key]
-          const bf16x8 qtf = trfrag(Q_lds, qt * 32 + 16 * s2, dt * 32, lane);
-          dk[dt] = mfma32(qtf, db, dk[dt]);              // dK^T[d][key]  += Q^T[d][q] dS[q][key]
+          dv[dt] = mfma32(dotf[s2][dt], pb, dv[dt]);     // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+          dk[dt] = mfma32(qtf[s2][dt], db, dk[dt]);      // dK^T[d][key]  += Q^T[d][q] dS[q][key]
         }
       }
     }
@@ -647,6 +693,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
       *(bf16x4*)(dkg + dt * 32 + 8 * g + 4 * h) = o1;
       *(bf16x4*)(dvg + dt * 32 + 8 * g + 4 * h) = o2;
     }
+#endif
 }
 
 // dk|dv = sum over the chunks (in chunk order) of the fp32 partials; 8 elements per thread
