@@ -318,6 +318,24 @@ class KernelProfile:
         return agg
 
 
+def _profiled(key, flops, fn):
+    """Run fn() (a kernel launch on the current stream); when KernelProfile is on, bracket it with HIP events."""
+    if not KernelProfile.enabled:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    KernelProfile.records.append((key, flops, e0, e1))
+
+
+def _attn_flops(kind, B, T, heads, L, P):
+    """Algorithmic FLOPs of ONE product pair (QK^T + PV) over the unmasked token pairs: video training mask
+    T(T+1) frame pairs x P^2, dense per-frame attention L^2 per frame."""
+    pairs = (T * (T + 1) * P * P * B) if kind == "video" else (B * L * L)
+    return 4.0 * 64 * heads * pairs
+
+
 def _patch_w(W):
     return 16 if W >= 16 else W
 
@@ -829,7 +847,10 @@ class _AttentionFn(torch.autograd.Function):
         out = torch.empty((N, P, C), dtype=BF16, device=dev)
         lse = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
         a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
-        check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+        fl = _attn_flops(kind, Bq, T, heads, L, P)
+        ks = 2 if (mask_mode != 0 and L >= 2048) else 1
+        _profiled(f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>", fl,
+                  lambda: check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd"))
         ctx.meta = (kind, B, T, heads, Bq, L, frames, P, C, mask_mode)
         ctx.tabs, ctx.tabs_r = tabs, tabs_r
         ctx.save_for_backward(qkv, qr, kr, v, out, lse)
@@ -847,13 +868,17 @@ class _AttentionFn(torch.autograd.Function):
         dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
         a = _attn_args(qr, kr, v, None, None, None, out, lse, ctx.tabs, Bq, heads, L, L, C, mask_mode, P, T)
         a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
-        check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq")
+        fl = _attn_flops(kind, Bq, T, heads, L, P)
+        ks = 2 if (mask_mode != 0 and L >= 2048) else 1
+        _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
+                  lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
         # causal tables: split every key block's query list so that no workgroup walks more than ~32 sub-tiles
         nch = max(1, min(ATTN_DKV_CHUNKS, L // ATTN_DKV_MIN_L)) if mask_mode == 2 else 1
         if nch > 1:
             part = torch.empty((2, nch, Bq, L, C), dtype=torch.float32, device=dev)
             a.dkv_part, a.dkv_chunks = _p(part), nch
-        check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv")
+        _profiled(f"attn_bwd_dkv_kernel<MODE={mask_mode}>", 2.0 * fl,
+                  lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))     # (+ the partial-sum reduce)
         if kind == "video":
             dqn, dkn = torch.empty_like(dq), torch.empty_like(dk)
             _rope(dq, dqn, None, ctx.tabs_r, 3, Bq, frames, P, C, 0, T)
