@@ -174,10 +174,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   const int trow = qb >> d.tshift, tmask = (1 << d.tshift) - 1;
   const int nkv = a.kv_num ? (a.kv_num[trow] << d.tshift) : (Lk + 127) / 128;
   const int nsub = nkv * 2;
+  // the row's block list sits in one VGPR (lane i = entry i; rows with more than 64 entries fall back to memory):
+  // a scalar load per tile put ~1 us of load latency into every iteration
+  const int nent = a.kv_num ? a.kv_num[trow] : 0;
+  const int kvl = (a.kv_idx && lane < nent) ? a.kv_idx[(size_t)trow * a.tab_cols + lane] : 0;
+  asm volatile("" ::"v"(kvl));                      // consume the ordinary load before any LDS-DMA is in flight
   auto key_start = [&](int idx) __attribute__((always_inline)) {
-    const int j = idx >> 1;
-    const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
-    return kb * 128 + (idx & 1) * 64;
+    const int j = idx >> 1, jj = j >> d.tshift;
+    int e = j;
+    if (a.kv_idx) e = ((nent <= 64 ? __builtin_amdgcn_readlane(kvl, jj) : a.kv_idx[(size_t)trow * a.tab_cols + jj]) << d.tshift) + (j & tmask);
+    return e * 128 + (idx & 1) * 64;
   };
 
   // DMA descriptors: NPC 16-byte pieces per thread and tile
@@ -367,10 +373,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
   const int trow = qb >> d.tshift, tmask = (1 << d.tshift) - 1;
   const int nkv = a.kv_num ? (a.kv_num[trow] << d.tshift) : (Lk + 127) / 128;
   const int nsub = nkv * 2;
+  // the row's block list sits in one VGPR (lane i = entry i; rows with more than 64 entries fall back to memory):
+  // a scalar load per tile put ~1 us of load latency into every iteration
+  const int nent = a.kv_num ? a.kv_num[trow] : 0;
+  const int kvl = (a.kv_idx && lane < nent) ? a.kv_idx[(size_t)trow * a.tab_cols + lane] : 0;
+  asm volatile("" ::"v"(kvl));                      // consume the ordinary load before any LDS-DMA is in flight
   auto key_start = [&](int idx) __attribute__((always_inline)) {
-    const int j = idx >> 1;
-    const int kb = a.kv_idx ? ((a.kv_idx[(size_t)trow * a.tab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
-    return kb * 128 + (idx & 1) * 64;
+    const int j = idx >> 1, jj = j >> d.tshift;
+    int e = j;
+    if (a.kv_idx) e = ((nent <= 64 ? __builtin_amdgcn_readlane(kvl, jj) : a.kv_idx[(size_t)trow * a.tab_cols + jj]) << d.tshift) + (j & tmask);
+    return e * 128 + (idx & 1) * 64;
   };
 
   constexpr int OOB = (int)0x80000000;
@@ -538,10 +550,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
   const int trow = kb >> d.tshift, tmask = (1 << d.tshift) - 1;
   const int nq = a.q_num ? (a.q_num[trow] << d.tshift) : (Lq + 127) / 128;
   const int nsub = nq * 2;
+  const int nent = a.q_num ? a.q_num[trow] : 0;      // (the row's block list in one VGPR: see attn_fwd_kernel)
+  const int qvl = (a.q_idx && lane < nent) ? a.q_idx[(size_t)trow * a.qtab_cols + lane] : 0;
+  asm volatile("" ::"v"(qvl));
   auto q_start = [&](int idx) __attribute__((always_inline)) {
-    const int j = idx >> 1;
-    const int qblk = a.q_idx ? ((a.q_idx[(size_t)trow * a.qtab_cols + (j >> d.tshift)] << d.tshift) + (j & tmask)) : j;
-    return qblk * 128 + (idx & 1) * 64;
+    const int j = idx >> 1, jj = j >> d.tshift;
+    int e = j;
+    if (a.q_idx) e = ((nent <= 64 ? __builtin_amdgcn_readlane(qvl, jj) : a.q_idx[(size_t)trow * a.qtab_cols + jj]) << d.tshift) + (j & tmask);
+    return e * 128 + (idx & 1) * 64;
   };
 
   constexpr int OOB = (int)0x80000000;
