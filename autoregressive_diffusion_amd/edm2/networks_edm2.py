@@ -164,6 +164,8 @@ class UNet(BetterModule):
             cs = dict(zip(map(id, blocks), ops.emb_scales(emb, self.__dict__["_oniris_groups"][0],
                                                           [b.emb_gain for b in blocks])))
             skips = []
+            stage_cb = self.__dict__.get("_oniris_stage_cb")
+            stage_at = self.__dict__.get("_oniris_stage_at") if stage_cb is not None else None
             for name, block in self.enc.items():
                 if isinstance(block, Block):
                     xcl, cache["enc", name] = block._cl(xcl, emb, B, c_noise, cache.get(("enc", name)), update_cache, just_2d,
@@ -171,6 +173,8 @@ class UNet(BetterModule):
                 else:
                     xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
                 skips.append(xcl)
+                if name == stage_at and xcl.requires_grad:            # everything downstream of here is final when
+                    xcl.register_hook(stage_cb)                       # this gradient arrives (OnirisDDP stage 1)
             for name, block in self.dec.items():
                 skip, cat_w = None, None
                 if "block" in name:                                   # mp_cat(x, skip, t) fused into the block's act kernel
@@ -191,6 +195,34 @@ class UNet(BetterModule):
     def _oniris_weight_groups(self):
         """Weights packed row-concatenated (one GEMM for all): every Block's emb_linear reads the same embedding."""
         return [[b.emb_linear.weight for b in self._emb_blocks()]]
+
+    def _oniris_overlap_plan(self, head_frac=0.12):
+        """(name of an encoder block, [parameters]) for OnirisDDP's early gradient exchange: the kernel-owned weights
+        (their .grad is written by weight_bwd, not by autograd) of every block AFTER the named one are final as soon
+        as the backward pass has produced the gradient of that block's output -- the backward of the remaining,
+        activation-heavy encoder levels then overlaps their all-reduce.  The boundary is the last encoder block up to
+        which at most `head_frac` of the kernel-owned parameters live.  Everything autograd accumulates itself (gates,
+        emb_gain: evaluated once for all blocks at the top of forward; the grouped emb_linear weights) stays in the
+        final exchange."""
+        from .conv import NormalizedWeight
+
+        def owned(mod, skip=()):
+            return [m.weight for m in mod.modules() if isinstance(m, NormalizedWeight) and id(m.weight) not in skip]
+        late = {id(b.emb_linear.weight.weight) for b in self._emb_blocks()}
+        names = list(self.enc.keys())
+        per = [owned(self.enc[n], late) for n in names]
+        tail_dec = [w for b in self.dec.values() for w in owned(b, late)] + owned(self.out_conv, late)
+        total = sum(w.numel() for ws in per for w in ws) + sum(w.numel() for w in tail_dec)
+        cum, at = 0, None
+        for i, ws in enumerate(per):
+            cum += sum(w.numel() for w in ws)
+            if cum > head_frac * total:
+                break
+            at = i
+        if at is None:
+            return None
+        early = [w for ws in per[at + 1:] for w in ws] + tail_dec
+        return names[at], [w for w in early if w.requires_grad]
 
     def _prime_gates(self, c_noise, cache):
         """Evaluate the gates of all gated convs at once and hand each layer its (ca, cb, counter)."""

@@ -25,6 +25,15 @@ class FlatParams:
         multi-tensor call (called by OnirisDDP at the end of backward and by FlatAdamW.step)."""
         self.params = [p for p in module.parameters() if p.requires_grad]
         assert self.params, "no trainable parameters"
+        # parameters whose gradient is final early in backward (module._oniris_overlap_plan) go, contiguous, to the
+        # END of the buffers: OnirisDDP exchanges [tail_start, numel) while the rest of backward is still running
+        plan = module._oniris_overlap_plan() if hasattr(module, "_oniris_overlap_plan") else None
+        self.stage_at, ntail = None, 0
+        if plan is not None and plan[1]:
+            tail = {id(p) for p in plan[1]}
+            head = [p for p in self.params if id(p) not in tail]
+            self.params = head + [p for p in self.params if id(p) in tail]
+            self.stage_at, ntail = plan[0], len(self.params) - len(head)
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.dtype == dt and p.device == dev for p in self.params)
         sizes = [p.numel() for p in self.params]
@@ -33,6 +42,7 @@ class FlatParams:
             self.offsets.append(off)
             off += (n + 3) // 4 * 4                      # 16-byte aligned slices
         self.numel = off
+        self.tail_start = self.offsets[len(self.params) - ntail] if ntail else off
         self.flat = torch.zeros(off, dtype=dt, device=dev)
         self.grad = torch.zeros(off, dtype=dt, device=dev)
         with torch.no_grad():
@@ -87,6 +97,10 @@ class OnirisDDP(nn.Module):
         self._sync_enabled = True
         self._queued = False
         self._works = []
+        self._tail_sent = False
+        if self.flat.stage_at is not None:               # early exchange of the tail (see FlatParams / _stage)
+            module.__dict__["_oniris_stage_at"] = self.flat.stage_at
+            module.__dict__["_oniris_stage_cb"] = self._stage
         # every rank starts from rank 0's parameters (what torch DDP does at construction)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self.flat.flat, src=0, group=self.process_group)
@@ -111,6 +125,24 @@ class OnirisDDP(nn.Module):
             torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
         return grad
 
+    def _active(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.process_group) > 1 or getattr(self, "force_collectives", False)
+
+    def _stage(self, grad):
+        """Tensor hook on the output of encoder block `flat.stage_at` (fires in the middle of backward): the weights
+        of every later block have all their wgrad slabs, so turn them into parameter gradients now (weight_bwd skips
+        weights with no pending slab) and start their all-reduce; RCCL runs it on its own stream, beside the backward
+        kernels of the remaining encoder levels."""
+        if self._sync_enabled and self._active() and not self._tail_sent:
+            bank = self.module.__dict__.get("_oniris_bank")
+            if bank is not None:
+                bank.backward()
+            self._exchange(self.flat.tail_start, self.flat.numel)
+            self._tail_sent = True
+        return None
+
     def _end_of_backward(self):
         self._queued = False
         if not self._sync_enabled:
@@ -121,16 +153,22 @@ class OnirisDDP(nn.Module):
         self.flat.gather()
         self.allreduce_grads()
 
-    def allreduce_grads(self):
-        if not (dist.is_available() and dist.is_initialized()):
-            return
-        world = dist.get_world_size(self.process_group)
-        if world == 1 and not getattr(self, "force_collectives", False):
-            return
+    def _exchange(self, lo, hi):
         g = self.flat.grad
-        g.mul_(1.0 / world)
-        self._works = [dist.all_reduce(g[s:s + self.bucket_elems], op=dist.ReduceOp.SUM, group=self.process_group,
-                                       async_op=True) for s in range(0, g.numel(), self.bucket_elems)]
+        world = dist.get_world_size(self.process_group)
+        avg = g.is_cuda                                  # RCCL averages in the collective; gloo has no AVG
+        if not avg:
+            g[lo:hi].mul_(1.0 / world)
+        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
+        self._works += [dist.all_reduce(g[s:min(hi, s + self.bucket_elems)], op=op, group=self.process_group,
+                                        async_op=True) for s in range(lo, hi, self.bucket_elems)]
+
+    def allreduce_grads(self):
+        """Exchange whatever `_stage` has not sent yet (everything, when no stage fired in this backward)."""
+        sent, self._tail_sent = self._tail_sent, False
+        if not self._active():
+            return
+        self._exchange(0, self.flat.tail_start if sent else self.flat.numel)
 
     def wait(self):
         """Block the current stream until the gradient exchange is done (call before the optimizer step)."""

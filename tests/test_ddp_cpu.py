@@ -23,14 +23,36 @@ class Net(nn.Module):
         return self.b(torch.tanh(self.a(x))), None
 
 
-def _worker(rank, world, port, q):
+class StagedNet(Net):
+    """Same maths, plus the two hooks a module offers OnirisDDP for the early (overlapped) exchange: the parameters
+    of `b` are final once the gradient of the hidden activation exists (UNet._oniris_overlap_plan / stage hook)."""
+    stage_calls = 0
+
+    def _oniris_overlap_plan(self):
+        return "hidden", list(self.b.parameters())
+
+    def forward(self, x):
+        h = torch.tanh(self.a(x))
+        cb = self.__dict__.get("_oniris_stage_cb")
+        if cb is not None and h.requires_grad:
+            def hook(g):
+                StagedNet.stage_calls += 1
+                return cb(g)
+            h.register_hook(hook)
+        return self.b(h), None
+
+
+def _worker(rank, world, port, q, staged=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from autoregressive_diffusion_amd.parallel import OnirisDDP, FlatAdamW
     torch.manual_seed(100 + rank)               # different init per rank: the wrapper must broadcast rank 0's
-    net = Net()
+    net = StagedNet() if staged else Net()
     ddp = OnirisDDP(net, bucket_mb=1e-4)        # tiny buckets -> several all-reduces
     assert ddp.flat.check()
+    if staged:                                  # b's parameters sit at the end of the flat buffers
+        assert ddp.flat.stage_at == "hidden" and 0 < ddp.flat.tail_start < ddp.flat.numel
+        assert [id(p) for p in ddp.flat.params[-2:]] == [id(p) for p in net.b.parameters()]
     opt = FlatAdamW(ddp.flat, lr=1e-2, weight_decay=0.0)
     g = torch.Generator().manual_seed(7)
     data = torch.randn(4, 5, 6, generator=g)    # 4 micro-batches: rank r takes 2r, 2r+1
@@ -39,20 +61,27 @@ def _worker(rank, world, port, q):
     with ddp.no_sync():
         out, _ = ddp(data[2 * rank]); out.pow(2).mean().backward()
     out, _ = ddp(data[2 * rank + 1]); out.pow(2).mean().backward()
+    if staged:                                  # the stage hook ran in both backwards, exchanged only in the synced one
+        assert StagedNet.stage_calls == 2 and not ddp._tail_sent and len(ddp._works) > 2
     ddp.wait()
     grad = ddp.flat.grad.clone()
     opt.step()
+    names = {id(p): n for n, p in net.named_parameters()}
     q.put((rank, {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}, grad.numpy().copy(),
-           list(ddp.flat.offsets)))
+           [(names[id(p)], o) for p, o in zip(ddp.flat.params, ddp.flat.offsets)]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_ddp_gloo_world2():
+import pytest
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_ddp_gloo_world2(staged):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, staged)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
@@ -71,8 +100,9 @@ def test_ddp_gloo_world2():
     data = torch.randn(4, 5, 6, generator=g)
     for i in range(4):
         out, _ = ref(data[i]); (out.pow(2).mean() / 2).backward()
-    params = [p for p in ref.parameters()]
-    for p, o in zip(params, offs):
+    params = dict(ref.named_parameters())
+    for name, o in offs:
+        p = params[name]
         got = g0[o:o + p.numel()].view_as(p)
         want = p.grad if p.grad is not None else torch.zeros_like(p)
         assert torch.allclose(got, want, atol=1e-6), "reduced gradient != mean of per-rank accumulated gradients"
