@@ -22,6 +22,11 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 GYM_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=32, channel_mult=[1, 2, 4, 8],
                channel_mult_noise=None, channel_mult_emb=None, num_blocks=2, video_attn_resolutions=[8],
                frame_attn_resolutions=[16])
+CS_CFG = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=128, channel_mult=[1, 2, 4, 4],
+              channel_mult_noise=None, channel_mult_emb=None, num_blocks=2, video_attn_resolutions=[4],
+              frame_attn_resolutions=[8])                       # cs_train.py:35-45 (BASELINE configs 3/4), 310.0 M
+
+
 def _pmc_traffic(key):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench, summarised by
@@ -110,7 +115,10 @@ def main():
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=2, help="sequences per GPU (weak scaling)")
-    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 64 gym / 32 cs)")
+    ap.add_argument("--net", choices=["gym", "cs"], default="gym",
+                    help="gym = BASELINE configs[1] (the headline metric); cs = the Counter-Strike net of configs[2]/[3] "
+                         "(32x32 latents, 310 M parameters, no conditioning) as an extra measurement")
     ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -121,6 +129,8 @@ def main():
                     help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
     ap.add_argument("--gen-frames", type=int, default=8)
     args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 64 if args.net == "gym" else 32
     if args.mode == "rollout":
         return rollout(args)
 
@@ -146,7 +156,8 @@ def main():
     from autoregressive_diffusion_amd import ops
 
     torch.manual_seed(0)
-    unet = UNet(**GYM_CFG).to(dev)
+    cs = args.net == "cs"
+    unet = UNet(**(CS_CFG if cs else GYM_CFG)).to(dev)
     for m in unet.modules():                      # give the zero-initialised gains a value so every branch carries signal
         if hasattr(m, "emb_gain"):
             torch.nn.init.constant_(m.emb_gain, 0.3)
@@ -157,12 +168,14 @@ def main():
         model.force_collectives = True
     net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
     opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
-    loss_fn = EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5)   # gym_train.py:66-67
+    loss_fn = (EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1) if cs else   # cs_train.py:75
+               EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5))         # gym_train.py:66-67
 
     B, T = args.batch, args.frames
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    latents = torch.randn(B, T, 8, 64, 64, device=dev, generator=g)
-    actions = torch.randint(0, 4, (B, T), device=dev, generator=g)
+    res = unet.img_resolution
+    latents = torch.randn(B, T, 8, res, res, device=dev, generator=g)
+    actions = None if cs else torch.randint(0, 4, (B, T), device=dev, generator=g)      # cs_train.py:103 conditioning=None
 
     def fwd_bwd(just_2d):
         opt.zero_grad()
@@ -263,7 +276,7 @@ def main():
         for i in range(4):
             step(i, profile=True)                                 # keep collectives matched across ranks
     cpu = None
-    if rank == 0 and world == 1 and args.cpu_frames > 0:
+    if rank == 0 and world == 1 and args.cpu_frames > 0 and not cs:
         cpu = cpu_baseline(args.cpu_frames)
     if world > 1:
         dist.barrier()
@@ -274,7 +287,8 @@ def main():
                "value": frames / dt, "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), "
+               "config": {"workload": (f"Counter-Strike latents {T}-frame seq, EDM2 UNet 310.0M (cs_train.py:35-45), " if cs else
+                                       f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), ") +
                                       f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + AdamW, 3:1 mix of "
                                       f"3-D/2-D steps", "global_batch": world * B, "seq_len": T,
                           "parallelism": f"dp{world}", "hip_graph": bool(use_graph),

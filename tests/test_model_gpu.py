@@ -221,37 +221,51 @@ def test_g9_sampler_rollout():
     assert e0 < 2e-2 and max(errs) < 5e-2
 
 
-def test_cs_shaped_unet_vs_oracle():
-    """Counter-Strike-shaped net (cs_train.py:35-45 topology at reduced width): 32x32 latents, video attention at 4x4
-    (P = 16 -> 8 frames per 128-token block: the BlockMask quirk F2 at its strongest), no conditioning, T = 8."""
+CS_SMALL = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=32, channel_mult=[1, 2, 4, 4],
+                num_blocks=1, video_attn_resolutions=[4], frame_attn_resolutions=[8])
+CS_FULL = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=128, channel_mult=[1, 2, 4, 4],
+               num_blocks=2, video_attn_resolutions=[4], frame_attn_resolutions=[8])          # cs_train.py:35-45, 310.0 M
+GYM_FULL = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=32, channel_mult=[1, 2, 4, 8],
+                num_blocks=2, video_attn_resolutions=[8], frame_attn_resolutions=[16])        # gym_train.py:37-47, 46.2 M
+
+
+@pytest.mark.parametrize("tag,cfg,Tn,labelled", [("cs-shaped", CS_SMALL, 8, False), ("cs-full-net", CS_FULL, 8, False),
+                                                 ("gym-full-net", GYM_FULL, 8, True)])
+def test_cs_shaped_unet_vs_oracle(tag, cfg, Tn, labelled):
+    """One 3-D training step (loss + every weight gradient) against the fp32 oracle on the same parameters and noise.
+    cs-shaped: Counter-Strike topology (cs_train.py:35-45) at reduced width: 32x32 latents, video attention at 4x4
+    (P = 16 -> 8 frames per 128-token block: the BlockMask quirk F2 at its strongest), no conditioning.
+    cs-full-net / gym-full-net: the FULL nets of BASELINE configs[2] and configs[1] (310.0 M / 46.2 M parameters, every
+    kernel variant the bench launches) on a short sequence, which is what the CPU oracle finishes in seconds."""
     from oracle import oniris_oracle as O
     from edm2.networks_edm2 import UNet, Precond
     from edm2.loss import EDM2Loss
-    cfg = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=32, channel_mult=[1, 2, 4, 4],
-               num_blocks=1, video_attn_resolutions=[4], frame_attn_resolutions=[8])
+    res = cfg["img_resolution"]
     p = paramgen.prenormalise(paramgen.precond_params(cfg, 303))
     net = load_params(Precond(UNet(**cfg), sigma_data=1.0), p).train()
     g = torch.Generator().manual_seed(304)
-    B, Tn = 1, 8
-    images = torch.randn(B, Tn, 8, 32, 32, generator=g)
+    B = 1
+    images = torch.randn(B, Tn, 8, res, res, generator=g)
+    labels = torch.randint(0, 4, (B, Tn), generator=g) if labelled else None
     sigma = (torch.randn(B, 2 * Tn, generator=g) + 0.9).exp()
     sigma[:, :Tn] = torch.rand(B, 1, generator=g) * 0.1
-    eps = torch.randn(B, 2 * Tn, 8, 32, 32, generator=g)
+    eps = torch.randn(B, 2 * Tn, 8, res, res, generator=g)
     loss, _ = EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1)(
-        net, images.to(DEV), None, sigma=sigma.to(DEV), noise=eps.to(DEV))
+        net, images.to(DEV), labels.to(DEV) if labelled else None, sigma=sigma.to(DEV), noise=eps.to(DEV))
     loss.backward()
     pr = {k: v.clone().requires_grad_(v.is_floating_point() and "rope" not in k and "fourier" not in k) for k, v in p.items()}
-    ref, _, _ = O.edm2_loss(pr, cfg, images, sigma, eps, None, sigma_data=1.0)
+    ref, _, _ = O.edm2_loss(pr, cfg, images, sigma, eps, labels, sigma_data=1.0)
     ref.backward()
     prm = dict(net.named_parameters())
     errs = {k: rel(prm[k].grad, pr[k].grad) for k in prm
             if k.endswith("weight.weight") and pr[k].grad is not None and float(pr[k].grad.abs().max()) > 0}
     worst = max(errs, key=errs.get)
-    print("cs-shaped: loss", loss.item(), ref.item(), "median weight-grad rel L2", float(np.median(list(errs.values()))),
+    print(tag, "loss", loss.item(), ref.item(), "median weight-grad rel L2", float(np.median(list(errs.values()))),
           "worst", worst, errs[worst])
     assert abs(loss.item() - ref.item()) / abs(ref.item()) < 2e-2
     assert np.median(list(errs.values())) < 2e-2 and errs[worst] < 8e-2
-    assert prm["unet.emb_label.weight.weight"].grad is None or float(prm["unet.emb_label.weight.weight"].grad.abs().max()) == 0
+    if not labelled:
+        assert prm["unet.emb_label.weight.weight"].grad is None or float(prm["unet.emb_label.weight.weight"].grad.abs().max()) == 0
 
 
 def test_hipgraph_step_matches_eager():
