@@ -37,7 +37,8 @@ class ConvArgs(C.Structure):
                 ("ctx_fill", c_float), ("epi", c_int32),
                 ("res", c_void_p), ("escale", c_void_p), ("emb_gain", c_void_p), ("out2", c_void_p),
                 ("ta", c_float), ("tb", c_float), ("clip", c_float), ("ctx_out", c_void_p),
-                ("big_tile", c_int32), ("pad_", c_int32)]
+                ("big_tile", c_int32), ("pad_", c_int32),
+                ("splitk_ws", c_void_p), ("splitk_ws_bytes", C.c_size_t)]
 
 
 class WgradArgs(C.Structure):

@@ -12,6 +12,7 @@
 // Roofline: MFMA-bound for C >= 64 (intensity ~ 27*C FLOP/B of activation), HBM-bound below.
 #pragma once
 #include <type_traits>
+#include <cstdlib>
 #include "common.h"
 #include "../../include/oniris.h"
 
@@ -28,6 +29,8 @@ struct Patch {
 struct ConvDev {
   OnirisConvArgs a;
   int ntx, nty, ntt, ncob;
+  int ksplit;            // > 1: the (chunk, phase) rounds of a tile are dealt to `ksplit` workgroups (conv_fwd_kernel)
+  int reduce;            // 1: second launch of a split-K conv -- sum the slices' partials and run the epilogue
 };
 
 template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW, int NW = 4>
@@ -56,11 +59,16 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
   unsigned char* W_lds = smem + Cfg::AROWS * ROWB;
 
   const OnirisConvArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  // (reduce launch of a split-K conv: one 64-thread block per wave of the tile, see below)
+  const bool red = d.reduce != 0;
+  const int tid = red ? (int)(blockIdx.x % (unsigned)NW) * 64 + (int)threadIdx.x : (int)threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const int H = a.H, W = a.W, T = a.T, Cin = a.Cin, HWp = a.H * a.W;
 
-  // ---- tile decode
-  int bid = blockIdx.x;
+  // ---- tile decode (split-K: consecutive workgroups are the K-slices of one tile)
+  const int ks = d.ksplit, kz = (ks > 1 && !red) ? (int)(blockIdx.x % (unsigned)ks) : 0;
+  const int tile_id = red ? (int)(blockIdx.x / (unsigned)NW) : (ks > 1) ? (int)(blockIdx.x / (unsigned)ks) : (int)blockIdx.x;
+  int bid = tile_id;
   int t0 = 0, y0 = 0, x0 = 0, q0 = 0;
   if constexpr (TAPS == 9) {
     const int tx = bid % d.ntx; bid /= d.ntx;
@@ -240,10 +248,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
     }
   };
 
-  const int nphase = nchunk * NPH;
-  load_phase(0, 0);
+  const int nphase_all = nchunk * NPH;
+  const int it0 = (ks > 1) ? (int)((long long)nphase_all * kz / ks) : 0;
+  const int nphase = red ? 0 : (ks > 1) ? (int)((long long)nphase_all * (kz + 1) / ks) : nphase_all;
+  if (it0 < nphase) load_phase(it0 / NPH, it0 % NPH);
 #pragma unroll 1
-  for (int itp = 0; itp < nphase; ++itp) {
+  for (int itp = it0; itp < nphase; ++itp) {
     const int ph = itp % NPH;
     store_phase(ph);
     __syncthreads();
@@ -255,6 +265,62 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
     if (ph == 0) mfma_steps(std::true_type{});
     else mfma_steps(std::false_type{});
     __syncthreads();
+  }
+
+  // -------------------------------------------------------------------- split-K: partial sums meet in the workspace
+  // Tiny grids (one generated frame in the rollout: 4..32 tiles) leave the chip idle while every workgroup walks
+  // its whole K = 27*Cin serially at HBM latency.  With ksplit > 1 each slice writes its accumulators to
+  // splitk_ws[tile][slice] and exits; a second launch of this kernel (d.reduce, one 64-thread block per wave of a
+  // tile: the reduction is latency/bandwidth-bound per block, so it is spread as wide as the epilogue allows) adds
+  // the slices in order (deterministic) and runs the epilogue.  The kernel boundary is the only synchronisation:
+  // an in-kernel "last slice reduces" needs agent-scope release/acquire = L2 writeback + invalidate per workgroup
+  // on a multi-XCD part, measured slower than not splitting at all.
+  if (ks > 1) {
+    constexpr int NACC = (S + (HAS_CTX ? 1 : 0)) * NT;
+    float* wsp = a.splitk_ws + ((size_t)tile_id * ks) * (size_t)(NACC * NTHR * 16);
+    if (!red) {
+      float* mine = wsp + (size_t)kz * (NACC * NTHR * 16) + tid * 16;
+      auto put = [&](int j, const f32x16& v) __attribute__((always_inline)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *(float4*)(mine + (size_t)j * NTHR * 16 + q * 4) = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+      };
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) put(s * NT + n, acc[s][n]);
+      if constexpr (HAS_CTX) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) put(S * NT + n, accc[n]);
+      }
+      return;
+    }
+    auto get = [&](int j, f32x16& v) __attribute__((always_inline)) {
+      const float* src = wsp + (size_t)j * NTHR * 16 + tid * 16;
+      for (int z0 = 0; z0 < ks; z0 += 4) {                  // 16 loads of 16 B in flight per lane
+        float4 t[4][4];
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            t[zz][q] = (z0 + zz < ks) ? *(const float4*)(src + (size_t)(z0 + zz) * (NACC * NTHR * 16) + q * 4)
+                                      : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int zz = 0; zz < 4; ++zz)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            v[4 * q] += t[zz][q].x; v[4 * q + 1] += t[zz][q].y; v[4 * q + 2] += t[zz][q].z; v[4 * q + 3] += t[zz][q].w;
+          }
+      }
+    };
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) get(s * NT + n, acc[s][n]);
+    if constexpr (HAS_CTX) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) get(S * NT + n, accc[n]);
+    }
   }
 
   // -------------------------------------------------------------------- epilogue
@@ -391,10 +457,29 @@ static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
   } else {
     d.ntx = 1; d.nty = 1; d.ntt = cdiv(a.T * a.H * a.W, Cfg::NPOS);
   }
-  const long long nblk = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
+  long long nblk = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { oniris_set_error("conv_fwd: bad grid %lld", nblk); return ONIRIS_EINVAL; }
+  // split-K when the caller lent a workspace and the tiles alone leave most of the chip idle
+  d.ksplit = 1; d.reduce = 0;
+  const long long ntile = nblk;
+  if (a.splitk_ws && nblk <= 64) {
+    const int nphase = cdiv(a.Cin, CK) * (HAS_CTX ? 3 : 1);
+    constexpr size_t per = (size_t)(S + (HAS_CTX ? 1 : 0)) * NT * Cfg::NTHR * 16 * sizeof(float);
+    static const int ks_cap = getenv("ONIRIS_KSCAP") ? atoi(getenv("ONIRIS_KSCAP")) : 12;
+    long long ks = 256 / nblk;
+    if (ks > nphase) ks = nphase;
+    if (ks > ks_cap) ks = ks_cap;
+    if (nphase < 6) ks = 1;                 // Cin = 32: three rounds, the second launch costs more than it saves
+    if ((size_t)nblk * ks * per > a.splitk_ws_bytes) ks = (long long)(a.splitk_ws_bytes / (nblk * per));
+    if (ks > 1) { d.ksplit = (int)ks; nblk *= ks; }
+  }
   auto kern = conv_fwd_kernel<S, TAPS, CK, NT, HAS_CTX, PW, NW>;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
+  if (d.ksplit > 1) {
+    ONIRIS_LAUNCH_CHECK();
+    d.reduce = 1;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(ntile * NW)), dim3(64), 0, stream, d);
+  }
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -107,6 +107,9 @@ class Gating(nn.Module):
         return lo + (1 - lo) * hi * torch.sigmoid(sv), n_context_frames + T
 
 
+_nctx_cache = {}
+
+
 def batched_gates(convs, c_noise, caches, training):
     """All Gating modules of a net in ONE vectorised evaluation (identical math to Gating.forward, conv.py:113-127):
     replaces ~60 x 20 tiny elementwise launches per step by ~20.  Returns per-layer (ca, cb, n_new)."""
@@ -120,7 +123,12 @@ def batched_gates(convs, c_noise, caches, training):
     hi = torch.sigmoid(torch.stack([m.gating.max_gating for m in convs]))[:, None, None]
     base = (torch.arange(B * tt, device=dev) % T).reshape(1, B, tt)
     if any(n_ctx):
-        base = base + torch.tensor(n_ctx, device=dev).reshape(-1, 1, 1)
+        key = (tuple(n_ctx), str(dev))
+        if key not in _nctx_cache:                     # one host->device copy per distinct frame count (the sampler
+            if len(_nctx_cache) > 64:                  # evaluates the net 31 times per frame; hipGraph-capturable)
+                _nctx_cache.clear()
+            _nctx_cache[key] = torch.tensor(n_ctx, device=dev).reshape(-1, 1, 1)
+        base = base + _nctx_cache[key]
     pos = base.to(c_noise.dtype).log1p()              # (no host->device copy in training: hipGraph-capturable)
     sv = c_noise[None] * mult[:, 0, None, None] + off[:, 0, None, None] + pos * mult[:, 1, None, None] + off[:, 1, None, None]
     g = (lo + (1 - lo) * hi * torch.sigmoid(sv)).reshape(len(convs), -1)
@@ -163,6 +171,10 @@ class MPCausal3DGatedConv(nn.Module):
         pad = cache.get("activations")
         if pad is None:
             pad = torch.ones(batch_size, 2, H, W, C, dtype=BF16, device=x.device)
+        if t == 1:              # one generated frame (the sampler's 31 evaluations): its context IS the cached pair
+            if update_cache:
+                cache["activations"] = torch.cat([pad[:, 1:], x.reshape(batch_size, 1, H, W, C)], dim=1)
+            return ops.gated_conv_eval(x, gate, pw2, pw3, batch_size, 1, pad.contiguous(), coefs, ctx_T=2, **epi), cache
         ctx = torch.cat([pad, x.reshape(batch_size, t, H, W, C)], dim=1).contiguous()
         if update_cache:
             cache["activations"] = ctx[:, -2:].clone()

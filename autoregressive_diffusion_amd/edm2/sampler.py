@@ -1,7 +1,52 @@
 """EDM / Heun sampler that generates ONE next frame against a cache (reference edm2/sampler.py:12-85):
 rho-schedule, optional churn, Euler + 2nd-order correction, cache updated on the last Euler evaluation only."""
+import os
 import numpy as np
 import torch
+
+
+SAMPLER_GRAPH = int(os.environ.get("ONIRIS_SAMPLER_GRAPH", "1"))
+_graph_pool = None
+
+
+class _GraphedDenoiser:
+    """The cache-reading UNet evaluations of ONE generated frame (30 of its 31: same cache, same shapes, only x and
+    sigma change) replayed from a hipGraph: the first evaluation runs eagerly (builds the mask / RoPE / gate tables
+    of this frame count), the second is captured, the rest are replays -- ~450 kernel launches per evaluation
+    without their host cost.  The last evaluation of the frame updates the cache and stays eager.  A new graph per
+    frame: the KV length and the cache tensors change with every frame."""
+
+    def __init__(self, net, cache, conditioning, B, dtype, device):
+        self.net, self.cache, self.cond = net, cache, conditioning
+        self.t = torch.ones(B, 1, device=device, dtype=dtype)
+        self.x, self.out, self.graph, self.calls = None, None, None, 0
+
+    def __call__(self, x, t):
+        global _graph_pool
+        self.calls += 1
+        if self.calls == 1:                                        # eager warm-up (tables for this frame count)
+            Dx, _ = self.net(x, self.t * t, self.cond, cache=self.cache, update_cache=False, just_2d=False)
+            return Dx
+        self.t.fill_(1.0).mul_(t)
+        if self.graph is None:
+            self.x = x.clone()
+            cur = torch.cuda.current_stream()
+            if _graph_pool is None:
+                _graph_pool = (torch.cuda.graph_pool_handle(), torch.cuda.Stream())
+            pool, side = _graph_pool
+            side.wait_stream(cur)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=pool, stream=side):
+                self.out, _ = self.net(self.x, self.t, self.cond, cache=self.cache, update_cache=False, just_2d=False)
+            self.graph, self.side = g, side
+        else:
+            self.x.copy_(x)
+        cur = torch.cuda.current_stream()
+        self.side.wait_stream(cur)
+        with torch.cuda.stream(self.side):
+            self.graph.replay()
+        cur.wait_stream(self.side)
+        return self.out.clone()
 
 
 @torch.no_grad()
@@ -13,7 +58,14 @@ def edm_sampler_with_mse(net, cache, target=None, gnet=None, conditioning=None, 
     B, _, C, H, W = cache.get("shape", (None,) * 5)
     device = net.device
 
+    graphed = None
+    if (SAMPLER_GRAPH and guidance == 1 and torch.device(device).type == "cuda" and dtype == torch.float32
+            and num_steps >= 4):
+        graphed = _GraphedDenoiser(net, cache, conditioning, B, dtype, device)
+
     def denoise(x, t, cache, update_cache):
+        if graphed is not None and not update_cache:
+            return graphed(x, t), cache
         t = torch.ones(B, 1, device=device, dtype=dtype) * t
         Dx, cache = net(x, t, conditioning, cache=cache, update_cache=update_cache, just_2d=False)
         if guidance == 1:

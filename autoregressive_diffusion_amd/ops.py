@@ -134,6 +134,9 @@ class _ZeroArena:
         self.off = 0
 
 
+_weights_epoch = 0          # bumped whenever a kernel writes parameters behind torch's back (weight_prep training, adamw_)
+
+
 class WeightBank:
     def __init__(self):
         self.zero_arena = _ZeroArena()
@@ -193,6 +196,7 @@ class WeightBank:
                      for w, _ in self.items)
 
     def _build(self, device):
+        self._packed_sig = None
         descs = (_lib.WeightDesc * len(self.items))()
         row = tile = 0
         nslots = len(self.items) + len(self.groups)
@@ -256,9 +260,19 @@ class WeightBank:
         """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
         self._ensure()
         self.zero_arena.reset()                        # (the previous step's backward is done with its accumulators)
+        global _weights_epoch
+        if training:
+            _weights_epoch += 1                        # parameters are rewritten in place (forced normalisation)
+        else:
+            # eval (the sampler calls the net 31 times per generated frame): the packed copies stay valid until a
+            # parameter changes -- through torch (._version) or through a raw-pointer kernel (_weights_epoch)
+            sig = (_weights_epoch, tuple(w.param._version for w, _ in self.items))
+            if getattr(self, "_packed_sig", None) == sig:
+                return
         check(lib.oniris_weight_prep(_p(self._dev_table), len(self.items), self.total_rows, self.total_tiles, int(training),
                                      _stream()),
               "weight_prep")
+        self._packed_sig = None if training else (_weights_epoch, tuple(w.param._version for w, _ in self.items))
 
     def backward(self):
         """Packed fp32 weight gradients (from the wgrad kernels) -> parameter .grad (accumulated); one launch."""
@@ -380,7 +394,23 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     a.epi, a.res, a.escale, a.emb_gain, a.out2 = epi, _p(res), _p(escale), _p(emb_gain), _p(out2)
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
     a.big_tile = BIG_TILE
+    if SPLITK and B * S * T * H * W <= 64 * 256:      # few tiles (one rollout frame): lend the split-K workspace
+        ws = _splitk_workspace(x.device)
+        a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
     check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
+
+
+SPLITK = int(_os.environ.get("ONIRIS_SPLITK", "1"))
+_splitk_cache = {}
+
+
+def _splitk_workspace(device):
+    """fp32 partial-sum workspace of the split-K conv path (OnirisConvArgs.splitk_ws); one per device: the two
+    launches of a conv and consecutive convs are ordered on the stream."""
+    key = str(device)
+    if key not in _splitk_cache:
+        _splitk_cache[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)        # 32 MB
+    return _splitk_cache[key]
 
 
 def _wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
@@ -621,8 +651,12 @@ def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0
 
 
 @torch.no_grad()
-def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None):
-    """Eval-mode gated conv: x (B*t,H,W,C); ctx_frames (B, t+2, H, W, C) = [2 cached frames, x frames]."""
+def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None,
+                    ctx_T=None):
+    """Eval-mode gated conv: x (B*t,H,W,C); ctx_frames (B, ctx_T, H, W, C) = [2 cached frames, x frames] (ctx_T = t+2),
+    or just the 2 cached frames when t == 1 (output frame 0 reads context frames 0 and 1 only)."""
+    ctx_T = t + 2 if ctx_T is None else ctx_T
+    assert ctx_frames.shape[1] == ctx_T and (ctx_T == t + 2 or t == 1)
     N, H, W, Cin = x.shape
     Co = roundup(pw2.cout, 8)
     out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
@@ -635,7 +669,7 @@ def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, t
         ret = torch.empty_like(out)
         kw = dict(epi=_lib.EPI_EMB_SILU, escale=cscale.float().contiguous(), out2=ret)
     _conv_launch(x, ctx_frames, pw2.wf, pw3.wf, out, ca, cb, B, 1, t, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
-                 ctx_bstride=t + 2, ctx_T=t + 2, coff=(0, 1), ctx_fill=0.0, **kw)
+                 ctx_bstride=ctx_T, ctx_T=ctx_T, coff=(0, 1), ctx_fill=0.0, **kw)
     return ret
 
 
@@ -935,5 +969,7 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
 
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
     _need_gpu(p, g, m, v)
+    global _weights_epoch
+    _weights_epoch += 1
     check(lib.oniris_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
                            _stream()), "adamw")

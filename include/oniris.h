@@ -120,6 +120,12 @@ typedef struct OnirisConvArgs {
   int32_t big_tile;       /* variant: 0 = 4-wave register-staged kernels, 1/2 = 8-wave ones where they fill the chip /
                            * always, >= 3 = persistent LDS-DMA kernel (csrc/conv_glds.h) wherever the shape allows   */
   int32_t pad_;
+  /* Optional split-K workspace (caller-allocated, reusable by consecutive launches on one stream): when given and
+   * the launch has <= 64 tiles (a single generated frame in the sampler, edm2/sampler.py:12-85), the
+   * K = taps*Cin*(1 or 3 phases) loop of a tile is dealt to several workgroups which write fp32 partial sums here;
+   * a second launch adds them in slice order and runs the epilogue.                                               */
+  float* splitk_ws;
+  size_t splitk_ws_bytes;
 } OnirisConvArgs;
 
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);

@@ -221,6 +221,31 @@ def test_g9_sampler_rollout():
     assert e0 < 2e-2 and max(errs) < 5e-2
 
 
+def test_sampler_graph_replay_matches_eager():
+    """Rollout with the per-frame hipGraph of the cache-reading UNet evaluations (edm2/sampler.py _GraphedDenoiser)
+    against the same rollout launched eagerly: same noise, 3 frames x 6 steps, frames and caches must agree."""
+    import edm2.sampler as S
+    z = load("g9_sampler")
+    outs = {}
+    for mode in (0, 1):
+        S.SAMPLER_GRAPH = mode
+        net = build_precond(SMALL_CFG, int(z["seed"]), 0.5).eval()
+        g = torch.Generator().manual_seed(5)
+        with torch.no_grad():
+            _, cache = net(T(z["ctx"]).to(DEV), torch.ones(1, 4, device=DEV) * 0.05, T(z["ctx_labels"]).to(DEV), update_cache=True)
+            frames = []
+            for step in range(3):
+                noise = torch.randn(1, 1, *z["ctx"].shape[2:], generator=g).to(DEV)
+                x, _, _, cache = S.edm_sampler_with_mse(net, cache, conditioning=torch.full((1, 1), step % 4, device=DEV),
+                                                        num_steps=6, sigma_min=0.01, sigma_max=80, rho=2, noise=noise)
+                frames.append(x.clone())
+        outs[mode] = (frames, cache[("enc", "8x8_block0")]["attn"][0].float().clone(), cache["n_context_frames"])
+    S.SAMPLER_GRAPH = 1
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.isfinite(a).all() and rel(b, a.cpu().numpy()) < 1e-5, rel(b, a.cpu().numpy())
+    assert outs[0][2] == outs[1][2] and rel(outs[1][1], outs[0][1].cpu().numpy()) < 1e-5
+
+
 CS_SMALL = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=32, channel_mult=[1, 2, 4, 4],
                 num_blocks=1, video_attn_resolutions=[4], frame_attn_resolutions=[8])
 CS_FULL = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=128, channel_mult=[1, 2, 4, 4],
