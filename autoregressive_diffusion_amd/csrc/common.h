@@ -53,6 +53,11 @@ __device__ __forceinline__ bf16 f2bf(float v) { return (bf16)v; }
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// sigmoid through the hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32: ~1 ulp, far below the bf16 rounding of every
+// consumer) instead of __expf + an IEEE division (~10 more VALU ops per element in the HBM-bound elementwise passes)
+__device__ __forceinline__ float sigmoid_fast(float z) {
+  return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z));
+}
 __device__ __forceinline__ int mfma_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
 __device__ __forceinline__ float wave_sum(float v) {

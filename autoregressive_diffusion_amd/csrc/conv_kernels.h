@@ -426,7 +426,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float z = bf2f(f2bf(v[nt][4 * g + k])) * cvv[k];     // the activation sees the bf16-rounded y
-            v[nt][4 * g + k] = z / (1.f + __expf(-z)) * (1.f / 0.596f);
+            v[nt][4 * g + k] = z * sigmoid_fast(z) * (1.f / 0.596f);
           }
         }
       stage();

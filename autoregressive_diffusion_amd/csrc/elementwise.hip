@@ -10,9 +10,9 @@
 
 #define SILU_SCALE (1.0f / 0.596f)
 
-__device__ __forceinline__ float silu_f(float z) { return z / (1.f + __expf(-z)); }
+__device__ __forceinline__ float silu_f(float z) { return z * sigmoid_fast(z); }
 __device__ __forceinline__ float dsilu_f(float z) {
-  const float sg = 1.f / (1.f + __expf(-z));
+  const float sg = sigmoid_fast(z);
   return sg * (1.f + z * (1.f - sg));
 }
 

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __rest
           float d;
           if (MODE == 1) {
             const float z = r_ * cv[s][i];
-            const float sg = 1.f / (1.f + __expf(-z));
+            const float sg = sigmoid_fast(z);
             const float dz = bf2f(gv[i]) * (sg * (1.f + z * (1.f - sg))) * (1.0f / 0.596f);
             part[s][i] += dz * r_;
             d = dz * cv[s][i];

@@ -74,6 +74,20 @@ class Block(nn.Module):
             cache["attn"] = None
         return x, cache
 
+    @torch.no_grad()
+    def load_from_2d(self, state_dict):
+        """state_dict of the matching 2-D EDM2 block (keys `conv_res0.weight`, `emb_linear.weight`, `conv_res1.weight`,
+        `emb_gain` [, `conv_skip.weight`, `attn_qkv.weight`, `attn_proj.weight`]); reference networks_edm2.py:96-110."""
+        sd = {(k[:-len(".weight")] if k.endswith(".weight") else k): v for k, v in state_dict.items()}
+        if "attn_qkv" in sd:
+            self.attn.attn_qkv.weight.weight.copy_(sd["attn_qkv"])
+            self.attn.attn_proj.weight.weight.copy_(sd["attn_proj"])
+        if "emb_gain" in sd:
+            self.emb_gain.copy_(sd["emb_gain"])
+        for name, child in self.named_children():
+            if callable(getattr(child, "load_from_2d", None)):
+                child.load_from_2d(sd[name])
+
     def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
         with weights_ready(self):
             pad = (-emb.shape[1]) % 8
@@ -247,7 +261,22 @@ class UNet(BetterModule):
 
     @torch.no_grad()
     def load_from_2d(self, unet):
-        raise NotImplementedError("importing NVIDIA EDM2 2-D checkpoints is listed under SURVEY 8(f), not built yet")
+        """Import the weights of a 2-D EDM2 UNet (NVIDIA's image model; reference networks_edm2.py:238-258, used by
+        test.py:28): blocks are matched BY ORDER within enc / dec, every 2-D conv lands in the own-frame path
+        (`last_frame_conv`) of the gated conv, the context weights and the gates keep their values; the single
+        Fourier embedding feeds both the sigma and the time embedding; `emb_time` is left alone."""
+        for mine, theirs in ((self.enc, unet.enc), (self.dec, unet.dec)):
+            for m3, m2 in zip(mine.children(), theirs.children()):
+                m3.load_from_2d(m2.state_dict())
+        sd = unet.state_dict()
+        self.emb_noise.load_from_2d(sd["emb_noise.weight"])
+        if self.label_dim != 0:
+            self.emb_label.load_from_2d(sd["emb_label.weight"])
+        for emb in (self.emb_fourier_sigma, self.emb_fourier_time):
+            emb.freqs.copy_(sd["emb_fourier.freqs"])
+            emb.phases.copy_(sd["emb_fourier.phases"])
+        self.out_conv.load_from_2d(sd["out_conv.weight"])
+        self.out_gain.copy_(sd["out_gain"])
 
 
 class Precond(BetterModule):

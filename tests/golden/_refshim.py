@@ -44,9 +44,22 @@ def install():
         _mode.__enter__()
         torch.Tensor.cuda = lambda self, *a, **k: self
         torch.nn.Module.cuda = lambda self, *a, **k: self
-    if REF not in sys.path:
-        sys.path.insert(0, REF)
+    # The reference must win over this repository's own top-level `edm2/` compatibility package.  The reference's
+    # edm2 has no __init__.py (a namespace package), so a regular package of that name ANYWHERE on sys.path beats it:
+    # the repository root goes to the end of sys.path, after the import of the reference package.
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    mine = [p for p in sys.path if os.path.abspath(p or ".") == root]
+    for p in mine:
+        sys.path.remove(p)
+    while REF in sys.path:
+        sys.path.remove(REF)
+    sys.path.insert(0, REF)
+    for name in [m for m in sys.modules if m == "edm2" or m.startswith("edm2.")]:
+        del sys.modules[name]
     import edm2  # noqa
+    where = list(getattr(edm2, "__path__", []))
+    assert where and all(w.startswith(REF) for w in where), f"fixtures must come from the reference, got {where}"
     import edm2.networks_edm2  # noqa
     from edm2.attention import attention_modules as am
 
@@ -66,4 +79,5 @@ def install():
         return torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
 
     am.compiled_flex_attention = dense_flex
+    sys.path.append(root)
     return edm2

@@ -401,7 +401,25 @@ def g9():
     save("g9_sampler", **out)
 
 
+# ------------------------------------------------------------------ G10 import of a 2-D EDM2 net (load_from_2d)
+def g10():
+    """UNet.load_from_2d (networks_edm2.py:238-258): the reference net starts from parameter set A, imports the 2-D
+    stand-in built from set B (tests/golden/twod.py); the fixture is the per-key sum / abs-sum of its state_dict
+    afterwards (pure copies, so the sums pin exactly which tensors moved where)."""
+    import twod
+    out = {}
+    for tag, cfg, sa, sb in [("small", SMALL_CFG, 90, 91), ("c1", C1_CFG, 92, 93)]:
+        pa, pb = paramgen.unet_params(cfg, sa), paramgen.unet_params(cfg, sb)
+        unet = UNet(**cfg)
+        unet.load_state_dict({k: v.clone() for k, v in pa.items()}, strict=True)
+        unet.load_from_2d(twod.Net2D(pb, list(unet.enc.keys()), list(unet.dec.keys())))
+        keys, sums, asums = twod.state_sums(unet.state_dict())
+        out[tag + "_keys"], out[tag + "_sums"], out[tag + "_abs"] = np.array(keys), np.array(sums), np.array(asums)
+        out[tag + "_seeds"] = np.array([sa, sb])
+    save("g10_load2d", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()
