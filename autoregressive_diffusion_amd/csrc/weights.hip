@@ -174,11 +174,19 @@ extern "C" int oniris_weight_bwd(const OnirisWeightDesc* descs_dev, int ndesc, i
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// fused multi-tensor AdamW over the flat fp32 parameter / gradient buffers (gym_train.py:61,105-106 uses
-// torch.optim.AdamW; here one elementwise pass: 16 B/lane loads, 4 buffers)
+// Optimizer step of gym_train.py:105-108 / cs_train.py:117-121 on the flat fp32 buffers:
+//   clip_grad_norm_(params, max_norm)  ->  AdamW  ->  PowerFunctionEMA.update (edm2/phema.py:101-106, two profiles)
+// as ONE elementwise pass (16 B/lane): the clip coefficient comes from a device scalar (the squared gradient norm,
+// oniris_sqnorm) so nothing synchronises with the host, and each EMA copy is lerp'ed towards the freshly updated
+// parameter while it is still in registers.
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
-                             float bc1, float bc2, float gscale) {
+                             float bc1, float bc2, float gscale, const float* __restrict__ gnorm_sq, float max_norm,
+                             float* __restrict__ ema0, float w0, float* __restrict__ ema1, float w1) {
+  if (gnorm_sq) {                               // torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
+    const float coef = max_norm / (sqrtf(*gnorm_sq) * fabsf(gscale) + 1e-6f);
+    if (coef < 1.f) gscale *= coef;
+  }
   size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
   for (; i + 3 < n; i += stride) {
@@ -193,6 +201,16 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
       pp[k] = pp[k] * (1.f - lr * wd) - lr * mh / (sqrtf(vh) + eps);
     }
     *(float4*)(p + i) = P; *(float4*)(m + i) = M; *(float4*)(v + i) = V;
+    if (ema0) {
+      float4 E = *(float4*)(ema0 + i);
+      E.x += w0 * (P.x - E.x); E.y += w0 * (P.y - E.y); E.z += w0 * (P.z - E.z); E.w += w0 * (P.w - E.w);
+      *(float4*)(ema0 + i) = E;
+    }
+    if (ema1) {
+      float4 E = *(float4*)(ema1 + i);
+      E.x += w1 * (P.x - E.x); E.y += w1 * (P.y - E.y); E.z += w1 * (P.z - E.z); E.w += w1 * (P.w - E.w);
+      *(float4*)(ema1 + i) = E;
+    }
   }
   if (i < n && i + 3 >= n) {
     for (size_t k = i; k < n; ++k) {
@@ -200,21 +218,75 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
       m[k] = b1 * m[k] + (1.f - b1) * gr;
       v[k] = b2 * v[k] + (1.f - b2) * gr * gr;
       p[k] = p[k] * (1.f - lr * wd) - lr * (m[k] / bc1) / (sqrtf(v[k] / bc2) + eps);
+      if (ema0) ema0[k] += w0 * (p[k] - ema0[k]);
+      if (ema1) ema1[k] += w1 * (p[k] - ema1[k]);
     }
   }
 }
 
-extern "C" int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-                            float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream_) {
-  hipStream_t stream = (hipStream_t)stream_;
+static int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                        float eps, float weight_decay, int step, float grad_scale, const float* gnorm_sq, float max_norm,
+                        float* ema0, float w0, float* ema1, float w1, hipStream_t stream) {
   ONIRIS_CHECK_ARG(p && g && m && v && step >= 1, "adamw: bad arguments");
+  ONIRIS_CHECK_ARG(!gnorm_sq || max_norm > 0.f, "adamw: clipping needs max_norm > 0");
   if (n == 0) return ONIRIS_OK;
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   size_t nb = (n / 4 + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (nb == 0) nb = 1;
   hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2, grad_scale);
+                     weight_decay, bc1, bc2, grad_scale, gnorm_sq, max_norm, ema0, w0, ema1, w1);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream_) {
+  return launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, nullptr, 0.f, nullptr, 0.f,
+                      nullptr, 0.f, (hipStream_t)stream_);
+}
+
+extern "C" int oniris_adamw_clip_ema(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1,
+                                     float beta2, float eps, float weight_decay, int step, float grad_scale,
+                                     const float* gnorm_sq, float max_norm, float* ema0, float ema_w0, float* ema1,
+                                     float ema_w1, oniris_stream_t stream_) {
+  return launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, gnorm_sq, max_norm, ema0,
+                      ema_w0, ema1, ema_w1, (hipStream_t)stream_);
+}
+
+// sum of squares of a flat fp32 buffer -> out[0] (device).  Two stages through out[1 .. 1+ONIRIS_SQNORM_WS) so the
+// result is deterministic (no float atomics): <= 1024 block partials, then one block adds them in a fixed order.
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ part) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) {
+    const float4 G = *(const float4*)(g + i);
+    acc += G.x * G.x + G.y * G.y + G.z * G.z + G.w * G.w;
+  }
+  if (i < n && i + 3 >= n)
+    for (size_t k = i; k < n; ++k) acc += g[k] * g[k];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ out) {
+  __shared__ float red[16];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) acc += part[i];
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) out[0] = acc;
+}
+
+extern "C" int oniris_sqnorm(const float* g, size_t n, float* out, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(g && out, "sqnorm: null pointer");
+  size_t nb = (n / 4 + 255) / 256;
+  if (nb > ONIRIS_SQNORM_WS) nb = ONIRIS_SQNORM_WS;
+  if (nb == 0) nb = 1;
+  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g, n, out + 1);
+  ONIRIS_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)(out + 1), (int)nb, out);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

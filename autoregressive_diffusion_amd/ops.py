@@ -967,9 +967,28 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
 # ------------------------------------------------------------------------------------------------------------------
 # optimizer
 
-def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0):
+SQNORM_WS = 1024          # ONIRIS_SQNORM_WS in include/oniris.h
+
+
+def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_norm=None, norm_buf=None,
+           emas=()):
+    """Optimizer side of a training step on flat fp32 buffers (gym_train.py:105-108): optional gradient-norm clipping
+    (norm_buf: 1 + SQNORM_WS floats of scratch, receives sum(g^2) in [0]), AdamW, and the power-function EMA update
+    of up to two tracked copies -- emas = [(flat_tensor, 1 - beta), ...]."""
     _need_gpu(p, g, m, v)
     global _weights_epoch
     _weights_epoch += 1
-    check(lib.oniris_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step, grad_scale,
-                           _stream()), "adamw")
+    if max_norm is None and not emas:
+        check(lib.oniris_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                               grad_scale, _stream()), "adamw")
+        return
+    assert len(emas) <= 2
+    gn = None
+    if max_norm is not None:
+        assert norm_buf is not None and norm_buf.numel() >= 1 + SQNORM_WS and norm_buf.dtype == torch.float32
+        check(lib.oniris_sqnorm(_p(g), g.numel(), _p(norm_buf), _stream()), "sqnorm")
+        gn = norm_buf
+    e = list(emas) + [(None, 0.0)] * (2 - len(emas))
+    check(lib.oniris_adamw_clip_ema(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                                    grad_scale, _p(gn), float(max_norm or 0.0), _p(e[0][0]), float(e[0][1]),
+                                    _p(e[1][0]), float(e[1][1]), _stream()), "adamw_clip_ema")

@@ -185,31 +185,88 @@ class OnirisDDP(nn.Module):
             self._sync_enabled = old
 
 
+def power_function_exponent(std):
+    """Exponent gamma of the power-function EMA profile with relative standard deviation `std` (EDM2, the relation
+    edm2/phema.py:18-32 inverts): std^2 = (gamma + 1) / ((gamma + 2)^2 (gamma + 3)), solved by bisection on the
+    decreasing branch gamma >= 0 (std <= 0.2886)."""
+    f = lambda g: (g + 1.0) / ((g + 2.0) ** 2 * (g + 3.0))
+    target = float(std) ** 2
+    if not (0.0 < target <= f(0.0)):
+        raise ValueError(f"relative std {std} outside (0, {f(0.0) ** 0.5:.4f}]")
+    lo, hi = 0.0, 1.0
+    while f(hi) > target:
+        hi *= 2.0
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if f(mid) > target else (lo, mid)
+    return 0.5 * (lo + hi)
+
+
+def power_function_beta(std, t_next, t_delta):
+    """EMA decay of one update that advances training time from t_next - t_delta to t_next (edm2/phema.py:66-68)."""
+    return (1.0 - t_delta / t_next) ** (power_function_exponent(std) + 1.0)
+
+
+class FlatEMA:
+    """PowerFunctionEMA (edm2/phema.py:90-106) on the flat parameter buffer: one fp32 copy per profile, updated
+    inside the fused optimizer kernel (FlatAdamW.step(ema=...)) instead of one lerp_ launch per parameter and profile."""
+
+    def __init__(self, flat, stds=(0.050, 0.100)):
+        assert 1 <= len(stds) <= 2
+        self.flat, self.stds = flat, list(stds)
+        self.emas = [flat.flat.clone() for _ in stds]
+
+    def reset(self):
+        for e in self.emas:
+            e.copy_(self.flat.flat)
+
+    def weights(self, cur_nimg, batch_size):
+        """[(ema buffer, 1 - beta)] for the update that ends at `cur_nimg` images."""
+        return [(e, 1.0 - power_function_beta(s, cur_nimg, batch_size)) for e, s in zip(self.emas, self.stds)]
+
+    def view(self, k, param):
+        """The EMA value of `param` (a parameter re-homed in self.flat) under profile k."""
+        i = [id(p) for p in self.flat.params].index(id(param))
+        o = self.flat.offsets[i]
+        return self.emas[k][o:o + param.numel()].view_as(param)
+
+
 class FlatAdamW:
-    """AdamW on the flat buffers.  GPU: one fused HIP kernel (oniris_adamw); CPU tensors (tests): plain torch math."""
+    """AdamW on the flat buffers, optionally with gradient-norm clipping and the EMA update in the same pass.
+    GPU: fused HIP kernels (oniris_sqnorm + oniris_adamw_clip_ema); CPU tensors (tests): plain torch math."""
 
     def __init__(self, flat, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
         self.steps = 0
+        self._norm_buf = None
 
     @torch.no_grad()
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, max_norm=None, ema=None):
+        """max_norm: torch.nn.utils.clip_grad_norm_(params, max_norm) before the update (gym_train.py:105);
+        ema: FlatEMA.weights(cur_nimg, batch_size) -> the tracked copies follow the updated parameters (:108)."""
         self.steps += 1
         f = self.flat
         f.gather()
+        ema = list(ema or ())
         if f.flat.is_cuda:
             from . import ops
+            if max_norm is not None and self._norm_buf is None:
+                self._norm_buf = torch.zeros(1 + ops.SQNORM_WS, dtype=torch.float32, device=f.flat.device)
             ops.adamw_(f.flat, f.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
-                       self.weight_decay, self.steps, grad_scale)
+                       self.weight_decay, self.steps, grad_scale, max_norm, self._norm_buf, ema)
             return
         b1, b2 = self.betas
         g = f.grad * grad_scale
+        if max_norm is not None:
+            g = g * min(1.0, max_norm / (float(g.norm()) + 1e-6))
         self.m.mul_(b1).add_(g, alpha=1 - b1)
         self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
         mh, vh = self.m / (1 - b1 ** self.steps), self.v / (1 - b2 ** self.steps)
         f.flat.mul_(1 - self.lr * self.weight_decay).sub_(self.lr * mh / (vh.sqrt() + self.eps))
+        for e, w in ema:
+            e.lerp_(f.flat, w)
 
     def zero_grad(self):
         self.flat.zero_grad()

@@ -152,7 +152,7 @@ def main():
 
     from edm2.networks_edm2 import UNet, Precond
     from edm2.loss import EDM2Loss
-    from autoregressive_diffusion_amd.parallel import FlatParams, OnirisDDP, FlatAdamW
+    from autoregressive_diffusion_amd.parallel import FlatParams, OnirisDDP, FlatAdamW, FlatEMA
     from autoregressive_diffusion_amd import ops
 
     torch.manual_seed(0)
@@ -168,6 +168,11 @@ def main():
         model.force_collectives = True
     net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
     opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
+    # optimizer side as in the reference loops: clip_grad_norm_(0.1) (gym_train.py:105 only) + AdamW +
+    # PowerFunctionEMA(stds 0.05 / 0.10).update (gym_train.py:108, cs_train.py:121) -- one fused pass
+    ema = FlatEMA(flat, stds=(0.050, 0.100))
+    max_norm = None if cs else 0.1
+    nimg = [0]
     loss_fn = (EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1) if cs else   # cs_train.py:75
                EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5))         # gym_train.py:66-67
 
@@ -208,7 +213,8 @@ def main():
             loss = fwd_bwd(just_2d)
         if world > 1 or force_dist:
             model.wait()
-        opt.step()
+        nimg[0] += world * B
+        opt.step(max_norm=max_norm, ema=ema.weights(nimg[0] + world * B, world * B))
         return loss
 
     def fence():
@@ -289,8 +295,8 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": (f"Counter-Strike latents {T}-frame seq, EDM2 UNet 310.0M (cs_train.py:35-45), " if cs else
                                        f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), ") +
-                                      f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + AdamW, 3:1 mix of "
-                                      f"3-D/2-D steps", "global_batch": world * B, "seq_len": T,
+                                      f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
+                                      f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
                           "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
                           **{k: round(v, 2) for k, v in per_mode.items()}},
                "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "roofline_attention": roof_attn,

@@ -79,6 +79,17 @@ int oniris_weight_bwd(const OnirisWeightDesc* descs, int ndesc, int total_rows, 
 /* Fused AdamW over flat fp32 buffers (the optimizer step of gym_train.py:105-106 / cs_train.py:117-118).       */
 int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream);
+/* The whole optimizer side of a training step in one pass (gym_train.py:105-108): gradient-norm clipping
+ * (torch.nn.utils.clip_grad_norm_: gradients scaled by min(1, max_norm / (||grad_scale*g|| + 1e-6)); gnorm_sq = device
+ * scalar holding sum(g^2) from oniris_sqnorm, NULL = no clipping), AdamW, and the power-function EMA update of up to
+ * two tracked copies (edm2/phema.py:101-106: ema += ema_w * (p_new - ema), ema_w = 1 - beta; NULL = not tracked).  */
+int oniris_adamw_clip_ema(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, float grad_scale, const float* gnorm_sq,
+                          float max_norm, float* ema0, float ema_w0, float* ema1, float ema_w1, oniris_stream_t stream);
+/* out[0] <- sum of squares of g[0..n) ; out must hold 1 + ONIRIS_SQNORM_WS floats (out[1..] is workspace).
+ * Deterministic (two-stage, no float atomics), never synchronises.                                               */
+#define ONIRIS_SQNORM_WS 1024
+int oniris_sqnorm(const float* g, size_t n, float* out, oniris_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Gated causal 3-D convolution as ONE implicit GEMM (MFMA bf16 -> fp32), forward and data-gradient.

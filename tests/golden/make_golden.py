@@ -419,7 +419,19 @@ def g10():
     save("g10_load2d", **out)
 
 
+# ------------------------------------------------------------------ G11 power-function EMA coefficients
+def g11():
+    """edm2/phema.py: std_to_exp and power_function_beta on a grid (known answers for parallel.power_function_*)."""
+    from edm2 import phema
+    stds = np.array([0.01, 0.05, 0.10, 0.15, 0.20, 0.25])
+    tn = np.array([16.0, 1000.0, 123456.0, 5.0e7])
+    td = np.array([8.0, 8.0, 64.0, 2048.0])
+    exps = np.array([float(phema.std_to_exp(s)) for s in stds])
+    betas = np.array([[float(phema.power_function_beta(std=s, t_next=a, t_delta=b)) for a, b in zip(tn, td)] for s in stds])
+    save("g11_phema", stds=stds, t_next=tn, t_delta=td, exps=exps, betas=betas)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()
