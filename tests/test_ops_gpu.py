@@ -194,6 +194,50 @@ def test_gated_conv_eval_matches_oracle():
     assert e < 1e-2
 
 
+@pytest.mark.parametrize("B,H,cin,cout,epi", [(1, 8, 256, 256, "silu"), (1, 16, 128, 128, "mpsum"), (2, 32, 64, 64, "none"),
+                                              (1, 8, 96, 160, "mpsum"), (1, 64, 32, 32, "silu"), (3, 4, 128, 64, "none")])
+def test_gated_conv_eval_one_frame_splitk(B, H, cin, cout, epi, monkeypatch):
+    """One generated frame per sequence (the sampler's shape): the context pair comes straight from the cache tensor
+    and the K loop of the few tiles is split over workgroups (OnirisConvArgs.splitk_ws).  Checked against the fp32
+    reference for every epilogue, and split-K on/off must agree to the bf16 rounding of the output."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(cin + H)
+    w2, w3 = torch.randn(cout, cin, 3, 3), torch.randn(cout, cin, 2, 3, 3)
+    p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=False)
+    x0 = bfr(torch.randn(B, cin, H, H))
+    cache0 = bfr(torch.randn(B, cin, 2, H, H))
+    g0 = torch.rand(B) * 0.6 + 0.05
+    x = nhwc(x0)
+    pad = cache0.permute(0, 2, 3, 4, 1).to(DEV, torch.bfloat16).contiguous()          # (B, 2, H, H, C)
+    kw, F = {}, torch.nn.functional
+    if epi == "silu":
+        cs0 = torch.rand(B, cout) + 0.5
+        kw = dict(cscale=cs0.to(DEV))
+    elif epi == "mpsum":
+        r0 = bfr(torch.randn(B, cout, H, H))
+        kw = dict(res=nhwc(r0), ta=0.7, tb=0.5, clip=2.0)
+    outs = {}
+    for sk in (1, 0):
+        monkeypatch.setattr(ops, "SPLITK", sk)
+        outs[sk] = ops.gated_conv_eval(x, g0.to(DEV), pw2, pw3, B, 1, pad, ctx_T=2, **kw).float().cpu()
+    e2, _ = O.weight_effective(w2, 1.0, False)
+    e3, _ = O.weight_effective(w3, 1.0, False)
+    y3 = F.conv2d(cache0[:, :, 0], e3[:, :, 0], padding=1) + F.conv2d(cache0[:, :, 1], e3[:, :, 1], padding=1)
+    yr = O.mp_sum(F.conv2d(x0, e2, padding=1), y3, g0)
+    if epi == "silu":
+        yr = F.silu(yr * cs0[:, :, None, None]) / 0.596
+    elif epi == "mpsum":
+        yr = (0.7 * r0 + 0.5 * yr).clamp(-2.0, 2.0)
+    got = outs[1].permute(0, 3, 1, 2)[:, :cout]
+    e = rel(got, yr)
+    d = (outs[1] - outs[0]).abs().max().item()
+    print("one-frame eval", (B, H, cin, cout, epi), "rel", e, "split vs unsplit max abs", d)
+    assert e < 1e-2
+    assert d <= 2.0 ** -6 * max(1.0, float(outs[0].abs().max()))          # one bf16 ulp of the largest value
+
+
 def _attn_ref(x0, wq, wp, B, m, training, just_2d=False, rope=True):
     p = {"a.attn_qkv.weight.weight": wq, "a.attn_proj.weight.weight": wp,
          "a.rope.inv_freq": 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64)),
