@@ -203,8 +203,12 @@ def main():
                 return lambda: fwd_bwd(j2d)
         graphed = {False: GraphedStep(make(False)), True: GraphedStep(make(True))}
 
+    _only = os.environ.get("ONIRIS_ONLY_MODE")
+
     def step(i, profile=False):
         just_2d = (i % 4 == 0)                                   # gym_train.py:96
+        if _only:                                                # profiling aid: ONIRIS_ONLY_MODE=2d|3d (not the metric)
+            just_2d = _only == "2d"
         if use_graph and not profile:
             loss = graphed[just_2d]()
             if world > 1:
@@ -298,6 +302,7 @@ def main():
                                       f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
                                       f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
                           "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                          **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
                           **{k: round(v, 2) for k, v in per_mode.items()}},
                "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "roofline_attention": roof_attn,
                "kernels": kernels}
