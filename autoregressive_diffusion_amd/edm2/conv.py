@@ -16,7 +16,9 @@ _tls = threading.local()
 
 def _bank_of(root):
     bank = root.__dict__.get("_oniris_bank")
-    mods = [m for m in root.modules() if isinstance(m, NormalizedWeight)]
+    mods = root.__dict__.get("_oniris_mods")          # the module tree of a built net is fixed: walk it once
+    if mods is None:                                   # (~0.5 ms of host time per forward for the gym net otherwise)
+        mods = root.__dict__["_oniris_mods"] = [m for m in root.modules() if isinstance(m, NormalizedWeight)]
     if bank is None or bank._n_mods != len(mods) or any(m.pw is None or m.pw.param is not m.weight or m.pw.bank is not bank
                                                         for m in mods):
         bank = ops.WeightBank()

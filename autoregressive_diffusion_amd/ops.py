@@ -14,12 +14,20 @@ from ._lib import lib, check
 BF16 = torch.bfloat16
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a raw handle (every kernel launch calls this: the raw getter
+    avoids building a torch.cuda.Stream object per launch, ~1.5 ms of host time per training step)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _p(t):
-    return None if t is None else ctypes.c_void_p(t.data_ptr())
+    """Device pointer as a plain int (ctypes converts it for c_void_p arguments and struct fields; None = NULL)."""
+    return None if t is None else t.data_ptr()
 
 
 def _need_gpu(*ts):
