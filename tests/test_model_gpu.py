@@ -293,6 +293,46 @@ def test_cs_shaped_unet_vs_oracle(tag, cfg, Tn, labelled):
         assert prm["unet.emb_label.weight.weight"].grad is None or float(prm["unet.emb_label.weight.weight"].grad.abs().max()) == 0
 
 
+@pytest.mark.parametrize("tag,Tn,j", [("gym", 64, 41), ("cs", 32, 19), ("cs64", 64, 50)])
+def test_full_size_causality_and_batch_independence(tag, Tn, j):
+    """BASELINE configs[1] / [2] / [3] at FULL size (gym net 46.2 M with T = 64: L = 8192 tokens per VideoAttention
+    layer; Counter-Strike net 310 M with T = 32 and T = 64, P = 16 so 8 frames share a 128-token mask block),
+    training-mode forward.  Size-independent properties of the path, checked bit-exactly inside ONE call (a
+    training-mode call re-normalises the weights in place, conv.py:16-18, so two calls are not comparable bit for
+    bit): the batch holds [a, b, a', b] where a' = a with clean frame j and noised frame j perturbed.  Then
+    (1) the two copies of b agree exactly (nothing mixes sequences, every kernel is deterministic),
+    (2) every output frame < j of a' equals a's, in both halves (the DART mask lets noised frame f see only clean
+        frames < f and itself, the causal conv reads the two PREVIOUS clean frames, everything else is per slot),
+    (3) frames >= j differ."""
+    from edm2.networks_edm2 import UNet, Precond
+    torch.manual_seed(11)
+    cfg = GYM_FULL if tag == "gym" else CS_FULL
+    res = cfg["img_resolution"]
+    net = Precond(UNet(**cfg), sigma_data=1.0).to(DEV).train()
+    for m in net.modules():
+        if hasattr(m, "emb_gain"):
+            torch.nn.init.constant_(m.emb_gain, 0.3)
+    torch.nn.init.constant_(net.unet.out_gain, 1.0)
+    g = torch.Generator().manual_seed(12)
+    xa, xb = (torch.randn(2 * Tn, 8, res, res, generator=g) for _ in range(2))
+    sa, sb = ((torch.randn(2 * Tn, generator=g) + 1.2).exp() for _ in range(2))
+    la, lb = (torch.randint(0, 4, (2 * Tn,), generator=g) for _ in range(2))
+    xa2 = xa.clone()
+    xa2[j] += 0.5
+    xa2[Tn + j] -= 0.5
+    x = torch.stack([xa, xb, xa2, xb]).to(DEV)
+    sigma = torch.stack([sa, sb, sa, sb]).to(DEV)
+    lab = torch.stack([la, lb, la, lb]).to(DEV) if tag == "gym" else None       # cs_train.py:103: no conditioning
+    with torch.no_grad():
+        d, _ = net(x, sigma, lab)
+    assert torch.isfinite(d).all()
+    assert torch.equal(d[1], d[3]), "identical sequences in different batch slots disagree"
+    assert torch.equal(d[0, :j], d[2, :j]), "clean frames before the perturbed one changed"
+    assert torch.equal(d[0, Tn:Tn + j], d[2, Tn:Tn + j]), "noised frames before the perturbed one changed"
+    for f in (j, j + 1, Tn - 1):
+        assert not torch.equal(d[0, f], d[2, f]) and not torch.equal(d[0, Tn + f], d[2, Tn + f]), f
+
+
 def test_hipgraph_step_matches_eager():
     """The captured-and-replayed training micro-step (graphs.GraphedStep) follows the eager trajectory."""
     from edm2.loss import EDM2Loss
