@@ -333,6 +333,32 @@ def test_full_size_causality_and_batch_independence(tag, Tn, j):
         assert not torch.equal(d[0, f], d[2, f]) and not torch.equal(d[0, Tn + f], d[2, Tn + f]), f
 
 
+def test_full_size_gradient_causality():
+    """Backward counterpart at full size (gym net, B = 2, T = 64): the loss reads only the outputs of frames < j of
+    sequence 0, so the gradient with respect to the input must be EXACTLY zero for every frame >= j of sequence 0
+    (both halves: nothing later can influence an earlier frame) and for the whole of sequence 1, and non-zero before."""
+    from edm2.networks_edm2 import UNet, Precond
+    torch.manual_seed(13)
+    net = Precond(UNet(**GYM_FULL), sigma_data=1.0).to(DEV).train()
+    for m in net.modules():
+        if hasattr(m, "emb_gain"):
+            torch.nn.init.constant_(m.emb_gain, 0.3)
+    torch.nn.init.constant_(net.unet.out_gain, 1.0)
+    B, Tn, j = 2, 64, 37
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, 2 * Tn, 8, 64, 64, generator=g).to(DEV).requires_grad_(True)
+    sigma = (torch.randn(B, 2 * Tn, generator=g) + 1.2).exp().to(DEV)
+    lab = torch.randint(0, 4, (B, 2 * Tn), generator=g).to(DEV)
+    d, _ = net(x, sigma, lab)
+    (d[0, :j].square().sum() + d[0, Tn:Tn + j].square().sum()).backward()
+    gx = x.grad
+    assert gx is not None and torch.isfinite(gx).all()
+    assert float(gx[1].abs().max()) == 0.0, "gradient leaked into the other sequence"
+    assert float(gx[0, j:Tn].abs().max()) == 0.0, "gradient reached clean frames >= j"
+    assert float(gx[0, Tn + j:].abs().max()) == 0.0, "gradient reached noised frames >= j"
+    assert float(gx[0, :j].abs().min(dim=0).values.max()) > 0 and float(gx[0, Tn:Tn + j].abs().sum()) > 0
+
+
 def test_hipgraph_step_matches_eager():
     """The captured-and-replayed training micro-step (graphs.GraphedStep) follows the eager trajectory."""
     from edm2.loss import EDM2Loss
