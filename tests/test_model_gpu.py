@@ -359,6 +359,40 @@ def test_full_size_gradient_causality():
     assert float(gx[0, :j].abs().min(dim=0).values.max()) > 0 and float(gx[0, Tn:Tn + j].abs().sum()) > 0
 
 
+def test_full_size_cached_equals_uncached():
+    """The reference's own consistency property (consistency_test.py:129-172,261-307) on the FULL gym net in eval
+    mode: denoising 8 frames in one causal call equals denoising them one at a time against the KV / activation
+    caches (different kernels: causal prefill vs single-frame decode with split-K convs), and a 5 + 3 split too."""
+    from edm2.networks_edm2 import UNet, Precond
+    torch.manual_seed(15)
+    net = Precond(UNet(**GYM_FULL), sigma_data=1.0).to(DEV).eval()
+    for m in net.modules():
+        if hasattr(m, "emb_gain"):
+            torch.nn.init.constant_(m.emb_gain, 0.3)
+    torch.nn.init.constant_(net.unet.out_gain, 1.0)
+    g = torch.Generator().manual_seed(16)
+    t = 8
+    x = torch.randn(1, t, 8, 64, 64, generator=g).to(DEV)
+    sigma = (torch.randn(1, t, generator=g) * 0.5).exp().to(DEV)
+    lab = torch.randint(0, 4, (1, t), generator=g).to(DEV)
+    with torch.no_grad():
+        full, _ = net(x, sigma, lab)
+        cache, outs = None, []
+        for k in range(t):
+            o, cache = net(x[:, k:k + 1], sigma[:, k:k + 1], lab[:, k:k + 1], cache=cache, update_cache=True)
+            outs.append(o)
+        step = torch.cat(outs, 1)
+        a, cache = net(x[:, :5], sigma[:, :5], lab[:, :5], update_cache=True)
+        errs = []
+        for k in range(5, t):
+            o, cache = net(x[:, k:k + 1], sigma[:, k:k + 1], lab[:, k:k + 1], cache=cache, update_cache=True)
+            errs.append(rel(o, full[:, k:k + 1].cpu().numpy()))
+    e1, e2 = rel(step, full.cpu().numpy()), rel(a, full[:, :5].cpu().numpy())
+    print("cached vs uncached (full gym net): frame-by-frame", e1, "prefill 5", e2, "then decode", errs)
+    assert cache["n_context_frames"] == t
+    assert e1 < 1e-2 and e2 < 1e-2 and max(errs) < 1e-2
+
+
 def test_hipgraph_step_matches_eager():
     """The captured-and-replayed training micro-step (graphs.GraphedStep) follows the eager trajectory."""
     from edm2.loss import EDM2Loss
