@@ -50,6 +50,7 @@ class VideoAttention(_AttentionBase):
             return self._frame_cl(x, clip), cache
         N, H, W, C = x.shape
         P = H * W
+        self.__dict__["_tokens_per_frame"] = P               # (UNet.prewarm_eval sizes the next RoPE table from it)
         qkv = self.attn_qkv._cl(x).reshape(N, P, 3 * C)
         rope_bufs = (self.rope.inv_freq, self.rope.scale)
         if self.training:

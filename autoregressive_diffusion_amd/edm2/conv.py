@@ -112,6 +112,17 @@ class Gating(nn.Module):
 _nctx_cache = {}
 
 
+def nctx_tensor(n_ctx, dev):
+    """Per-layer frame counters as a device vector: one host->device copy per distinct frame count (the sampler
+    evaluates the net 31 times per frame; cached so that the evaluation is hipGraph-capturable)."""
+    key = (tuple(n_ctx), str(dev))
+    if key not in _nctx_cache:
+        if len(_nctx_cache) > 64:
+            _nctx_cache.clear()
+        _nctx_cache[key] = torch.tensor(list(n_ctx), device=dev).reshape(-1, 1, 1)
+    return _nctx_cache[key]
+
+
 def batched_gates(convs, c_noise, caches, training):
     """All Gating modules of a net in ONE vectorised evaluation (identical math to Gating.forward, conv.py:113-127):
     replaces ~60 x 20 tiny elementwise launches per step by ~20.  Returns per-layer (ca, cb, n_new)."""
@@ -125,12 +136,7 @@ def batched_gates(convs, c_noise, caches, training):
     hi = torch.sigmoid(torch.stack([m.gating.max_gating for m in convs]))[:, None, None]
     base = (torch.arange(B * tt, device=dev) % T).reshape(1, B, tt)
     if any(n_ctx):
-        key = (tuple(n_ctx), str(dev))
-        if key not in _nctx_cache:                     # one host->device copy per distinct frame count (the sampler
-            if len(_nctx_cache) > 64:                  # evaluates the net 31 times per frame; hipGraph-capturable)
-                _nctx_cache.clear()
-            _nctx_cache[key] = torch.tensor(n_ctx, device=dev).reshape(-1, 1, 1)
-        base = base + _nctx_cache[key]
+        base = base + nctx_tensor(n_ctx, dev)
     pos = base.to(c_noise.dtype).log1p()              # (no host->device copy in training: hipGraph-capturable)
     sv = c_noise[None] * mult[:, 0, None, None] + off[:, 0, None, None] + pos * mult[:, 1, None, None] + off[:, 1, None, None]
     g = (lo + (1 - lo) * hi * torch.sigmoid(sv)).reshape(len(convs), -1)

@@ -238,6 +238,41 @@ class UNet(BetterModule):
         early = [w for ws in per[at + 1:] for w in ws] + tail_dec
         return names[at], [w for w in early if w.requires_grad]
 
+    def prewarm_eval(self, cache):
+        """Build, OUTSIDE any hipGraph capture, the small per-frame-count device tables the next cached one-frame
+        evaluation will ask for (RoPE tables for the grown key length, the gates' frame-counter vector): they are
+        host->device uploads and must not happen inside a capture (edm2/sampler.py _GraphedDenoiser)."""
+        from .conv import nctx_tensor
+        dev = self.out_gain.device
+        convs, caches = self._gate_layers(cache)
+        n_ctx = [int(c.get("n_context_frames", 0)) if c else 0 for c in caches]
+        if any(n_ctx):
+            nctx_tensor(n_ctx, dev)
+        for side, blocks in (("enc", self.enc), ("dec", self.dec)):
+            for name, block in blocks.items():
+                att = getattr(block, "attn", None)
+                kv = (cache.get((side, name)) or {}).get("attn") if isinstance(block, Block) else None
+                if att is None or kv is None or not hasattr(att, "rope") or "_tokens_per_frame" not in att.__dict__:
+                    continue
+                nk = kv[0].shape[1] // att.__dict__["_tokens_per_frame"] + 1
+                ops.rope_tables(att.rope.inv_freq, att.rope.scale, nk, dev)
+
+    def _gate_layers(self, cache):
+        convs, caches = [], []
+
+        def visit(mod, c):
+            if isinstance(mod, MPCausal3DGatedConv):
+                convs.append(mod); caches.append(c)
+            else:
+                c = c or {}
+                convs.extend([mod.conv_res0, mod.conv_res1]); caches.extend([c.get("conv_res0"), c.get("conv_res1")])
+        for name, block in self.enc.items():
+            visit(block, cache.get(("enc", name)))
+        for name, block in self.dec.items():
+            visit(block, cache.get(("dec", name)))
+        visit(self.out_conv, cache.get("out_conv"))
+        return convs, caches
+
     def _prime_gates(self, c_noise, cache):
         """Evaluate the gates of all gated convs at once and hand each layer its (ca, cb, counter)."""
         convs, caches = [], []

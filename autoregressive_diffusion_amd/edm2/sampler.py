@@ -11,9 +11,9 @@ _graph_pool = None
 
 class _GraphedDenoiser:
     """The cache-reading UNet evaluations of ONE generated frame (30 of its 31: same cache, same shapes, only x and
-    sigma change) replayed from a hipGraph: the first evaluation runs eagerly (builds the mask / RoPE / gate tables
-    of this frame count), the second is captured, the rest are replays -- ~450 kernel launches per evaluation
-    without their host cost.  The last evaluation of the frame updates the cache and stays eager.  A new graph per
+    sigma change) replayed from a hipGraph: the per-frame-count tables (RoPE, gate counters) are built first
+    (UNet.prewarm_eval), the first evaluation is captured, the rest are replays -- ~400 kernel launches per
+    evaluation without their host cost.  The last evaluation of the frame updates the cache and stays eager.  A new graph per
     frame: the KV length and the cache tensors change with every frame."""
 
     def __init__(self, net, cache, conditioning, B, dtype, device):
@@ -24,9 +24,13 @@ class _GraphedDenoiser:
     def __call__(self, x, t):
         global _graph_pool
         self.calls += 1
-        if self.calls == 1:                                        # eager warm-up (tables for this frame count)
-            Dx, _ = self.net(x, self.t * t, self.cond, cache=self.cache, update_cache=False, just_2d=False)
-            return Dx
+        if self.calls == 1:
+            unet = getattr(self.net, "unet", None)
+            if hasattr(unet, "prewarm_eval"):                      # tables for this frame count, built outside the capture
+                unet.prewarm_eval(self.cache)
+            else:                                                  # unknown net: one eager evaluation builds them
+                Dx, _ = self.net(x, self.t * t, self.cond, cache=self.cache, update_cache=False, just_2d=False)
+                return Dx
         self.t.fill_(1.0).mul_(t)
         if self.graph is None:
             self.x = x.clone()
