@@ -80,6 +80,12 @@ _SIGS = {
                                       c_float, c_float, c_int, c_float, c_void_p, c_float, c_void_p, c_float, c_void_p,
                                       c_float, c_void_p]),
     "oniris_sqnorm": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
+    "oniris_dart_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_float, c_void_p]),
+    "oniris_dart_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                 c_int, c_int, c_float, c_void_p]),
+    "oniris_dart_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                     c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "oniris_conv_fwd": (c_int, [C.POINTER(ConvArgs), c_void_p]),
     "oniris_conv_wgrad": (c_int, [C.POINTER(WgradArgs), c_void_p]),
     "oniris_conv_wgrad_group": (c_int, [C.POINTER(WgradArgs), c_int, c_void_p]),

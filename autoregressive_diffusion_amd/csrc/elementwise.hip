@@ -291,3 +291,118 @@ extern "C" int oniris_resample(const void* in, void* out, int64_t N, int H, int 
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// DART training input / loss (edm2/loss.py:17-47 + Precond.forward, networks_edm2.py:278-297) without the ~25
+// activation-sized fp32 passes of the eager formulation.  Slot n = (b, s, t), s = 0 clean | 1 noised (S = 1: 2-D
+// steps); x[n] = images[b,t] + sigma[b, s*T+t] * noise[b, s*T+t]  (NCHW fp32 inputs, never materialised).
+//   dart_input:   UNet input c_in*x, channels-last bf16, channel C = 1 (the reference's ones channel), rest 0
+//   dart_loss:    per noised frame  mean_{c,h,w} (c_skip*x + c_out*out_gain*F - images)^2   (one block per frame)
+//   dart_loss_bwd: dF (bf16, zero for the clean slots) and per-frame partial sums of d out_gain
+__global__ __launch_bounds__(256) void dart_input_kernel(const float* __restrict__ img, const float* __restrict__ noise,
+                                                         const float* __restrict__ sigma, bf16* __restrict__ xcl, int S,
+                                                         int T, int C, int HW, float sd) {
+  const int n = blockIdx.y, b = n / (S * T), st = n % (S * T), t = st % T;
+  const float sg = sigma[b * S * T + st];
+  const float cin = 1.f / sqrtf(sd * sd + sg * sg);
+  const float* ip = img + (size_t)(b * T + t) * C * HW;
+  const float* np_ = noise + (size_t)(b * S * T + st) * C * HW;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    bf16 o[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      float v = 0.f;
+      if (c < C) v = cin * __fadd_rn(ip[(size_t)c * HW + p], __fmul_rn(sg, np_[(size_t)c * HW + p]));
+      else if (c == C) v = 1.f;
+      o[c] = f2bf(v);
+    }
+    uint4* dst = (uint4*)(xcl + ((size_t)n * HW + p) * 16);
+    dst[0] = *(const uint4*)&o[0];
+    dst[1] = *(const uint4*)&o[8];
+  }
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void dart_loss_kernel(const bf16* __restrict__ F, const float* __restrict__ img,
+                                                        const float* __restrict__ noise, const float* __restrict__ sigma,
+                                                        const float* __restrict__ out_gain, const float* __restrict__ g,
+                                                        float* __restrict__ losses, bf16* __restrict__ dF,
+                                                        float* __restrict__ dgain, int S, int T, int C, int HW, float sd) {
+  __shared__ float red[16];
+  const int n = blockIdx.x, b = n / (S * T), st = n % (S * T), s = st / T, t = st % T;
+  if (s != S - 1) {                               // clean half: not part of the loss (loss.py:38 uses out[:, -T:])
+    if (BWD)
+      for (int p = threadIdx.x; p < HW; p += 256) *(uint4*)(dF + ((size_t)n * HW + p) * 8) = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  const float sg = sigma[b * S * T + st], og = out_gain[0];
+  const float den = sg * sg + sd * sd;
+  const float cskip = sd * sd / den, cout = sg * sd / sqrtf(den);
+  const float* ip = img + (size_t)(b * T + t) * C * HW;
+  const float* np_ = noise + (size_t)(b * S * T + st) * C * HW;
+  const float inv = 1.f / (float)(C * HW);
+  const float gl = BWD ? g[b * T + t] * 2.f * inv : 0.f;
+  float acc = 0.f;
+  for (int p = threadIdx.x; p < HW; p += 256) {
+    const uint4 fv = *(const uint4*)(F + ((size_t)n * HW + p) * 8);
+    const bf16* f = (const bf16*)&fv;
+    bf16 o[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      float d = 0.f;
+      if (c < C) {
+        const float im = ip[(size_t)c * HW + p];
+        const float x = __fadd_rn(im, __fmul_rn(sg, np_[(size_t)c * HW + p]));
+        const float fo = bf2f(f[c]);
+        const float e = cskip * x + cout * (fo * og) - im;
+        if (BWD) { d = gl * e * cout; acc += d * fo; d *= og; }
+        else acc += e * e;
+      }
+      o[c] = f2bf(d);
+    }
+    if (BWD) *(uint4*)(dF + ((size_t)n * HW + p) * 8) = *(const uint4*)&o[0];
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) {
+    if (BWD) dgain[b * T + t] = acc;
+    else losses[b * T + t] = acc * inv;
+  }
+}
+
+extern "C" int oniris_dart_input(const float* images, const float* noise, const float* sigma, void* xcl, int B, int S,
+                                 int T, int C, int H, int W, float sigma_data, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(images && noise && sigma && xcl && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 && C < 16 && H > 0 && W > 0,
+                   "dart_input: bad arguments");
+  const int HW = H * W;
+  int gx = cdiv(HW, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(dart_input_kernel, dim3(gx, B * S * T), dim3(256), 0, stream, images, noise, sigma, (bf16*)xcl, S, T, C,
+                     HW, sigma_data);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_dart_loss(const void* F, const float* images, const float* noise, const float* sigma,
+                                const float* out_gain, float* losses, int B, int S, int T, int C, int H, int W,
+                                float sigma_data, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(F && images && noise && sigma && out_gain && losses && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 &&
+                   C <= 8 && H > 0 && W > 0, "dart_loss: bad arguments");
+  hipLaunchKernelGGL(dart_loss_kernel<false>, dim3(B * S * T), dim3(256), 0, stream, (const bf16*)F, images, noise, sigma,
+                     out_gain, (const float*)nullptr, losses, (bf16*)nullptr, (float*)nullptr, S, T, C, H * W, sigma_data);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_dart_loss_bwd(const void* F, const float* images, const float* noise, const float* sigma,
+                                    const float* out_gain, const float* dlosses, void* dF, float* dgain_part, int B, int S,
+                                    int T, int C, int H, int W, float sigma_data, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(F && images && noise && sigma && out_gain && dlosses && dF && dgain_part && B > 0 && (S == 1 || S == 2) &&
+                   T > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "dart_loss_bwd: bad arguments");
+  hipLaunchKernelGGL(dart_loss_kernel<true>, dim3(B * S * T), dim3(256), 0, stream, (const bf16*)F, images, noise, sigma,
+                     out_gain, dlosses, (float*)nullptr, (bf16*)dF, dgain_part, S, T, C, H * W, sigma_data);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}

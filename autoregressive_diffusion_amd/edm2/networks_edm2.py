@@ -149,11 +149,16 @@ class UNet(BetterModule):
         args, _, _, values = inspect.getargvalues(frame)
         self.kwargs = {arg: values[arg] for arg in args if arg != "self"}
 
-    def forward(self, x, c_noise, conditioning=None, cache=None, update_cache=False, just_2d=False):
+    _oniris_cl_io = True        # forward(..., _cl_io=(B, tt)) takes / returns channels-last bf16 (edm2/loss.py fast path)
+
+    def forward(self, x, c_noise, conditioning=None, cache=None, update_cache=False, just_2d=False, _cl_io=None):
+        """_cl_io = (B, tt): `x` is already the packed UNet input (B*tt, H, W, 16) bf16 with the ones channel
+        (ops.dart_input) and the raw channels-last output (B*tt, H, W, 8k) bf16 is returned WITHOUT out_gain -- the
+        fused DART loss applies it (ops.dart_loss).  Default: the reference signature (:191)."""
         if cache is None:
             cache = {}
         with weights_ready(self):
-            B, tt = x.shape[:2]
+            B, tt = x.shape[:2] if _cl_io is None else _cl_io
             n_ctx = cache.get("n_context_frames", 0)
             _, n_new = self.out_res(c_noise, n_ctx, just_2d)              # frame counter (value unused, :197)
             if update_cache:
@@ -169,9 +174,12 @@ class UNet(BetterModule):
             emb = emb.to(BF16)[:, None, None, :].contiguous()
             # input: (B,t,C,H,W) -> channels-last with the extra all-ones channel (:221), padded to 16 channels
             N = B * tt
-            xc = x.reshape(N, *x.shape[2:])
-            xc = torch.cat([xc, torch.ones_like(xc[:, :1])], dim=1)
-            xcl = to_cl(xc, pad_to=-(-xc.shape[1] // 16) * 16)
+            if _cl_io is None:
+                xc = x.reshape(N, *x.shape[2:])
+                xc = torch.cat([xc, torch.ones_like(xc[:, :1])], dim=1)
+                xcl = to_cl(xc, pad_to=-(-xc.shape[1] // 16) * 16)
+            else:
+                xcl = x
             if not just_2d:
                 self._prime_gates(c_noise, cache)
             blocks = self._emb_blocks()
@@ -199,6 +207,8 @@ class UNet(BetterModule):
                 xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d,
                                                     skip=skip, cat_w=cat_w, c=cs[id(block)])
             xcl, cache["out_conv"] = self.out_conv._cl(xcl, B, c_noise, cache.get("out_conv"), update_cache, just_2d)
+            if _cl_io is not None:
+                return xcl, cache
             out = from_cl(xcl[..., :self.img_channels], torch.float32)
             out = out.reshape(B, tt, *out.shape[1:]) * self.out_gain
             return out, cache

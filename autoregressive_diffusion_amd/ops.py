@@ -975,6 +975,51 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
 # ------------------------------------------------------------------------------------------------------------------
 # optimizer
 
+def dart_input(images, noise, sigma, S, sigma_data):
+    """Packed UNet input of a DART training step (oniris_dart_input): images (B,T,C,H,W), noise (B,S*T,C,H,W), sigma
+    (B,S*T) fp32 -> (B*S*T, H, W, 16) bf16 = c_in * (images + sigma*noise) with the ones channel."""
+    _need_gpu(images, noise, sigma)
+    B, T, C, H, W = images.shape
+    xcl = torch.empty((B * S * T, H, W, 16), dtype=BF16, device=images.device)
+    check(lib.oniris_dart_input(_p(images), _p(noise), _p(sigma), _p(xcl), B, S, T, C, H, W, float(sigma_data), _stream()),
+          "dart_input")
+    return xcl
+
+
+class _DartLoss(torch.autograd.Function):
+    """losses[b,t] = mean_{c,h,w} (c_skip*x + c_out*out_gain*F - images)^2 over the noised half (edm2/loss.py:37-38 with
+    Precond's output scaling, networks_edm2.py:293-297); F = raw channels-last UNet output.  Backward writes dF in
+    bf16 directly (zero for the clean slots) and d out_gain."""
+
+    @staticmethod
+    def forward(ctx, F, out_gain, images, noise, sigma, S, sigma_data):
+        _need_gpu(F, images, noise, sigma)
+        B, T, C, H, W = images.shape
+        assert F.dtype == BF16 and F.shape == (B * S * T, H, W, 8) and F.is_contiguous()
+        og = out_gain.detach().float().reshape(1).contiguous()
+        losses = torch.empty((B, T), dtype=torch.float32, device=F.device)
+        check(lib.oniris_dart_loss(_p(F), _p(images), _p(noise), _p(sigma), _p(og), _p(losses), B, S, T, C, H, W,
+                                   float(sigma_data), _stream()), "dart_loss")
+        ctx.save_for_backward(F, og, images, noise, sigma)
+        ctx.cfg = (S, float(sigma_data), out_gain.shape)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        F, og, images, noise, sigma = ctx.saved_tensors
+        S, sd, gshape = ctx.cfg
+        B, T, C, H, W = images.shape
+        dF = torch.empty_like(F)
+        part = torch.empty((B, T), dtype=torch.float32, device=F.device)
+        check(lib.oniris_dart_loss_bwd(_p(F), _p(images), _p(noise), _p(sigma), _p(og), _p(g.float().contiguous()), _p(dF),
+                                       _p(part), B, S, T, C, H, W, sd, _stream()), "dart_loss_bwd")
+        return dF, part.sum().reshape(gshape), None, None, None, None, None
+
+
+def dart_loss(F, out_gain, images, noise, sigma, S, sigma_data):
+    return _DartLoss.apply(F, out_gain, images, noise, sigma, S, sigma_data)
+
+
 SQNORM_WS = 1024          # ONIRIS_SQNORM_WS in include/oniris.h
 
 

@@ -76,6 +76,22 @@ int oniris_weight_prep(const OnirisWeightDesc* descs, int ndesc, int total_rows,
                        oniris_stream_t stream);
 int oniris_weight_bwd(const OnirisWeightDesc* descs, int ndesc, int total_rows, oniris_stream_t stream);
 
+/* DART training input and loss (edm2/loss.py:17-47 with Precond.forward, networks_edm2.py:278-297) as three passes
+ * instead of ~25 activation-sized fp32 elementwise launches.  images [B][T][C][H][W], noise [B][S*T][C][H][W], sigma
+ * [B][S*T] fp32; slot n = (b, s, t), s = 0 clean | 1 noised (S = 1 in 2-D steps); x[n] = images[b,t] + sigma*noise is
+ * never materialised.
+ *   dart_input:    xcl bf16 [B*S*T][H][W][16] = c_in * x, channel C = 1 (ones channel), the rest 0          (C < 16)
+ *   dart_loss:     losses[b][t] = mean_{c,h,w} (c_skip*x + c_out*out_gain*F - images)^2 of the noised half; F = the
+ *                  UNet's channels-last output bf16 [B*S*T][H][W][8], out_gain a device scalar             (C <= 8)
+ *   dart_loss_bwd: dF (bf16, zero for clean slots) and dgain_part[b][t] (sum them for d out_gain) from dlosses[b][t] */
+int oniris_dart_input(const float* images, const float* noise, const float* sigma, void* xcl, int B, int S, int T, int C,
+                      int H, int W, float sigma_data, oniris_stream_t stream);
+int oniris_dart_loss(const void* F, const float* images, const float* noise, const float* sigma, const float* out_gain,
+                     float* losses, int B, int S, int T, int C, int H, int W, float sigma_data, oniris_stream_t stream);
+int oniris_dart_loss_bwd(const void* F, const float* images, const float* noise, const float* sigma,
+                         const float* out_gain, const float* dlosses, void* dF, float* dgain_part, int B, int S, int T,
+                         int C, int H, int W, float sigma_data, oniris_stream_t stream);
+
 /* Fused AdamW over flat fp32 buffers (the optimizer step of gym_train.py:105-106 / cs_train.py:117-118).       */
 int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream);

@@ -199,6 +199,37 @@ def test_g8_unet_loss(tag, cfg):
             assert g is None or float(g.abs().max()) == 0.0, n
 
 
+@pytest.mark.parametrize("mode", ["3d", "2d"])
+def test_fused_dart_loss_matches_eager_path(mode, monkeypatch):
+    """EDM2Loss through the three fused passes (oniris_dart_input / dart_loss / dart_loss_bwd) against the same loss
+    through Precond.forward and torch elementwise ops: loss, un-weighted loss and every gradient (incl. out_gain)."""
+    import edm2.loss as L
+    g = torch.Generator().manual_seed(21)
+    B, Tn = 2, 4
+    images = torch.randn(B, Tn, 8, 64, 64, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (B, Tn), generator=g).to(DEV)
+    n = Tn if mode == "2d" else 2 * Tn
+    sigma = (torch.randn(B, n, generator=g) + 0.4).exp().to(DEV)
+    eps = torch.randn(B, n, 8, 64, 64, generator=g).to(DEV)
+    res = {}
+    for fused in (1, 0):
+        monkeypatch.setattr(L, "FUSED", fused)
+        net = build_precond(C1_CFG, 31, 1.0).train()
+        loss, unw = L.EDM2Loss(sigma_data=1.0)(net, images, labels, sigma=sigma, just_2d=(mode == "2d"), noise=eps)
+        loss.backward()
+        res[fused] = (loss.item(), unw, {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert abs(res[1][0] - res[0][0]) <= 2e-3 * abs(res[0][0]) and abs(res[1][1] - res[0][1]) <= 2e-3 * abs(res[0][1])
+    assert set(res[1][2]) == set(res[0][2])
+    worst = max(res[0][2], key=lambda k: rel(res[1][2][k], res[0][2][k].cpu().numpy()) if res[0][2][k].numel() > 2 else 0.0)
+    print("fused vs eager loss", res[1][0], res[0][0], "worst grad", worst, rel(res[1][2][worst], res[0][2][worst].cpu().numpy()),
+          "out_gain grad", res[1][2]["unet.out_gain"].item(), res[0][2]["unet.out_gain"].item())
+    for k, v in res[0][2].items():
+        if v.numel() > 2 and float(v.abs().max()) > 0:
+            assert rel(res[1][2][k], v.cpu().numpy()) < 2e-2, k
+    og1, og0 = res[1][2]["unet.out_gain"].item(), res[0][2]["unet.out_gain"].item()
+    assert abs(og1 - og0) <= 2e-2 * abs(og0) + 1e-6
+
+
 def test_g9_sampler_rollout():
     from edm2.sampler import edm_sampler_with_mse
     z = load("g9_sampler")
