@@ -1,5 +1,6 @@
 #include "conv_fwd_common.h"
 #include "conv_glds.h"
+#include "conv1x1_glds.h"
 
 // Plain 3x3 convs (the 2-D training steps, stem / non-gated layers): with big_tile >= 3 and an even frame count they
 // run on the persistent LDS-DMA kernel as "two slots of T/2 frames, no context phases".
@@ -16,6 +17,7 @@ int conv_dispatch_s1(const OnirisConvArgs& a, hipStream_t st) {
   return conv3x3_pick<1, false>(a, st);
 }
 int conv_dispatch_1x1(const OnirisConvArgs& a, hipStream_t st) {
+  if (a.big_tile >= 3 && conv1x1_glds_ok(a)) return launch_conv1x1_glds(a, st);     // persistent LDS-DMA GEMM
   if (a.CoutP % 64 == 0) return launch_conv_fwd<1, 1, 64, 2, false, 16>(a, st);
   return launch_conv_fwd<1, 1, 64, 1, false, 16>(a, st);
 }

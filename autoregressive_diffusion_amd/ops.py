@@ -380,6 +380,9 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
               and ((H % 16 == 0 and W % 16 == 0) or (H == 8 and W == 8 and CoutP % 64 == 0))):   # conv_dispatch_s1()
             key = (f"conv_glds_kernel<NT={nt},PW=16,NW=8,MT=1,WC=1,CTX=0>" if H % 16 == 0 else
                    "conv_glds_kernel<NT=1,PW=8,NW=8,MT=1,WC=2,CTX=0>")
+        elif (BIG_TILE >= 3 and taps == 1 and ctx is None and Cin % 64 == 0 and CinP == Cin and epi in (0, _lib.EPI_MPSUM)
+              and B * S * T * H * W >= 8192):                 # conv1x1_glds_ok() in csrc/conv1x1_glds.h
+            key = "conv1x1_glds_kernel"
         else:
             key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

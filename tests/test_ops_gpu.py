@@ -97,6 +97,9 @@ def test_weight_perm3():
 
 @pytest.mark.parametrize("N,H,cin,cout,k", [(6, 16, 32, 64, 3), (5, 8, 96, 32, 3), (16, 4, 64, 64, 3), (3, 32, 16, 40, 3),
                                             (7, 8, 64, 192, 1), (3, 16, 48, 32, 1), (130, 1, 64, 96, 1),
+                                            # 1x1 with >= 8192 positions and Cin % 64 == 0: the LDS-DMA GEMM (conv1x1_glds.h);
+                                            # ragged last position tile, Cout not a multiple of the 128-channel tile
+                                            (15, 24, 64, 192, 1), (9, 32, 128, 136, 1), (8, 32, 192, 64, 1), (2, 64, 256, 768, 1),
                                             # even frame counts on Cin % 32 == 0: the LDS-DMA kernel without context phases
                                             (4, 8, 32, 128, 3), (2, 32, 32, 32, 3), (10, 16, 64, 96, 3)])
 def test_conv_plain(N, H, cin, cout, k):
@@ -236,6 +239,35 @@ def test_gated_conv_eval_one_frame_splitk(B, H, cin, cout, epi, monkeypatch):
     print("one-frame eval", (B, H, cin, cout, epi), "rel", e, "split vs unsplit max abs", d)
     assert e < 1e-2
     assert d <= 2.0 ** -6 * max(1.0, float(outs[0].abs().max()))          # one bf16 ulp of the largest value
+
+
+@pytest.mark.parametrize("N,H,cin,cout,clip", [(9, 32, 128, 128, 2.0), (15, 24, 64, 200, 0.0), (33, 16, 256, 256, 3.0)])
+def test_conv1x1_mpsum_large(N, H, cin, cout, clip):
+    """attn_proj-shaped op on the LDS-DMA GEMM: out = clip(ta*res + tb*(W x)) with >= 8192 positions, + gradients."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(cin + N)
+    w0 = O.normalize(O.normalize(torch.randn(cout, cin, 1, 1)))
+    p = torch.nn.Parameter(w0.clone().to(DEV))
+    bank, (pw,) = make_bank([p])
+    bank.prepare(training=True)
+    x0, r0 = bfr(torch.randn(N, cin, H, H)), bfr(torch.randn(N, cout, H, H) * 1.5)
+    gy0 = bfr(torch.randn(N, cout, H, H))
+    x, res = nhwc(x0).requires_grad_(True), nhwc(r0).requires_grad_(True)
+    y = ops.conv(x, pw, res=res, ta=0.8, tb=0.6, clip=clip)
+    y.backward(nhwc(gy0))
+    bank.backward()
+    wr, xr, rr = w0.clone().requires_grad_(True), x0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
+    w_eff, _ = O.weight_effective(wr, 1.0, training=True)
+    pre = 0.8 * rr + 0.6 * torch.nn.functional.conv2d(xr, w_eff)
+    if clip > 0:
+        keep = (nchw(y).abs() < clip).float()              # (mask from the bf16 result, see test_conv_epilogues)
+        yr = pre * keep + pre.detach().clamp(-clip, clip) * (1 - keep)
+    else:
+        yr = pre
+    (yr * gy0).sum().backward()
+    e = dict(y=rel(nchw(y), yr), dx=rel(nchw(x.grad), xr.grad), dres=rel(nchw(res.grad), rr.grad), dw=rel(p.grad, wr.grad))
+    print("conv1x1 mpsum", (N, H, cin, cout, clip), e)
+    assert e["y"] < 1e-2 and e["dx"] < 1.5e-2 and e["dres"] < 1e-2 and e["dw"] < 2e-2
 
 
 def _attn_ref(x0, wq, wp, B, m, training, just_2d=False, rope=True):
