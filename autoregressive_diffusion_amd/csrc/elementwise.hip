@@ -191,7 +191,8 @@ extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c
                    "emb_silu_bwd: bad arguments (C %% 8 == 0, C <= 512)");
   int slices = 1;
   const int npl = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
-  while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < 2048) slices *= 2;
+  // (every block ends with C global atomics: fewer, longer blocks are faster -- see oniris_gconv_bwd_fused)
+  while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < 512) slices *= 2;
   const int ppb = cdiv(P, slices);
   hipMemsetAsync(dc, 0, sizeof(float) * (size_t)N * C, stream);
   hipLaunchKernelGGL(emb_silu_bwd_kernel, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
