@@ -10,9 +10,14 @@ _capture_stream = None
 
 
 class GraphedStep:
-    def __init__(self, fn, warmup=3):
-        """fn(): runs forward+backward on STATIC input tensors and returns a (loss) tensor."""
+    def __init__(self, fn, warmup=3, params=None):
+        """fn(): runs forward+backward on STATIC input tensors and returns a (loss) tensor.
+        params: parameters whose .grad autograd (re)creates inside fn (FlatParams(lazy_small=True) sets them to None
+        before every backward): the tensors the CAPTURED backward assigned are the ones every replay writes, so they
+        are re-attached as .grad after each replay (otherwise FlatParams.gather() sees the stale aliases of the
+        previous step and the replayed gradients of ~190 small parameters are silently dropped)."""
         self.fn, self.warmup = fn, warmup
+        self.params, self._grads = list(params or ()), []
         self.graph, self.out, self.calls = None, None, 0
         # ONE side stream for the warm-up and the capture of EVERY GraphedStep: autograd pins each parameter's
         # AccumulateGrad node to the stream it was first used on; a node living on another stream would run outside
@@ -32,6 +37,8 @@ class GraphedStep:
             with torch.cuda.stream(self.stream):
                 self.graph.replay()
             cur.wait_stream(self.stream)
+            for p, g in self._grads:
+                p.grad = g
             return self.out
         self.calls += 1
         if self.calls <= self.warmup:              # eager warm-up: builds tables, sets kernel attributes, fills caches
@@ -45,4 +52,5 @@ class GraphedStep:
         with torch.cuda.graph(g, stream=self.stream):
             out = self.fn()
         self.graph, self.out = g, out
+        self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
         return self.__call__()

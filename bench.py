@@ -201,7 +201,7 @@ def main():
         else:
             def make(j2d):
                 return lambda: fwd_bwd(j2d)
-        graphed = {False: GraphedStep(make(False)), True: GraphedStep(make(True))}
+        graphed = {False: GraphedStep(make(False), params=flat.params), True: GraphedStep(make(True), params=flat.params)}
 
     _only = os.environ.get("ONIRIS_ONLY_MODE")
 

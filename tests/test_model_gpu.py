@@ -437,7 +437,7 @@ def test_hipgraph_step_matches_eager():
     traj = {}
     for mode in ("eager", "graph"):
         net = build_precond(SMALL_CFG, 55, 1.0).train()
-        flat = FlatParams(net.unet)
+        flat = FlatParams(net.unet, lazy_small=True)          # (autograd-owned gradients re-created every backward)
         opt = FlatAdamW(flat, lr=2e-3)
         loss_fn = EDM2Loss(sigma_data=1.0)
 
@@ -447,7 +447,8 @@ def test_hipgraph_step_matches_eager():
                               sync=False)
             loss.backward()
             return loss
-        steps = {False: GraphedStep(lambda: fwd_bwd(False)), True: GraphedStep(lambda: fwd_bwd(True))}
+        steps = {False: GraphedStep(lambda: fwd_bwd(False), params=flat.params),
+                 True: GraphedStep(lambda: fwd_bwd(True), params=flat.params)}
         out = []
         for i in range(20):
             j2d = (i % 4 == 0)
