@@ -5,6 +5,8 @@
 // (conv_glds.h: 8 waves, 16x16-pixel workgroup tiles) wherever the shape allows it.
 template <int NT>
 static int glds_pick(const OnirisConvArgs& a, hipStream_t st) {
+  if constexpr (NT == 1)            // one 32-channel chunk: all three phases of a tile are resident, copies run a tile ahead
+    if (a.Cin == 32 && a.big_tile != 7) return launch_conv_glds<1, 16, 8, 1, 1, true, true>(a, st);
   return launch_conv_glds<NT, 16, 8, 1>(a, st);
 }
 

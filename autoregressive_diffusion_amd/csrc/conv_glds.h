@@ -42,13 +42,18 @@ struct GldsCfg {
   static_assert(PW == 16 || PW == 8, "tile geometries of the LDS-DMA kernel");
   static constexpr int LDS_BYTES = (2 * BUF > EPI) ? 2 * BUF : EPI;
   static_assert(LDS_BYTES <= 160 * 1024, "two staging buffers must fit the 160 KB LDS");
+  // "resident" layout (RES, one 32-channel chunk = three phases per tile): own | ctx0 | ctx1 regions + a dedicated
+  // epilogue staging area, so that every region of tile t+1 is copied while tile t is still being worked on
+  static constexpr int BUFC = (SROWS + WROWS) * 64;
+  static constexpr int RES_EOFF = BUF + 2 * BUFC;
+  static constexpr int RES_BYTES = RES_EOFF + 2 * FT * BN * 4 + EPI;
   static_assert(2 * FT * BN * 4 + EPI <= BUF, "the epilogue stages through ONE of the two buffers");
   static_assert((NWP * 2 * HW) % 16 == 0 || MT == 1, "position tiles of a wave must be 16-row aligned apart");
 };
 
 // CTX = false: plain 3x3 convolution of an even number of frames, run as "two slots, no context phases" (the 2-D
 // training steps and every non-gated 3x3 conv): same tiles, one phase per 32-channel chunk.
-template <int NT, int PW, int NW, int MT, int WC = 1, bool CTX = true>
+template <int NT, int PW, int NW, int MT, int WC = 1, bool CTX = true, bool RES = false>
 __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(const ConvDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource builtins do not exist in the host pass (the stub needs no body)
   using Cfg = GldsCfg<NT, PW, NW, MT, WC>;
@@ -56,7 +61,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   constexpr int S = 2, TAPS = 9, CK = 32, KS = CK / 16, HW_ = Cfg::HW, HH_ = Cfg::HH, FT = Cfg::FT, NWP = Cfg::NWP;
   constexpr int NPH = CTX ? 3 : 1;                         // phases per channel chunk
   constexpr int BN = Cfg::BN, NTHR = Cfg::NTHR, AROWS = Cfg::AROWS, BUF = Cfg::BUF;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[Cfg::LDS_BYTES];     // static: see conv_kernels.h
+  static_assert(!RES || (CTX && FT == 1 && Cfg::RES_BYTES <= 160 * 1024), "resident layout: gated conv, one frame per tile");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[RES ? Cfg::RES_BYTES : Cfg::LDS_BYTES];     // static: see conv_kernels.h
 
   const OnirisConvArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
@@ -148,7 +154,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 
   auto issue = [&](const Tile& t, int ch, int ph, int bsel) __attribute__((always_inline)) {
     const int c0 = ch * CK;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + bsel * BUF + wave * 1024);   // + i * NW * 1024 per piece
+    // two alternating buffers, or (RES) the phase's own region: own at 0, ctx0 / ctx1 behind it (weights follow the
+    // SROWS context rows there)
+    const int boff = RES ? ((ph == 0) ? 0 : BUF + (ph - 1) * Cfg::BUFC) : bsel * BUF;
+    const int woff = (RES && ph != 0) ? Cfg::SROWS * 64 : AROWS * 64;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + boff + wave * 1024);   // + i * NW * 1024 per piece
     if (ph == 0) {
       const bf16* xb = (const bf16*)a.x + (size_t)t.b * S * T * frame_elems;
       const i32x4 rs_x = make_rsrc(xb, S * T * frame_elems * 2);
@@ -189,16 +199,16 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     if (ph == 0) {
 #pragma unroll
       for (int i = 0; i < NIW; ++i)
-        if ((i * NW + wave) * 64 + lane < TOTW) dma16(rs_wo, wdesc[i], sw, dst + AROWS * 64 + i * NW * 1024);
+        if ((i * NW + wave) * 64 + lane < TOTW) dma16(rs_wo, wdesc[i], sw, dst + woff + i * NW * 1024);
     } else {
 #pragma unroll
       for (int i = 0; i < NIW; ++i)
-        if ((i * NW + wave) * 64 + lane < TOTW) dma16(rs_wc, wdesc[i], sw, dst + AROWS * 64 + i * NW * 1024);
+        if ((i * NW + wave) * 64 + lane < TOTW) dma16(rs_wc, wdesc[i], sw, dst + woff + i * NW * 1024);
     }
   };
 
   // ---- fragment addresses (k-step 0; k-step 1 is the same address ^ 32)
-  const int wa0 = (wc * NT * 32 + r) * 64 + ((h ^ ((r >> 2) & 3)) << 4) + AROWS * 64;
+  const int wa0 = (wc * NT * 32 + r) * 64 + ((h ^ ((r >> 2) & 3)) << 4);          // + offset of the weight rows in the buffer
   // slot 1 and the wave's further position tiles are whole multiples of 16 rows away: same swizzle, constant offset
   int xa0[TAPS];
 #pragma unroll
@@ -210,17 +220,18 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   f32x16 acc[S][MT][NT];
   f32x16 accc[MT][NT];
 
-  auto mfma_steps = [&](auto own_, int bsel) __attribute__((always_inline)) {
+  auto mfma_steps = [&](auto own_, int boff, int woff) __attribute__((always_inline)) {
     constexpr bool OWN = decltype(own_)::value;
     constexpr int NX = OWN ? S : 1;
     constexpr int NSTEP = TAPS * KS;
-    const unsigned char* base = smem + bsel * BUF;
+    const unsigned char* base = smem + boff;
+    const unsigned char* wbase = base + woff;
     bf16x8 wf[2][NT], xf[2][NX][MT];
     auto ld = [&](int fb, int st) __attribute__((always_inline)) {
       const int tap = st / KS, ks = st % KS;
 #pragma unroll
       for (int n = 0; n < NT; ++n)
-        wf[fb][n] = *(const bf16x8*)(base + ((wa0 ^ (ks * 32)) + (tap * BN + n * 32) * 64));
+        wf[fb][n] = *(const bf16x8*)(wbase + ((wa0 ^ (ks * 32)) + (tap * BN + n * 32) * 64));
 #pragma unroll
       for (int s = 0; s < NX; ++s)
 #pragma unroll
@@ -255,6 +266,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   set_adesc(cur);
   int bsel = 0;
   issue(cur, 0, 0, 0);
+  if constexpr (RES) { issue(cur, 0, 1, 0); issue(cur, 0, 2, 0); }
+  Tile nxt = cur;
+  bool more = false;
+  int tl_next = tl;
 #pragma unroll 1
   for (;;) {
     dma_wait();
@@ -279,20 +294,23 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       if (co < a.Cout && cur.t0 + f_ < T)
         esc_v = ((const float*)a.escale)[(size_t)((cur.b * S + s_) * T + cur.t0 + f_) * a.Cout + co];
     }
+    if constexpr (!RES) {
 #pragma unroll 1
-    for (int itp = 0; itp < nphase; ++itp) {
-      const int ph = itp % NPH;
-      if (itp + 1 < nphase) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
-      if (!CTX || ph == 0) mfma_steps(std::true_type{}, bsel);
-      else mfma_steps(std::false_type{}, bsel);
-      dma_wait();                        // this wave's share of the next phase has landed ...
-      __syncthreads();                   // ... everybody's has; and everybody is done reading buffer bsel
-      bsel ^= 1;
+      for (int itp = 0; itp < nphase; ++itp) {
+        const int ph = itp % NPH;
+        if (itp + 1 < nphase) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
+        if (!CTX || ph == 0) mfma_steps(std::true_type{}, bsel * BUF, AROWS * 64);
+        else mfma_steps(std::false_type{}, bsel * BUF, AROWS * 64);
+        dma_wait();                        // this wave's share of the next phase has landed ...
+        __syncthreads();                   // ... everybody's has; and everybody is done reading buffer bsel
+        bsel ^= 1;
+      }
     }
     // Both buffers are free now.  The epilogue stages through buffer bsel^1 (the one just consumed); the first DMA of
-    // the next tile goes to buffer bsel, continuing the alternation.
-    unsigned char* stg = smem + (bsel ^ 1) * BUF;
+    // the next tile goes to buffer bsel, continuing the alternation.  (RES: a dedicated staging area.)
+    unsigned char* stg = smem + (RES ? Cfg::RES_EOFF : (bsel ^ 1) * BUF);
     unsigned char* ep = stg + ESC + wave * 32 * EROW;
+    if constexpr (RES) mfma_steps(std::true_type{}, 0, AROWS * 64);       // own phase (all three regions landed at the tile top)
 
     // -- epilogue inputs must not wait behind the next LDS-DMA (vmcnt is in order, and hipcc waits vmcnt(0) at the
     // first use of an ordinary load issued while DMA is in flight): gate coefficients and emb-scale were fetched at
@@ -303,10 +321,22 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     }
     asm volatile("" ::"v"(cown0), "v"(cown1), "v"(cctx0), "v"(cctx1));   // consume here: nothing is in flight at this point
     // -- first DMA of the next tile (runs under the epilogue below)
-    const int tl_next = tl + tl_step;
-    const bool more = tl_next < tl_hi;
-    Tile nxt = cur;
-    if (more) {
+    tl_next = tl + tl_step;
+    more = tl_next < tl_hi;
+    nxt = cur;
+    if constexpr (RES) {
+      // Resident layout: a region is refilled for the NEXT tile as soon as its phase of this tile is done, so every
+      // copy has the rest of the tile (one or two phases + the epilogue) to land, and the one wait at the tile top is
+      // the only one.  (Ordinary loads were consumed above: from here on DMA is always in flight.)
+      __syncthreads();                                   // everybody is done reading the own region
+      if (more) { nxt = decode(tl_next); set_adesc(nxt); issue(nxt, 0, 0, 0); }
+      mfma_steps(std::false_type{}, BUF, Cfg::SROWS * 64);
+      __syncthreads();
+      if (more) issue(nxt, 0, 1, 0);
+      mfma_steps(std::false_type{}, BUF + Cfg::BUFC, Cfg::SROWS * 64);
+      __syncthreads();
+      if (more) issue(nxt, 0, 2, 0);
+    } else if (more) {
       nxt = decode(tl_next);
       set_adesc(nxt);
       issue(nxt, 0, 0, bsel);
@@ -422,7 +452,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 #endif
 }
 
-template <int NT, int PW, int NW, int MT, int WC = 1, bool CTX = true>
+template <int NT, int PW, int NW, int MT, int WC = 1, bool CTX = true, bool RES = false>
 static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
   using Cfg = GldsCfg<NT, PW, NW, MT, WC>;
   using P = typename Cfg::P;
@@ -440,7 +470,7 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
       ncu = 256;
   }
   const long long nblk = ntiles < ncu ? ntiles : ncu;
-  auto kern = conv_glds_kernel<NT, PW, NW, MT, WC, CTX>;
+  auto kern = conv_glds_kernel<NT, PW, NW, MT, WC, CTX, RES>;
   hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
