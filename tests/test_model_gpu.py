@@ -424,6 +424,71 @@ def test_full_size_cached_equals_uncached():
     assert e1 < 1e-2 and e2 < 1e-2 and max(errs) < 1e-2
 
 
+def _ddp_worker(q):
+    """Single-rank RCCL group on cuda:0: OnirisDDP with its early (mid-backward) exchange against the plain backward."""
+    import os
+    import sys
+    import numpy as np   # noqa: F401
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, os.path.join(here, "golden"))
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        from edm2.loss import EDM2Loss
+        from autoregressive_diffusion_amd.parallel import FlatParams, OnirisDDP
+        import test_model_gpu as M
+        g = torch.Generator().manual_seed(41)
+        images = torch.randn(1, 4, 8, 64, 64, generator=g).to(dev)
+        labels = torch.randint(0, 4, (1, 4), generator=g).to(dev)
+        sigma = (torch.randn(1, 8, generator=g) + 0.4).exp().to(dev)
+        eps = torch.randn(1, 8, 8, 64, 64, generator=g).to(dev)
+        grads = {}
+        for mode in ("plain", "ddp"):
+            net = M.build_precond(M.C1_CFG, 43, 1.0).train()
+            flat = FlatParams(net.unet, lazy_small=True)
+            staged = flat.stage_at is not None and 0 < flat.tail_start < flat.numel
+            if mode == "ddp":
+                ddp = OnirisDDP(net.unet, flat=flat)
+                ddp.force_collectives = True
+                net.unet = ddp
+            loss, _ = EDM2Loss(sigma_data=1.0)(net, images, labels, sigma=sigma, noise=eps, sync=False)
+            loss.backward()
+            if mode == "ddp":
+                sent_early = len(ddp._works)
+                ddp.wait()
+            flat.gather()
+            torch.cuda.synchronize()
+            grads[mode] = flat.grad.clone()
+        d = (grads["plain"] - grads["ddp"]).abs().max().item()
+        q.put(("ok", staged, sent_early, d, grads["plain"].abs().max().item()))
+        dist.destroy_process_group()
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put(("error", traceback.format_exc()))
+
+
+def test_ddp_staged_exchange_single_rank():
+    """OnirisDDP on the real UNet (one RCCL rank): the tensor hook fires mid-backward, weight_bwd runs twice (pending
+    slabs only), the tail of the flat gradient buffer is exchanged early and the head at the end -- and the resulting
+    gradients equal those of the plain backward."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ddp_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res[0] == "ok", res[1]
+    _, staged, sent, d, gmax = res
+    print("ddp single rank: staged", staged, "all-reduces", sent, "max |grad diff|", d, "of", gmax)
+    assert staged and sent >= 2
+    assert d <= 1e-3 * gmax
+
+
 def test_hipgraph_step_matches_eager():
     """The captured-and-replayed training micro-step (graphs.GraphedStep) follows the eager trajectory."""
     from edm2.loss import EDM2Loss
