@@ -156,7 +156,7 @@ class OnirisDDP(nn.Module):
     def _exchange(self, lo, hi):
         g = self.flat.grad
         world = dist.get_world_size(self.process_group)
-        avg = g.is_cuda                                  # RCCL averages in the collective; gloo has no AVG
+        avg = g.is_cuda and dist.get_backend(self.process_group) == "nccl"   # RCCL averages in the collective; gloo has no AVG
         if not avg:
             g[lo:hi].mul_(1.0 / world)
         op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM

@@ -143,12 +143,20 @@ def main():
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
                          f"--nproc-per-node {args.gpus} bench.py ...")
+    # debug aid (NOT a measurement): ONIRIS_SHARE_GPU=1 runs every rank on cuda:0 with the gloo backend, so that the
+    # multi-rank control flow of this script (collective matching, staged exchange) can be exercised on a 1-GPU box
+    share = bool(os.environ.get("ONIRIS_SHARE_GPU"))
+    if share:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        if share:
+            dist.init_process_group("gloo", init_method="env://")
+        else:
+            dist.init_process_group("nccl", init_method="env://", device_id=dev)
 
     from edm2.networks_edm2 import UNet, Precond
     from edm2.loss import EDM2Loss
@@ -302,6 +310,7 @@ def main():
                                       f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
                                       f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
                           "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                          **({"shared_gpu_gloo_NOT_A_MEASUREMENT": True} if share else {}),
                           **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
                           **{k: round(v, 2) for k, v in per_mode.items()}},
                "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "roofline_attention": roof_attn,
