@@ -121,24 +121,40 @@ def _nsplit_cap(cin, cout, taps):
 
 class _ZeroArena:
     """Pre-zeroed fp32 scratch for the accumulators the backward kernels add into with atomics (gate / emb-scale
-    gradient sums): ONE fill per step (WeightBank.prepare) instead of one `torch.zeros` launch per conv."""
+    gradient sums): ONE fill per step (WeightBank.prepare) instead of one `torch.zeros` launch per conv.
+
+    The fill covers the WHOLE buffer on every reset, whatever the previous step took: the launch sequence of
+    `prepare()` must not depend on host-side state, because it is captured into hipGraphs (a graph captured right
+    after a 2-D step, which takes nothing, would otherwise contain no fill at all and every 3-D replay behind another
+    3-D replay would add its gate / emb-scale gradient sums on top of the previous step's)."""
+
+    MIN_ELEMS = 1 << 22                      # 16 MB: one ~4 us fill per step
 
     def __init__(self):
-        self.buf, self.off = None, 0
+        self.buf, self.off, self.want = None, 0, self.MIN_ELEMS
+
+    def _capturing(self):
+        return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
     def take(self, n, device):
         n = (n + 63) // 64 * 64
         if self.buf is None or self.buf.device != device:
-            self.buf, self.off = torch.zeros(1 << 22, dtype=torch.float32, device=device), 0
+            self.buf, self.off = torch.zeros(self.want, dtype=torch.float32, device=device), 0
         if self.off + n > self.buf.numel():
+            self.want = max(self.want, 2 * (self.off + n))      # grown at the next reset outside a capture
+            self.off += n
             return torch.zeros(n, dtype=torch.float32, device=device)
         v = self.buf[self.off:self.off + n]
         self.off += n
         return v
 
-    def reset(self):
-        if self.buf is not None and self.off:
-            self.buf[:self.off].zero_()
+    def reset(self, device=None):
+        if self.buf is not None and self.want > self.buf.numel() and not self._capturing():
+            self.buf = None                                      # a step overflowed: take a larger arena
+        if self.buf is None and device is not None and not self._capturing():
+            self.buf = torch.empty(self.want, dtype=torch.float32, device=device)
+        if self.buf is not None:
+            self.buf.zero_()
         self.off = 0
 
 
@@ -267,7 +283,8 @@ class WeightBank:
     def prepare(self, training):
         """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
         self._ensure()
-        self.zero_arena.reset()                        # (the previous step's backward is done with its accumulators)
+        if training or torch.is_grad_enabled():        # (a no_grad evaluation -- the rollout -- never takes from the arena)
+            self.zero_arena.reset(self.items[0][0].param.device)   # the previous step's backward is done with its accumulators
         global _weights_epoch
         if training:
             _weights_epoch += 1                        # parameters are rewritten in place (forced normalisation)

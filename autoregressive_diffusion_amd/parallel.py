@@ -23,8 +23,12 @@ class FlatParams:
         one tiny `add_` kernel per parameter (~190 launches per step for the gym net); their .grad is None during
         backward, so autograd just hands the tensor over, and `gather()` adds all of them into the flat buffer with one
         multi-tensor call (called by OnirisDDP at the end of backward and by FlatAdamW.step)."""
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        self.params = [p for _, p in named]
         assert self.params, "no trainable parameters"
+        self.module = module
+        self.names = {id(p): n for n, p in named}          # state_dict keys of the re-homed parameters
+        self.orig_params = list(self.params)                # module.parameters() order (the order a torch optimizer sees)
         # parameters whose gradient is final early in backward (module._oniris_overlap_plan) go, contiguous, to the
         # END of the buffers: OnirisDDP exchanges [tail_start, numel) while the rest of backward is still running
         plan = module._oniris_overlap_plan() if hasattr(module, "_oniris_overlap_plan") else None
@@ -64,6 +68,16 @@ class FlatParams:
         for p, _ in self._lazy:
             p.grad = None
 
+    def offset_of(self, param):
+        if not hasattr(self, "_off_by_id"):
+            self._off_by_id = {id(p): o for p, o in zip(self.params, self.offsets)}
+        return self._off_by_id[id(param)]
+
+    def slice_of(self, buf, param):
+        """The part of `buf` (any tensor laid out like self.flat: optimizer moments, EMA copies) that belongs to `param`."""
+        o = self.offset_of(param)
+        return buf[o:o + param.numel()].view_as(param)
+
     def gather(self):
         """Add the autograd-owned gradients into their flat slices (one multi-tensor add) and re-alias .grad."""
         src, dst = [], []
@@ -101,9 +115,29 @@ class OnirisDDP(nn.Module):
         if self.flat.stage_at is not None:               # early exchange of the tail (see FlatParams / _stage)
             module.__dict__["_oniris_stage_at"] = self.flat.stage_at
             module.__dict__["_oniris_stage_cb"] = self._stage
-        # every rank starts from rank 0's parameters (what torch DDP does at construction)
+        # every rank starts from rank 0's parameters AND buffers (what torch DDP does at construction: MPFourier's
+        # random freqs / phases are buffers, utils.py:63-64 -- ranks built from different RNG states would otherwise
+        # keep different noise / time embeddings under shared weights)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self.flat.flat, src=0, group=self.process_group)
+            self._broadcast_buffers()
+
+    def _broadcast_buffers(self):
+        """Rank 0's module buffers to every rank: one coalesced broadcast per dtype, copied back in place."""
+        by_dtype = {}
+        for b in self.module.buffers():
+            if b is not None and b.numel():
+                by_dtype.setdefault((b.dtype, b.device), []).append(b)
+        for (dt, dev), bufs in by_dtype.items():
+            flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+            if dt == torch.bool:
+                flat = flat.to(torch.uint8)
+            dist.broadcast(flat, src=0, group=self.process_group)
+            off = 0
+            with torch.no_grad():
+                for b in bufs:
+                    b.copy_(flat[off:off + b.numel()].view_as(b).to(dt))
+                    off += b.numel()
 
     def __getattr__(self, name):
         try:
@@ -147,11 +181,7 @@ class OnirisDDP(nn.Module):
         self._queued = False
         if not self._sync_enabled:
             return
-        bank = self.module.__dict__.get("_oniris_bank")
-        if bank is not None:
-            bank._finish()                               # weight gradients must be final before the exchange
-        self.flat.gather()
-        self.allreduce_grads()
+        self.allreduce_grads()                           # (finalises weight gradients + gathers the small ones first)
 
     def _exchange(self, lo, hi):
         g = self.flat.grad
@@ -164,7 +194,15 @@ class OnirisDDP(nn.Module):
                                         async_op=True) for s in range(lo, hi, self.bucket_elems)]
 
     def allreduce_grads(self):
-        """Exchange whatever `_stage` has not sent yet (everything, when no stage fired in this backward)."""
+        """Exchange whatever `_stage` has not sent yet (everything, when no stage fired in this backward).
+        Also the entry point after a backward that ran under `no_sync()` (bench.py --graph replays forward+backward
+        from a hipGraph and exchanges eagerly): the weight gradients are finalised and the autograd-owned small
+        gradients (gates, emb_gain, out_gain, grouped emb weights) are gathered into the flat buffer FIRST, so that
+        they take part in the average instead of being added, un-averaged, by the optimizer's own gather()."""
+        bank = self.module.__dict__.get("_oniris_bank")
+        if bank is not None:
+            bank._finish()                               # no-op unless a backward left it pending
+        self.flat.gather()
         sent, self._tail_sent = self._tail_sent, False
         if not self._active():
             return
@@ -226,9 +264,34 @@ class FlatEMA:
 
     def view(self, k, param):
         """The EMA value of `param` (a parameter re-homed in self.flat) under profile k."""
-        i = [id(p) for p in self.flat.params].index(id(param))
-        o = self.flat.offsets[i]
-        return self.emas[k][o:o + param.numel()].view_as(param)
+        return self.flat.slice_of(self.emas[k], param)
+
+    def state_dict(self):
+        """The reference's layout (edm2/phema.py:110-111): dict(stds, emas=[module-style state_dict per profile]) --
+        every profile keyed like `module.state_dict()` of the module the flat buffer was built on (parameters from
+        the EMA copy, buffers and frozen parameters from the live module, as `PowerFunctionEMA.get()` copies them)."""
+        f = self.flat
+        live = f.module.state_dict()
+        by_name = {n: p for n, p in f.module.named_parameters()}
+        out = []
+        for e in self.emas:
+            sd = {}
+            for k, v in live.items():
+                p = by_name.get(k)
+                sd[k] = (f.slice_of(e, p) if p is not None and id(p) in f.names else v).detach().clone()
+            out.append(sd)
+        return dict(stds=list(self.stds), emas=out)
+
+    def load_state_dict(self, state):
+        assert list(state["stds"]) == list(self.stds), (state["stds"], self.stds)
+        f = self.flat
+        by_name = {n: p for n, p in f.module.named_parameters()}
+        with torch.no_grad():
+            for e, sd in zip(self.emas, state["emas"]):
+                for k, v in sd.items():
+                    p = by_name.get(k)
+                    if p is not None and id(p) in f.names:
+                        f.slice_of(e, p).copy_(v)
 
 
 class FlatAdamW:
@@ -236,11 +299,47 @@ class FlatAdamW:
     GPU: fused HIP kernels (oniris_sqnorm + oniris_adamw_clip_ema); CPU tensors (tests): plain torch math."""
 
     def __init__(self, flat, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
-        self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.flat = flat
+        # one group, torch.optim style: the reference loops set the learning rate through it (gym_train.py:110-112)
+        self.param_groups = [dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                  maximize=False, params=list(range(len(flat.orig_params))))]
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
         self.steps = 0
         self._norm_buf = None
+
+    lr = property(lambda self: self.param_groups[0]["lr"], lambda self, v: self.param_groups[0].__setitem__("lr", v))
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+
+    def state_dict(self):
+        """torch.optim.AdamW's layout (what gym_train.py:137-138 saves): per-parameter `step` / `exp_avg` /
+        `exp_avg_sq`, indexed in module.parameters() order, + param_groups."""
+        f = self.flat
+        st = {i: dict(step=torch.tensor(float(self.steps)), exp_avg=f.slice_of(self.m, p).detach().clone(),
+                      exp_avg_sq=f.slice_of(self.v, p).detach().clone()) for i, p in enumerate(f.orig_params)}
+        return dict(state=st if self.steps else {}, param_groups=[dict(g) for g in self.param_groups])
+
+    def load_state_dict(self, state):
+        """Accepts its own state_dict() and a torch.optim.AdamW state_dict over the same parameters in the same
+        order (one group; every parameter must be at the same step -- the fused kernel keeps ONE step counter)."""
+        f = self.flat
+        groups = state["param_groups"]
+        assert len(groups) == 1 and len(groups[0]["params"]) == len(f.orig_params), "one group over the same parameters"
+        for k in ("lr", "betas", "eps", "weight_decay"):
+            if k in groups[0]:
+                self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
+        st = state["state"]
+        self.m.zero_(); self.v.zero_()
+        # torch keeps one step counter per parameter (a parameter whose .grad is None is skipped); the fused kernel
+        # keeps one for the whole buffer: resume from the furthest one
+        self.steps = max((int(float(s["step"])) for s in st.values()), default=0)
+        with torch.no_grad():
+            for i, s in st.items():
+                p = f.orig_params[int(i)]
+                f.slice_of(self.m, p).copy_(s["exp_avg"])
+                f.slice_of(self.v, p).copy_(s["exp_avg_sq"])
 
     @torch.no_grad()
     def step(self, grad_scale=1.0, max_norm=None, ema=None):

@@ -226,7 +226,7 @@ def main():
         if world > 1 or force_dist:
             model.wait()
         nimg[0] += world * B
-        opt.step(max_norm=max_norm, ema=ema.weights(nimg[0] + world * B, world * B))
+        opt.step(max_norm=max_norm, ema=ema.weights(nimg[0], world * B))      # t_next = images seen so far (gym_train.py:108)
         return loss
 
     def fence():

@@ -146,3 +146,118 @@ def test_flat_lazy_small_grads():
         assert torch.allclose(fa.grad, fb.grad, atol=1e-7)
         oa.step(); ob.step()
     assert torch.allclose(fa.flat, fb.flat, atol=1e-7) and fa.check()
+
+
+def test_flat_adamw_state_dict_roundtrip_with_torch():
+    """FlatAdamW.state_dict() has torch.optim.AdamW's layout (gym_train.py:76-81,137-138 save / resume through it):
+    a torch optimizer's state loads into the flat one and both continue on the same trajectory; param_groups sets lr."""
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW
+    torch.manual_seed(3)
+    a, b = Net(), Net()
+    b.load_state_dict(a.state_dict())
+    ref = torch.optim.AdamW(list(b.parameters()), lr=1e-2, eps=1e-8, weight_decay=0.01)
+    xs = torch.randn(6, 5, 6)
+
+    def grads(net, x):
+        net(x)[0].pow(2).mean().backward()
+        for p in net.unused.parameters():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+    for i in range(2):                                     # two steps on the torch side only
+        ref.zero_grad(); grads(b, xs[i]); ref.step()
+    a.load_state_dict(b.state_dict())
+    flat = FlatParams(a)
+    opt = FlatAdamW(flat, lr=123.0)
+    opt.load_state_dict(ref.state_dict())                  # lr, betas, eps, wd, moments, step come from the checkpoint
+    assert opt.lr == 1e-2 and opt.steps == 2
+    sd = opt.state_dict()
+    assert set(sd) == {"state", "param_groups"} and set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    for i, p in enumerate(b.parameters()):
+        assert torch.equal(sd["state"][i]["exp_avg"], ref.state_dict()["state"][i]["exp_avg"])
+    for g in opt.param_groups + ref.param_groups:          # the loops' lr schedule (gym_train.py:110-112)
+        g["lr"] = 5e-3
+    for i in range(2, 5):
+        opt.zero_grad(); ref.zero_grad(); grads(a, xs[i]); grads(b, xs[i]); opt.step(); ref.step()
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.allclose(v, w, atol=1e-6), k
+    opt2 = FlatAdamW(flat)
+    opt2.load_state_dict(opt.state_dict())                 # own round trip
+    assert torch.equal(opt2.m, opt.m) and torch.equal(opt2.v, opt.v) and opt2.steps == opt.steps
+
+
+def test_flat_ema_state_dict_layout():
+    """FlatEMA.state_dict() = dict(stds, emas=[module.state_dict()-shaped dicts]) (edm2/phema.py:110-111)."""
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatEMA
+    torch.manual_seed(4)
+    net = Net()
+    net.register_buffer("freqs", torch.randn(3))
+    flat = FlatParams(net)
+    ema = FlatEMA(flat, stds=(0.05, 0.1))
+    with torch.no_grad():
+        flat.flat.add_(1.0)
+    for e, w in ema.weights(8, 4):
+        e.lerp_(flat.flat, w)
+    sd = ema.state_dict()
+    assert sd["stds"] == [0.05, 0.1] and len(sd["emas"]) == 2
+    assert list(sd["emas"][0].keys()) == list(net.state_dict().keys())
+    assert torch.equal(sd["emas"][1]["freqs"], net.freqs)
+    assert torch.equal(sd["emas"][0]["a.weight"], ema.view(0, net.a.weight))
+    other = FlatEMA(flat, stds=(0.05, 0.1))
+    other.load_state_dict(sd)
+    assert all(torch.equal(other.view(k, p), ema.view(k, p)) for k in range(2) for p in flat.params)
+
+
+class BufNet(Net):
+    """Net with a random buffer (MPFourier's freqs / phases, utils.py:63-64) and autograd-owned small parameters."""
+    def __init__(self):
+        super().__init__()
+        self.register_buffer("freqs", torch.randn(5))
+        self.register_buffer("count", torch.zeros((), dtype=torch.int64))
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x))) * self.freqs[:3].sum(), None
+
+
+def _worker_nosync(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autoregressive_diffusion_amd.parallel import OnirisDDP, FlatAdamW, FlatParams
+    torch.manual_seed(200 + rank)               # different parameters AND buffers per rank
+    net = BufNet()
+    flat = FlatParams(net, lazy_small=True)     # (toy net: every gradient is autograd-owned, i.e. lazy)
+    ddp = OnirisDDP(net, flat=flat)
+    opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.0)
+    g = torch.Generator().manual_seed(9)
+    data = torch.randn(2, 5, 6, generator=g)
+    # the bench's --graph flow: forward+backward under no_sync (a replayed graph), then the exchange issued by hand
+    for step in range(2):
+        opt.zero_grad()
+        with ddp.no_sync():
+            out, _ = ddp(data[rank]); out.pow(2).mean().backward()
+        ddp.allreduce_grads()
+        ddp.wait()
+        opt.step()
+    q.put((rank, {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ddp_no_sync_then_manual_exchange_keeps_ranks_equal():
+    """Buffers follow rank 0 at construction, and gradients that autograd hands over lazily (lazy_small) take part
+    in a hand-issued allreduce_grads() after a no_sync backward: parameters stay bit-equal across ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_nosync, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, sd0), (_, sd1) = res
+    for k in sd0:
+        assert (sd0[k] == sd1[k]).all(), f"ranks diverged on {k}"
+    torch.manual_seed(200)
+    ref = BufNet()
+    assert (sd0["freqs"] == ref.freqs.numpy()).all(), "buffers must be rank 0's"

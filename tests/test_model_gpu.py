@@ -525,3 +525,62 @@ def test_hipgraph_step_matches_eager():
     print("eager", [round(v, 4) for v in traj["eager"][-6:]], "graph", [round(v, 4) for v in traj["graph"][-6:]])
     for a, b in zip(traj["eager"], traj["graph"]):
         assert abs(a - b) <= 5e-3 * abs(a) + 1e-4, (traj["eager"], traj["graph"])
+
+
+def test_hipgraph_gradients_match_eager_after_consecutive_3d_replays():
+    """The gradient buffer itself (not only the loss trajectory) of a replayed 3-D step equals the eager one, for a
+    3-D graph that was CAPTURED right after a 2-D step and is replayed behind another 3-D replay: the atomically
+    accumulated gate / emb-scale gradient sums (gconv_bwd_fused) must start from zero on every replay -- the arena
+    fill has to be part of the captured sequence whatever the previous step took from it."""
+    from edm2.loss import EDM2Loss
+    from autoregressive_diffusion_amd.parallel import FlatParams
+    from autoregressive_diffusion_amd.graphs import GraphedStep
+    g = torch.Generator().manual_seed(78)
+    images = torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (1, 4), generator=g).to(DEV)
+    sig3, eps3 = (torch.randn(1, 8, generator=g) + 0.4).exp().to(DEV), torch.randn(1, 8, 4, 32, 32, generator=g).to(DEV)
+    sig2, eps2 = (torch.randn(1, 4, generator=g) + 0.4).exp().to(DEV), torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    net = build_precond(SMALL_CFG, 56, 1.0).train()
+    for m in net.unet.modules():                       # emb-scale branch carries signal
+        if hasattr(m, "emb_gain"):
+            torch.nn.init.constant_(m.emb_gain, 0.3)
+    flat = FlatParams(net.unet, lazy_small=True)
+    loss_fn = EDM2Loss(sigma_data=1.0)
+
+    def fwd_bwd(j2d):
+        flat.zero_grad()
+        loss, _ = loss_fn(net, images, labels, sigma=sig2 if j2d else sig3, noise=eps2 if j2d else eps3, just_2d=j2d,
+                          sync=False)
+        loss.backward()
+        return loss
+
+    def grads():
+        flat.gather()
+        torch.cuda.synchronize()
+        return flat.grad.clone()
+    fwd_bwd(False); fwd_bwd(False)                     # (forced weight-norm reaches its fixed point)
+    fwd_bwd(False)
+    want = grads()
+    step3, step2 = GraphedStep(lambda: fwd_bwd(False), params=flat.params, warmup=1), \
+        GraphedStep(lambda: fwd_bwd(True), params=flat.params, warmup=1)
+    step3(); step2()                                   # eager warm-up calls
+    step2()                                            # capture + first replay of the 2-D step
+    step3()                                            # 3-D graph captured right behind a 2-D step
+    got = []
+    for _ in range(3):                                 # 3-D replays behind 3-D replays
+        step3()
+        got.append(grads())
+    names = {id(p): n for n, p in net.unet.named_parameters()}
+    scale = want.abs().max().item()
+    worst = {}
+    for p, o in zip(flat.params, flat.offsets):
+        n = names[id(p)]
+        kind = ("gating" if ".gating." in n else "emb_gain" if n.endswith("emb_gain") else
+                "emb_linear" if "emb_linear" in n or "emb_noise" in n or "emb_label" in n else "other")
+        w = want[o:o + p.numel()]
+        for k, gk in enumerate(got):
+            d = (gk[o:o + p.numel()] - w).abs().max().item()
+            tol = 2e-3 * w.abs().max().item() + 1e-5 * scale        # fp32 atomics re-order between launches, nothing more
+            worst[kind] = max(worst.get(kind, 0.0), d / (tol + 1e-30))
+    print("graph vs eager gradient, worst |diff| / tolerance per class:", {k: round(v, 3) for k, v in worst.items()})
+    assert all(v <= 1.0 for v in worst.values()), worst
