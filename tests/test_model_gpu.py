@@ -580,7 +580,9 @@ def test_hipgraph_gradients_match_eager_after_consecutive_3d_replays():
         w = want[o:o + p.numel()]
         for k, gk in enumerate(got):
             d = (gk[o:o + p.numel()] - w).abs().max().item()
-            tol = 2e-3 * w.abs().max().item() + 1e-5 * scale        # fp32 atomics re-order between launches, nothing more
+            # fp32 atomics re-order between launches, nothing more; the scalar parameters (gates, emb_gain) are sums of
+            # cancelling terms (3 % class tolerance) -- a missing arena fill shows as 100 %, 200 % ...
+            tol = (2e-2 if kind in ("gating", "emb_gain") else 2e-3) * w.abs().max().item() + 1e-5 * scale
             worst[kind] = max(worst.get(kind, 0.0), d / (tol + 1e-30))
     print("graph vs eager gradient, worst |diff| / tolerance per class:", {k: round(v, 3) for k, v in worst.items()})
     assert all(v <= 1.0 for v in worst.values()), worst
