@@ -9,6 +9,11 @@ HDRS := $(wildcard $(CSRC)/*.h) include/oniris.h
 
 all: $(OUT)
 
+# attention: MFMA results in arch VGPRs even where the register budget would allow AGPRs (the one-wave-per-SIMD forward
+# feeds every S^T accumulator to v_exp_f32; the AGPR form costs one v_accvgpr_read per element)
+build/attention.hip.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1
+build/attention_stamp.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1
+
 build/%.hip.o: $(CSRC)/%.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -19,6 +24,15 @@ build/misc.cpp.o: $(CSRC)/misc.cpp $(HDRS)
 
 $(OUT): $(OBJS)
 	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+
+# diagnostic build: the attention kernels with in-kernel cycle stamps (scratch/attn_stamp.py loads it through
+# ONIRIS_LIB_NAME); never used by the product path
+STAMP_OUT := autoregressive_diffusion_amd/liboniris_hip_stamp.so
+build/attention_stamp.o: $(CSRC)/attention.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DATTN_STAMP -c $< -o $@
+stamp: build/attention_stamp.o $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(STAMP_OUT) build/attention_stamp.o $(filter-out build/attention.hip.o,$(OBJS)) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 clean:
 	rm -rf build $(OUT)

@@ -9,7 +9,7 @@ import os
 import torch  # noqa: F401  -- MUST come first: binds liboniris_hip.so to the HIP/RCCL runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboniris_hip.so")
+LIB_PATH = os.path.join(_HERE, os.environ.get("ONIRIS_LIB_NAME", "liboniris_hip.so"))   # (diagnostic builds: `make stamp`)
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(f"{LIB_PATH} not found: build the HIP extension first (make -j8 at the repo root); "
@@ -59,7 +59,8 @@ class AttnArgs(C.Structure):
                 ("mask_mode", c_int32), ("P", c_int32), ("T", c_int32), ("tab_block", c_int32),
                 ("dout", c_void_p), ("doutt", c_void_p), ("delta", c_void_p),
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
-                ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("pad_", c_int32)]
+                ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("pad_", c_int32),
+                ("sched", c_void_p), ("sched_wgs", c_int32), ("sched_slots", c_int32)]
 
 
 EPI_NONE, EPI_EMB_SILU, EPI_MPSUM = 0, 1, 2
@@ -72,6 +73,7 @@ _SIGS = {
     "oniris_train_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_infer_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_mask_transpose": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "oniris_attn_schedule": (c_int, [c_int, c_int, c_void_p, c_int, c_void_p, c_int]),
     "oniris_weight_prep": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_weight_bwd": (c_int, [c_void_p, c_int, c_int, c_void_p]),
     "oniris_adamw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float, c_float, c_float,

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
@@ -18,7 +19,7 @@ void oniris_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* oniris_last_error(void) { return g_err; }
-extern "C" int oniris_abi_version(void) { return 1; }
+extern "C" int oniris_abi_version(void) { return 2; }
 
 // ---- mask tables (reference: edm2/attention/attention_masking.py:27-53, 64-90); 128 = flex default block
 static const int kFlexBlock = 128;
@@ -78,6 +79,47 @@ extern "C" int oniris_mask_transpose(int n_rows, int n_cols, const int32_t* kv_n
       q_idx[(size_t)c * n_rows + q_num[c]++] = r;
     }
   return ONIRIS_OK;
+}
+
+// ---- static balanced schedule of attention work items over persistent workgroups (see include/oniris.h)
+extern "C" int oniris_attn_schedule(int n_pairs, int n_blocks, const int32_t* weight, int n_wg, int32_t* sched,
+                                    int n_slots) {
+  ONIRIS_CHECK_ARG(n_pairs > 0 && n_blocks > 0 && n_blocks < 65536 && n_pairs < 32768 && weight && n_wg > 0,
+                   "attn_schedule: bad arguments");
+  int ng = 1;
+  for (int g = 8; g > 1; g >>= 1)
+    if (n_pairs % g == 0 && n_wg % g == 0) { ng = g; break; }
+  std::vector<int> order(n_blocks);
+  for (int i = 0; i < n_blocks; ++i) order[i] = i;
+  // heaviest block first (stable: equal weights keep block order)
+  for (int i = 1; i < n_blocks; ++i) {
+    const int v = order[i];
+    int j = i - 1;
+    while (j >= 0 && weight[order[j]] < weight[v]) { order[j + 1] = order[j]; --j; }
+    order[j + 1] = v;
+  }
+  std::vector<long long> load(n_wg, 0);
+  std::vector<std::vector<int32_t>> lists(n_wg);
+  for (int g = 0; g < ng; ++g) {
+    // the group's items: every block of every pair of the group, heaviest first (pairs interleaved)
+    for (int bi = 0; bi < n_blocks; ++bi) {
+      const int blk = order[bi];
+      for (int p = g; p < n_pairs; p += ng) {
+        int best = -1;
+        for (int w = g; w < n_wg; w += ng)
+          if (best < 0 || load[w] < load[best]) best = w;
+        load[best] += weight[blk];
+        lists[best].push_back((int32_t)((p << 16) | blk));
+      }
+    }
+  }
+  int need = 1;
+  for (int w = 0; w < n_wg; ++w) need = std::max(need, (int)lists[w].size());
+  if (!sched) return need;
+  ONIRIS_CHECK_ARG(n_slots >= need, "attn_schedule: %d slots given, %d needed", n_slots, need);
+  for (int w = 0; w < n_wg; ++w)
+    for (int k = 0; k < n_slots; ++k) sched[(size_t)w * n_slots + k] = k < (int)lists[w].size() ? lists[w][k] : -1;
+  return need;
 }
 
 // ---- RCCL helpers

@@ -99,6 +99,35 @@ def device_tables(kind, n_frames, image_size, device):
     return _table_cache[key]
 
 
+_sched_cache = {}
+_cu_count = {}
+ATTN_PERSISTENT = int(__import__("os").environ.get("ONIRIS_ATTN_PERSISTENT", "1"))   # 0: grid kernels (A/B knob)
+
+
+def attn_schedule(weights, n_pairs, device, n_wg=None):
+    """Device copy of the static balanced schedule (oniris_attn_schedule) of n_pairs x len(weights) work items over
+    the persistent workgroups (one per CU); cached per (weights, pairs, device).  Returns (tensor [n_wg][slots], n_wg,
+    slots)."""
+    if n_wg is None:
+        n_wg = _cu_count.get(str(device))
+        if n_wg is None:
+            n_wg = _cu_count[str(device)] = torch.cuda.get_device_properties(device).multi_processor_count
+    w = np.ascontiguousarray(weights, dtype=np.int32)
+    key = (w.tobytes(), n_pairs, str(device), n_wg)
+    hit = _sched_cache.get(key)
+    if hit is None:
+        need = lib.oniris_attn_schedule(n_pairs, len(w), w.ctypes.data_as(ctypes.c_void_p), n_wg, None, 0)
+        if need < 0:
+            check(need, "attn_schedule")
+        tab = np.zeros((n_wg, need), dtype=np.int32)
+        rc = lib.oniris_attn_schedule(n_pairs, len(w), w.ctypes.data_as(ctypes.c_void_p), n_wg,
+                                      tab.ctypes.data_as(ctypes.c_void_p), need)
+        if rc < 0:
+            check(rc, "attn_schedule")
+        hit = _sched_cache[key] = (torch.from_numpy(tab).to(device), n_wg, need)
+    return hit
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # weight bank: descriptor table + packed buffers for every NormalizedWeight of a model
 
@@ -876,6 +905,20 @@ def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mo
     return a
 
 
+def _train_sched(T, P, n_pairs, dev, which):
+    """Schedule of the DART training table's blocks over the persistent workgroups: which = 'fwd' (query blocks of 128
+    rows weighted by their key-block count) or 'dkv' (key blocks weighted by their query-block count)."""
+    num, idx, blk = train_mask_table(T, P)
+    if which == "fwd":
+        per = blk // 128
+        w = np.repeat(num * per + 1, per)                    # a table row of `blk` tokens = per 128-row query blocks
+    else:
+        qn, _ = mask_transpose(num, idx)
+        per = blk // 128
+        w = np.repeat(qn * per + 1, per)
+    return attn_schedule(w, n_pairs, dev)
+
+
 class _AttentionFn(torch.autograd.Function):
     """qkv (N, P, 3C) bf16 (channel = s*C + head*64 + c)  ->  attention output (N, P, C).
     kind: 'video' (DART training mask + RoPE over frames, B sequences of 2T frames) or 'frame' (dense per frame)."""
@@ -911,8 +954,15 @@ class _AttentionFn(torch.autograd.Function):
         a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
         fl = _attn_flops(kind, Bq, T, heads, L, P)
         ks = 2 if (mask_mode != 0 and L >= 2048) else 1
-        _profiled(f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>", fl,
-                  lambda: check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd"))
+        name = f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>"
+        sched = None
+        if mask_mode == 2 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64:
+            # persistent kernel: query blocks of 128 rows, cost = key blocks of its table row + 1 (fixed per-item work)
+            sched = _train_sched(T, P, Bq * heads, dev, "fwd")
+            a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+            a.pad_ = ATTN_PERSISTENT if ATTN_PERSISTENT in (4, 8) else 0
+            name = {4: "attn_fwd_p4_kernel", 8: "attn_fwd_p_kernel"}.get(ATTN_PERSISTENT, "attn_fwd_ws_kernel") + f"<MODE={mask_mode}>"
+        _profiled(name, fl, lambda: check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd"))
         ctx.meta = (kind, B, T, heads, Bq, L, frames, P, C, mask_mode)
         ctx.tabs, ctx.tabs_r = tabs, tabs_r
         ctx.save_for_backward(qkv, qr, kr, v, out, lse)

@@ -273,7 +273,21 @@ typedef struct OnirisAttnArgs {
    * (deterministic, no atomics) and writes the bf16 dk, dv.  0 / 1: one workgroup per key block, no scratch.       */
   float* dkv_part;
   int32_t dkv_chunks, pad_;
+  /* static balanced schedule for the persistent kernels (oniris_attn_schedule): device int32 [sched_wgs][sched_slots],
+   * entry = (pair << 16) | block with pair = b * heads + head, or -1.  NULL: one workgroup per block (grid kernels).   */
+  const int32_t* sched;
+  int32_t sched_wgs, sched_slots;
 } OnirisAttnArgs;
+
+/* Static load balancing of block-sparse attention [host]: n_pairs (batch, head) pairs x n_blocks work items per pair
+ * (query blocks for the forward / dQ, key blocks for dK/dV), weight[blk] = cost of block blk (its list length in the
+ * mask table + a fixed per-item cost; the same for every pair).  The n_wg persistent workgroups form n_groups =
+ * 8 / 4 / 2 / 1 groups (workgroup w -> group w % n_groups: the XCD it is dispatched to under round-robin placement --
+ * speed only, never correctness); pair p belongs to group p % n_groups, so that its K / V stay in one L2.  Inside a
+ * group the items are dealt longest-processing-time first to the least loaded workgroup.  Writes
+ * sched[n_wg][n_slots] (see OnirisAttnArgs.sched) and returns the number of slots used (<= n_slots); with sched ==
+ * NULL only returns the number of slots needed.  <0 on error.                                                       */
+int oniris_attn_schedule(int n_pairs, int n_blocks, const int32_t* weight, int n_wg, int32_t* sched, int n_slots);
 
 int oniris_attn_fwd(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
 /* delta[b][h][q] = sum_c dout*out ; doutt = transposed dout                                                      */
