@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 }
 
 #include "attention_p.h"
+#include "attention_ws.h"
 
 // ================================================================================================================
 // backward: dQ   (the forward's structure: lane = query row, LDS-DMA double-buffered K / V tiles, KS key streams

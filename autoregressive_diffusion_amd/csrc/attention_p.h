@@ -547,376 +547,3 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_p4_kernel(const AttnDev d) {
 #endif
 #endif
 }
-
-// ================================================================================================================
-// attn_fwd_ws_kernel: persistent forward with wave specialisation -- 4 compute waves + 4 loader waves per workgroup.
-//
-// The stamped build of attn_fwd_p4_kernel (scratch/attn_stamp.py; cycles per wave for 33 blocks): the two pipelined
-// sub-steps 54 K, but DMA ISSUE 25 K (8 buffer_load..lds per wave and block at ~100 cycles each, with nothing else of
-// that wave issuing meanwhile), the masked last block + epilogue 29 K, item set-up 9 K.  So here
-//  * waves 4..7 (one per SIMD, beside a compute wave) only issue LDS-DMA and wait for it: their ~100-cycle issue slots
-//    run beside the MFMAs / exponentials of the compute wave on the same SIMD.  They run two blocks ahead through a
-//    four-slot ring (4 x 32 KB), and prefetch the NEXT item's Q tile and first two blocks while the compute waves
-//    finish the current item, so an item starts without a pipeline fill;
-//  * the compute waves (qw, st) are attn_fwd_p4_kernel's: 64 query rows x one key half, S^T of sub-step i+1 under the
-//    softmax of sub-step i; Q fragments come from the prefetched LDS tile;
-//  * the last block of a list (the only partial one) takes its mask as the INITIAL ACCUMULATOR of the S^T MFMAs
-//    (0 / -1e30 per element, built once per item), so its softmax is the unmasked code.
-// LDS: ring 128 KB + two Q tiles 32 KB = 160 KB.  Barriers per item: one per block + two in the epilogue; every wave of
-// the workgroup executes the same number.
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void attn_fwd_ws_kernel(const AttnDev d) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int SLOT = 2 * 128 * 128;              // K [128 keys][128 B] | V [128 keys][128 B]
-  constexpr int QOFF = 4 * SLOT, QTILE = 128 * 128;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLOT + 2 * QTILE];
-  const OnirisAttnArgs& a = d.a;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int C = a.C, Lq = a.Lq, Lk = a.Lk;
-  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
-  const int nslots = a.sched_slots;
-  const int32_t* sched = a.sched + (size_t)blockIdx.x * nslots;
-  auto item_at = [&](int i) __attribute__((always_inline)) { return i < nslots ? __builtin_amdgcn_readfirstlane(sched[i]) : -1; };
-  auto item_blocks = [&](int item) __attribute__((always_inline)) {       // 128-key blocks in the item's list
-    const int trow = (item & 0xffff) >> d.tshift;
-    return __builtin_amdgcn_readfirstlane(a.kv_num[trow] << d.tshift);
-  };
-
-  if (wave >= 4) {
-    // ------------------------------------------------------------------------------------------------ loader waves
-    const int lw = wave - 4;
-    const int drow = 8 * lw + (lane >> 3), dpp = lane & 7;        // piece (lw + 4 i): row 32 i + drow, 16-byte part dpp
-    const int ksw = (dpp ^ ((drow >> 1) & 7)) * 16, vsw_ = (dpp ^ (4 * ((drow >> 1) & 1))) * 16;
-    constexpr int OOB = (int)0x80000000;
-    int item = item_at(0);
-#pragma unroll 1
-    for (int it = 0; item >= 0; ++it) {
-      const int pair = item >> 16, qb128 = item & 0xffff;
-      const int b = pair / a.heads, head = pair - b * a.heads;
-      const int trow = qb128 >> d.tshift, tmask = (1 << d.tshift) - 1;
-      const int nent = __builtin_amdgcn_readfirstlane(a.kv_num[trow]);
-      const int nblk = nent << d.tshift;
-      const int kvl = (lane < nent) ? a.kv_idx[(size_t)trow * a.tab_cols + lane] : 0;
-      asm volatile("s_waitcnt vmcnt(0)" ::"v"(kvl) : "memory");    // (hipcc does not count the asm DMAs: drain by hand)
-      auto key_start = [&](int j) __attribute__((always_inline)) {
-        return (((__builtin_amdgcn_readlane(kvl, j >> d.tshift)) << d.tshift) + (j & tmask)) * 128;
-      };
-      const i32x4 rs_k = make_rsrc((const bf16*)a.k + (size_t)b * Lk * C, Lk * C * 2);
-      const i32x4 rs_v = make_rsrc((const bf16*)a.v + (size_t)b * Lk * C, Lk * C * 2);
-      const int kvo = (drow * C + head * 64) * 2 + ksw, vvo = (drow * C + head * 64) * 2 + vsw_;
-      auto issue_block = [&](int j) __attribute__((always_inline)) {        // block j of this item -> slot (j + 2) % 4
-        const int key0 = key_start(j);
-        const unsigned dst = lds0 + ((j + 2) & 3) * SLOT + lw * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool ok = drow + 32 * i < Lk - key0;
-          const int so = (key0 + 32 * i) * C * 2;
-          dma16(rs_k, ok ? kvo : OOB, so, dst + i * 4096);
-          dma16(rs_v, ok ? vvo : OOB, so, dst + i * 4096 + 16384);
-        }
-      };
-      auto issue_q = [&](int itm, int par) __attribute__((always_inline)) {  // Q tile of item itm -> Q buffer par
-        const int p2 = itm >> 16, q2 = itm & 0xffff;
-        const int b2 = p2 / a.heads, h2 = p2 - b2 * a.heads;
-        const i32x4 rs_q = make_rsrc((const bf16*)a.q + (size_t)b2 * Lq * C, Lq * C * 2);
-        const unsigned dst = lds0 + QOFF + par * QTILE + lw * 1024;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const bool ok = q2 * 128 + drow + 32 * i < Lq;
-          dma16(rs_q, ok ? ((drow * C + h2 * 64) * 2 + ksw) : OOB, (q2 * 128 + 32 * i) * C * 2, dst + i * 4096);
-        }
-      };
-      if (it == 0) {
-        issue_q(item, 0);
-        issue_block(0);
-        if (nblk > 1) issue_block(1);
-      }
-      if (nblk > 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                             // B0: Q tile + block 0 landed
-#pragma unroll 1
-      for (int j = 0; j + 1 < nblk; ++j) {
-        if (j + 2 < nblk) {
-#ifdef ATTN_STAMP
-          if (!(a.dkv_chunks & 1))                 // diagnostic: bit 0 = no DMA in the steady state (results are garbage)
-#endif
-          issue_block(j + 2);
-          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __syncthreads();                           // barrier_j: block j + 1 landed; block j - 1 released
-      }
-      const int next = item_at(it + 1);
-      if (next >= 0) issue_q(next, (it + 1) & 1);
-      __syncthreads();                             // E1: the compute waves are done with the ring
-      if (next >= 0) {                             // the next item's first two blocks -> slots 2, 3 (the merge uses 0, 1)
-        const int p2 = next >> 16, q2 = next & 0xffff;
-        const int b2 = p2 / a.heads, h2 = p2 - b2 * a.heads;
-        const int trow2 = q2 >> d.tshift;
-        const int nent2 = __builtin_amdgcn_readfirstlane(a.kv_num[trow2]);
-        const int kvl2 = (lane < nent2) ? a.kv_idx[(size_t)trow2 * a.tab_cols + lane] : 0;
-        asm volatile("" ::"v"(kvl2));
-        const i32x4 rs_k2 = make_rsrc((const bf16*)a.k + (size_t)b2 * Lk * C, Lk * C * 2);
-        const i32x4 rs_v2 = make_rsrc((const bf16*)a.v + (size_t)b2 * Lk * C, Lk * C * 2);
-        const int kvo2 = (drow * C + h2 * 64) * 2 + ksw, vvo2 = (drow * C + h2 * 64) * 2 + vsw_;
-        const int nb2 = nent2 << d.tshift;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          if (j < nb2) {
-            const int key0 = (((__builtin_amdgcn_readlane(kvl2, j >> d.tshift)) << d.tshift) + (j & tmask)) * 128;
-            const unsigned dst = lds0 + ((j + 2) & 3) * SLOT + lw * 1024;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              const bool ok = drow + 32 * i < Lk - key0;
-              const int so = (key0 + 32 * i) * C * 2;
-              dma16(rs_k2, ok ? kvo2 : OOB, so, dst + i * 4096);
-              dma16(rs_v2, ok ? vvo2 : OOB, so, dst + i * 4096 + 16384);
-            }
-          }
-        }
-      }
-      __syncthreads();                             // E2
-      item = next;
-    }
-    return;
-  }
-
-  // -------------------------------------------------------------------------------------------------- compute waves
-  const int r = lane & 31, h = lane >> 5;
-  const int qw = wave & 1, st = wave >> 1;
-  const int kb0 = (64 * st + r) * 128 + ((h ^ ((r >> 1) & 7)) << 4);
-  const int grp = lane >> 4, hh = grp >> 1, q4 = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
-  const int vb0 = 128 * 128 + (64 * st + 4 * hh + q4) * 128 + pcol * 2, vsw = (q4 >> 1) & 1;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  auto vtr = [&](const unsigned char* slot, int tokbase, int dt) __attribute__((always_inline)) {
-    const unsigned char* p0 = slot + vb0 + tokbase * 128 + ((dt ^ vsw) * 64);
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 128));
-    s16x8 v;
-    v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-    v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-    return __builtin_bit_cast(bf16x8, v);
-  };
-  f32x16 zero16;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-
-  int item = item_at(0);
-  STAMP_DECL
-#pragma unroll 1
-  for (int it = 0; item >= 0; ++it) {
-    const int pair = item >> 16, qb128 = item & 0xffff;
-    const int b = pair / a.heads, head = pair - b * a.heads;
-    const int qw0 = qb128 * 128 + qw * 64;          // this wave's 64 query rows; lane r of query block x: row qw0 + 32 x + r
-    const int nblk = item_blocks(item);
-    const int trow = qb128 >> d.tshift, tmask = (1 << d.tshift) - 1;
-    const int last_e = __builtin_amdgcn_readfirstlane(a.kv_idx[(size_t)trow * a.tab_cols + ((nblk - 1) >> d.tshift)]);
-    const int last_key0 = ((last_e << d.tshift) + ((nblk - 1) & tmask)) * 128 + 64 * st;
-
-    f32x16 o[2][2];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][0][i] = 0.f; o[0][1][i] = 0.f; o[1][0][i] = 0.f; o[1][1][i] = 0.f; }
-    float l2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
-
-    auto load_k = [&](bf16x8 (&kf)[4], const unsigned char* S0, int kt) __attribute__((always_inline)) {
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(S0 + ((kb0 ^ (ks * 32)) + kt * 4096));
-    };
-    auto load_v = [&](bf16x8 (&vf)[2][2], const unsigned char* S0, int kt) __attribute__((always_inline)) {
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) vf[s2][dt] = vtr(S0, kt * 32 + 16 * s2, dt);
-    };
-    auto softmax_part = [&](f32x16 (&s)[2], bf16x8 (&pb)[2][2], int x, int s2) __attribute__((always_inline)) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float p = __builtin_amdgcn_exp2f(s[x][8 * s2 + e]);
-        l2[x][e & 1] += p;
-        pb[x][s2][e] = f2bf(p);
-      }
-    };
-    auto pv = [&](bf16x8 (&vf)[2][2], bf16x8 (&pb)[2][2]) __attribute__((always_inline)) {
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) o[x][dt] = mfma32(vf[s2][dt], pb[x][s2], o[x][dt]);
-    };
-    // mask of the list's last block, added to its scores before the exponentials: 0 (allowed) / -1e30.  An accumulator
-    // register group rr = 4 g .. 4 g + 3 holds 4 consecutive, 4-aligned keys: one frame (P is a power of two >= 4) and
-    // one side of Lk (a multiple of 8), so the mask is evaluated once per group.
-    auto add_mask = [&](f32x16 (&s)[2], int kt) __attribute__((always_inline)) {
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-        const int qrow = qw0 + 32 * x + r;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int key = last_key0 + 32 * kt + 8 * g + 4 * h;
-          const float m = (key < Lk && qrow < Lq && tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) ? 0.f : NEG_BIG;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) s[x][4 * g + k] += m;
-        }
-      }
-    };
-
-    __syncthreads();                               // B0: Q tile + block 0 landed
-    STAMP(0)                                       // wait for the item's Q tile and first block
-    bf16x8 qf[2][4];
-    {
-      const unsigned char* Qt = smem + QOFF + (it & 1) * QTILE;
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const int row = 64 * qw + 32 * x + r;
-          const bf16x8 xx = *(const bf16x8*)(Qt + row * 128 + (((2 * ks + h) ^ ((row >> 1) & 7)) << 4));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) qf[x][ks][e] = f2bf(bf2f(xx[e]) * SCALE_LOG2);
-        }
-    }
-    bf16x8 kfa[4], vfa[2][2];
-    f32x16 sa[2], sb[2];
-    load_k(kfa, smem + 2 * SLOT, 0);
-#pragma unroll
-    for (int x = 0; x < 2; ++x)
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) sa[x] = mfma32(kfa[ks], qf[x][ks], ks == 0 ? zero16 : sa[x]);
-
-#ifdef ATTN_STAMP
-    asm volatile("" ::"v"(sa[0]), "v"(sa[1]));
-#endif
-    STAMP(1)                                       // Q fragments, first S^T
-    int sl = 2;
-#pragma unroll 1
-    for (int j = 0; j + 1 < nblk; ++j) {
-      const unsigned char* S0 = smem + sl * SLOT;
-      const int sl1 = (sl + 1) & 3;
-      const unsigned char* S1 = smem + sl1 * SLOT;
-      bf16x8 pb[2][2];
-      // ---- sub-step (j, 0): V of (j, 0) and K of (j, 1) are read first; S^T(j, 1) under softmax(j, 0)
-      load_v(vfa, S0, 0);
-      load_k(kfa, S0, 1);
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          sb[x] = mfma32(kfa[ks], qf[x][ks], ks == 0 ? zero16 : sb[x]);
-          if ((ks & 1) == 1) softmax_part(sa, pb, x, ks >> 1);
-        }
-      pv(vfa, pb);
-      // ---- sub-step (j, 1): its K fragments were read above; the next S^T needs block j + 1
-      load_v(vfa, S0, 1);
-#ifdef ATTN_STAMP
-      asm volatile("" ::"v"(o[0][0]), "v"(o[0][1]), "v"(o[1][0]), "v"(o[1][1]));
-#endif
-      STAMP(2)                                     // sub-step (j, 0)
-      __syncthreads();                             // barrier_j: block j + 1 landed (loader waves), block j - 1 released
-      STAMP(3)                                     // barrier
-      load_k(kfa, S1, 0);
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          sa[x] = mfma32(kfa[ks], qf[x][ks], ks == 0 ? zero16 : sa[x]);
-          if ((ks & 1) == 1) softmax_part(sb, pb, x, ks >> 1);
-        }
-      pv(vfa, pb);
-      sl = sl1;
-#ifdef ATTN_STAMP
-      asm volatile("" ::"v"(o[0][0]), "v"(o[0][1]), "v"(o[1][0]), "v"(o[1][1]));
-#endif
-      STAMP(4)                                     // sub-step (j, 1)
-    }
-    {                                              // last block of the list: the only one with a mask
-      const unsigned char* S0 = smem + sl * SLOT;
-      bf16x8 pb[2][2];
-      load_v(vfa, S0, 0);
-      load_k(kfa, S0, 1);
-      add_mask(sa, 0);
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          sb[x] = mfma32(kfa[ks], qf[x][ks], ks == 0 ? zero16 : sb[x]);
-          if ((ks & 1) == 1) softmax_part(sa, pb, x, ks >> 1);
-        }
-      pv(vfa, pb);
-      load_v(vfa, S0, 1);
-      add_mask(sb, 1);
-#pragma unroll
-      for (int x = 0; x < 2; ++x)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) softmax_part(sb, pb, x, s2);
-      pv(vfa, pb);
-    }
-
-    // ---- epilogue of the item: key half st = 1 hands (O, l) to st = 0 through LDS (ring slots 0, 1); normalise; rows
-    float l[2] = {l2[0][0] + l2[0][1], l2[1][0] + l2[1][1]};
-    float* red = (float*)smem;                     // [2 query waves][66][64] floats
-#ifdef ATTN_STAMP
-    asm volatile("" ::"v"(o[0][0]), "v"(o[0][1]), "v"(o[1][0]), "v"(o[1][1]));
-#endif
-    STAMP(5)                                       // last block
-    __syncthreads();                               // E1: every compute wave is done with the ring
-    STAMP(6)                                       // E1 barrier
-    if (st == 1) {
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          red[(qw * 66 + x * 33 + i) * 64 + lane] = o[x][0][i];
-          red[(qw * 66 + x * 33 + 16 + i) * 64 + lane] = o[x][1][i];
-        }
-        red[(qw * 66 + x * 33 + 32) * 64 + lane] = l[x];
-      }
-    }
-    __syncthreads();                               // E2
-    if (st == 0) {
-      unsigned char* ot = smem + 2 * 66 * 64 * 4 + qw * 4096;      // wave-private 32 rows x 128 B
-#pragma unroll
-      for (int x = 0; x < 2; ++x) {
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          o[x][0][i] += red[(qw * 66 + x * 33 + i) * 64 + lane];
-          o[x][1][i] += red[(qw * 66 + x * 33 + 16 + i) * 64 + lane];
-        }
-        float lx = l[x] + red[(qw * 66 + x * 33 + 32) * 64 + lane];
-        lx += __shfl_xor(lx, 32);
-        const float inv = (lx > 0.f) ? 1.f / lx : 0.f;
-        const int q0 = qw0 + 32 * x;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            bf16x4 ov;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) ov[k] = f2bf(o[x][dt][4 * g + k] * inv);
-            const int part = dt * 4 + g;
-            *(bf16x4*)(ot + r * 128 + ((part ^ (r & 7)) << 4) + 8 * h) = ov;
-          }
-        if (a.lse && h == 0 && q0 + r < Lq)
-          a.lse[(size_t)(b * a.heads + head) * Lq + q0 + r] = log2f(fmaxf(lx, 1e-30f));
-        bf16* og = (bf16*)a.out + ((size_t)b * Lq + q0) * C + head * 64;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = i * 8 + (lane >> 3), part = lane & 7;
-          const u32x4 v = *(const u32x4*)(ot + row * 128 + ((part ^ (row & 7)) << 4));
-          if (q0 + row < Lq) *(u32x4*)(og + (size_t)row * C + part * 8) = v;
-        }
-      }
-    }
-    item = item_at(it + 1);
-    STAMP(7)                                       // merge, normalise, stores
-  }
-#ifdef ATTN_STAMP
-  if (blockIdx.x == 0 && lane == 0 && a.dkv_part) {
-    unsigned long long* dst = (unsigned long long*)a.dkv_part + wave * 8;
-    for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
-  }
-#endif
-#endif
-}

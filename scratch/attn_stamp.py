@@ -30,7 +30,7 @@ e1.record(); torch.cuda.synchronize()
 print("us per launch (stamped build)", e0.elapsed_time(e1) * 100)
 names = (["setup", "dma wait", "barrier", "dma issue", "cls+ldsread", "mfma+softmax", "epilogue", "-"] if os.environ.get("P8") else
          ["setup", "fill", "substep0", "dma wait", "barrier", "dma issue", "substep1", "last+epilogue"] if os.environ.get("P4") else
-         ["B0 wait", "Q+first S", "substep0", "barrier", "substep1", "last block", "E1", "epilogue"])
+         ["B0 wait", "fill", "-", "steady blocks", "last 2 blocks", "E1 wait", "epilogue", "-"])
 s = stamps.view(8, 8).cpu()
 print("workgroup 0: items", [(int(e) >> 16, int(e) & 0xffff) for e in sched[0][0].cpu() if e >= 0], " (100 MHz ticks x 1)")
 for w in range(8):
