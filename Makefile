@@ -9,8 +9,8 @@ HDRS := $(wildcard $(CSRC)/*.h) include/oniris.h
 
 all: $(OUT)
 
-# attention: MFMA results in arch VGPRs even where the register budget would allow AGPRs (the one-wave-per-SIMD forward
-# feeds every S^T accumulator to v_exp_f32; the AGPR form costs one v_accvgpr_read per element)
+# attention: MFMA results in arch VGPRs (every S^T accumulator feeds v_exp_f32; the AGPR form hipcc otherwise picks for
+# kernels it cannot fit into 256 registers costs one v_accvgpr_read per element)
 build/attention.hip.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1
 build/attention_stamp.o: HIPFLAGS += -mllvm -amdgpu-mfma-vgpr-form=1
 

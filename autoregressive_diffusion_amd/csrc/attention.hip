@@ -324,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 #endif
 }
 
-#include "attention_p.h"
 #include "attention_ws.h"
 
 // ================================================================================================================
@@ -940,20 +939,12 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
   int rc = attn_prepare(args, d, "attn_fwd");
   if (rc) return rc;
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.out, "attn_fwd: null pointer");
-  if (d.a.sched) {                                  // persistent, statically balanced kernel (attention_p.h)
+  if (d.a.sched) {                                  // persistent, statically balanced, wave-specialised kernel (attention_ws.h)
     ONIRIS_CHECK_ARG(d.a.sched_wgs > 0 && d.a.sched_slots > 0, "attn_fwd: empty schedule");
     ONIRIS_CHECK_ARG(d.a.mask_mode != 0, "attn_fwd: the scheduled kernel serves the table-driven masks");
     ONIRIS_CHECK_ARG(d.a.kv_num && d.a.kv_idx && d.a.tab_cols <= 64, "attn_fwd: the scheduled kernel needs a table with <= 64 blocks per row");
-    if (d.a.pad_ == 8) {                            // A/B knob: the 8-wave, two-waves-per-SIMD variant
-      if (d.a.mask_mode == 1) hipLaunchKernelGGL(attn_fwd_p_kernel<1>, dim3(d.a.sched_wgs), dim3(512), 0, stream, d);
-      else hipLaunchKernelGGL(attn_fwd_p_kernel<2>, dim3(d.a.sched_wgs), dim3(512), 0, stream, d);
-    } else if (d.a.pad_ == 4) {                     // A/B knob: 4 waves, DMA issued by the compute waves
-      if (d.a.mask_mode == 1) hipLaunchKernelGGL(attn_fwd_p4_kernel<1>, dim3(d.a.sched_wgs), dim3(256), 0, stream, d);
-      else hipLaunchKernelGGL(attn_fwd_p4_kernel<2>, dim3(d.a.sched_wgs), dim3(256), 0, stream, d);
-    } else {
-      if (d.a.mask_mode == 1) hipLaunchKernelGGL(attn_fwd_ws_kernel<1>, dim3(d.a.sched_wgs), dim3(512), 0, stream, d);
-      else hipLaunchKernelGGL(attn_fwd_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), 0, stream, d);
-    }
+    if (d.a.mask_mode == 1) hipLaunchKernelGGL(attn_fwd_ws_kernel<1>, dim3(d.a.sched_wgs), dim3(512), 0, stream, d);
+    else hipLaunchKernelGGL(attn_fwd_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), 0, stream, d);
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }

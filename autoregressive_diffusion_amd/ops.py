@@ -960,8 +960,7 @@ class _AttentionFn(torch.autograd.Function):
             # persistent kernel: query blocks of 128 rows, cost = key blocks of its table row + 1 (fixed per-item work)
             sched = _train_sched(T, P, Bq * heads, dev, "fwd")
             a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
-            a.pad_ = ATTN_PERSISTENT if ATTN_PERSISTENT in (4, 8) else 0
-            name = {4: "attn_fwd_p4_kernel", 8: "attn_fwd_p_kernel"}.get(ATTN_PERSISTENT, "attn_fwd_ws_kernel") + f"<MODE={mask_mode}>"
+            name = f"attn_fwd_ws_kernel<MODE={mask_mode}>"
         _profiled(name, fl, lambda: check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd"))
         ctx.meta = (kind, B, T, heads, Bq, L, frames, P, C, mask_mode)
         ctx.tabs, ctx.tabs_r = tabs, tabs_r

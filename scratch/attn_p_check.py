@@ -11,7 +11,7 @@ inv = (1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).cuda()
 sc = ((torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)).cuda()
 g = torch.randn(N, P, C, device="cuda").to(torch.bfloat16)
 res = {}
-for mode in (0, 4, 1):
+for mode in (0, 1):
     ops.ATTN_PERSISTENT = mode
     xx = x.clone().requires_grad_(True)
     out = ops.attention_train(xx, "video", B, T, m, (inv, sc))

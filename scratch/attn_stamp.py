@@ -18,7 +18,6 @@ a.sched, a.sched_wgs, a.sched_slots = sched[0].data_ptr(), sched[1], sched[2]
 stamps = torch.zeros(8 * 8, dtype=torch.int64, device="cuda")
 a.dkv_part = stamps.data_ptr()
 a.dkv_chunks = int(os.environ.get('DBG', 0))
-a.pad_ = 8 if os.environ.get('P8') else 4 if os.environ.get('P4') else 0
 for _ in range(3):
     check(lib.oniris_attn_fwd(ctypes.byref(a), ops._stream()), "attn_fwd")
 torch.cuda.synchronize()
@@ -28,9 +27,7 @@ for _ in range(10):
     check(lib.oniris_attn_fwd(ctypes.byref(a), ops._stream()), "attn_fwd")
 e1.record(); torch.cuda.synchronize()
 print("us per launch (stamped build)", e0.elapsed_time(e1) * 100)
-names = (["setup", "dma wait", "barrier", "dma issue", "cls+ldsread", "mfma+softmax", "epilogue", "-"] if os.environ.get("P8") else
-         ["setup", "fill", "substep0", "dma wait", "barrier", "dma issue", "substep1", "last+epilogue"] if os.environ.get("P4") else
-         ["B0 wait", "fill", "-", "steady blocks", "last 2 blocks", "E1 wait", "epilogue", "-"])
+names = ["B0 wait", "fill", "-", "steady blocks", "last 2 blocks", "E1 wait", "epilogue", "-"]
 s = stamps.view(8, 8).cpu()
 print("workgroup 0: items", [(int(e) >> 16, int(e) & 0xffff) for e in sched[0][0].cpu() if e >= 0], " (100 MHz ticks x 1)")
 for w in range(8):
