@@ -69,3 +69,31 @@ def test_product_path_has_no_cpu_fallback():
     m = MPConv(16, 16, [3, 3])
     with pytest.raises(RuntimeError):
         m(torch.randn(1, 16, 8, 8))           # CPU tensors: loud failure, never a silent PyTorch path
+
+
+def test_attn_schedule_is_a_balanced_partition():
+    """oniris_attn_schedule (host): every (pair, block) item exactly once, pairs stay inside their workgroup group,
+    and at the C2 shape (8 pairs x 64 query blocks, 256 workgroups) every workgroup gets the same load."""
+    import ctypes
+    from autoregressive_diffusion_amd import ops, _lib
+    num, idx, blk = ops.train_mask_table(64, 64)
+    w = np.repeat(num * (blk // 128) + 1, blk // 128).astype(np.int32)
+    for pairs, n_wg in ((8, 256), (16, 256), (4, 256), (12, 256), (6, 64), (1, 8)):
+        need = _lib.lib.oniris_attn_schedule(pairs, len(w), w.ctypes.data_as(ctypes.c_void_p), n_wg, None, 0)
+        assert need >= 1
+        tab = np.full((n_wg, need), -7, np.int32)
+        assert _lib.lib.oniris_attn_schedule(pairs, len(w), w.ctypes.data_as(ctypes.c_void_p), n_wg,
+                                             tab.ctypes.data_as(ctypes.c_void_p), need) == need
+        items = sorted(int(e) for e in tab.ravel() if e >= 0)
+        assert items == sorted((p << 16) | b for p in range(pairs) for b in range(len(w)))
+        assert all((row[np.argmax(row < 0):] < 0).all() for row in tab if (row < 0).any()), "items first, then -1"
+        ng = next(g for g in (8, 4, 2, 1) if pairs % g == 0 and n_wg % g == 0)
+        for wg, row in enumerate(tab):
+            assert all((int(e) >> 16) % ng == wg % ng for e in row if e >= 0)
+        loads = np.array([sum(int(w[e & 0xffff]) for e in row if e >= 0) for row in tab])
+        if pairs in (8, 16):
+            assert loads.min() == loads.max()
+    # too few slots -> error code, message through oniris_last_error
+    tab = np.zeros((256, 1), np.int32)
+    assert _lib.lib.oniris_attn_schedule(8, len(w), w.ctypes.data_as(ctypes.c_void_p), 256,
+                                         tab.ctypes.data_as(ctypes.c_void_p), 1) < 0

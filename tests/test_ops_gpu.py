@@ -277,12 +277,17 @@ def _attn_ref(x0, wq, wp, B, m, training, just_2d=False, rope=True):
     return p
 
 
+@pytest.mark.parametrize("persistent", [1, 0])
 @pytest.mark.parametrize("B,T,H,m,chunks", [(2, 4, 8, 1, 1), (1, 8, 4, 2, 1), (1, 2, 16, 1, 1), (1, 16, 8, 2, 1),
                                             # dK/dV with every key block's query list split over 3 workgroups
-                                            (1, 16, 8, 2, 3), (2, 4, 8, 1, 3)])
-def test_video_attention_core_train(B, T, H, m, chunks, monkeypatch):
-    """qkv -> attention output (the part between the qkv conv and the proj conv), forward + backward."""
+                                            (1, 16, 8, 2, 3), (2, 4, 8, 1, 3),
+                                            # 12 (batch, head) pairs (4 XCD groups), Counter-Strike shape (P = 16, 8 heads)
+                                            (3, 16, 8, 4, 1), (1, 32, 4, 8, 1)])
+def test_video_attention_core_train(B, T, H, m, chunks, persistent, monkeypatch):
+    """qkv -> attention output (the part between the qkv conv and the proj conv), forward + backward; the forward
+    through the persistent wave-specialised kernel (attn_fwd_ws_kernel) and through the grid kernel."""
     from autoregressive_diffusion_amd import ops
+    monkeypatch.setattr(ops, "ATTN_PERSISTENT", persistent)
     monkeypatch.setattr(ops, "ATTN_DKV_CHUNKS", chunks)
     monkeypatch.setattr(ops, "ATTN_DKV_MIN_L", 128)
     torch.manual_seed(5)
