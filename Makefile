@@ -31,8 +31,11 @@ STAMP_OUT := autoregressive_diffusion_amd/liboniris_hip_stamp.so
 build/attention_stamp.o: $(CSRC)/attention.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DATTN_STAMP -c $< -o $@
-stamp: build/attention_stamp.o $(OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(STAMP_OUT) build/attention_stamp.o $(filter-out build/attention.hip.o,$(OBJS)) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+build/conv_fwd_s2ctx_stamp.o: $(CSRC)/conv_fwd_s2ctx.hip $(HDRS)
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -DCONV_STAMP -c $< -o $@
+stamp: build/attention_stamp.o build/conv_fwd_s2ctx_stamp.o $(OBJS)
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(STAMP_OUT) build/attention_stamp.o build/conv_fwd_s2ctx_stamp.o $(filter-out build/attention.hip.o build/conv_fwd_s2ctx.hip.o,$(OBJS)) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
 
 clean:
 	rm -rf build $(OUT)

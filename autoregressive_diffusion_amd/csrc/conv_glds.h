@@ -24,6 +24,16 @@
 
 #include "lds_dma.h"
 
+// Diagnostic build only (make stamp: -DCONV_STAMP): per-phase cycle sums of every wave of workgroup 0, written to the
+// buffer passed in OnirisConvArgs.splitk_ws (unused by this kernel): [wave][8] uint64.
+#ifdef CONV_STAMP
+#define CSTAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CSTAMP(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; }
+#else
+#define CSTAMP_DECL
+#define CSTAMP(i)
+#endif
+
 // NT: 32-channel tiles per wave; WC: channel groups of waves (a workgroup covers 32*NT*WC channels and
 // 32*(NW/WC)*MT positions).  PW = 16: one 16x16 tile of one frame; PW = 8: two whole 8x8 frames, and the halo rows are
 // 12 entries wide (2 unused) so that the patch rows py and py+2 a 16-lane read group takes are 24 = 8 (mod 16) rows apart.
@@ -220,7 +230,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   f32x16 acc[S][MT][NT];
   f32x16 accc[MT][NT];
 
-  auto mfma_steps = [&](auto own_, int boff, int woff) __attribute__((always_inline)) {
+  // `mid`: called once, in front of step MID_STEP (wave-uniform; the younger half of the workgroup issues its share of
+  // the next phase's DMA there, see the phase loop)
+  constexpr int MID_STEP = 4;
+  auto mfma_steps = [&](auto own_, int boff, int woff, auto mid) __attribute__((always_inline)) {
     constexpr bool OWN = decltype(own_)::value;
     constexpr int NX = OWN ? S : 1;
     constexpr int NSTEP = TAPS * KS;
@@ -241,6 +254,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     ld(0, 0);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
+      if (st == MID_STEP) mid();
       if (st + 1 < NSTEP) ld((st + 1) & 1, st + 1);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -258,6 +272,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       __builtin_amdgcn_sched_group_barrier(0x008, NX * MT * NT, 0);
     }
   };
+  auto no_mid = []() __attribute__((always_inline)) {};
 
   constexpr int EROW = Cfg::EROW;
   constexpr int ESC = 2 * FT * BN * 4;                  // emb-scale vectors [slot][frame][BN], in front of the staging tiles
@@ -270,10 +285,12 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   Tile nxt = cur;
   bool more = false;
   int tl_next = tl;
+  CSTAMP_DECL
 #pragma unroll 1
   for (;;) {
     dma_wait();
     __syncthreads();     // phase 0 of `cur` has landed for everybody; the previous epilogue is over
+    CSTAMP(0)
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -294,15 +311,33 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       if (co < a.Cout && cur.t0 + f_ < T)
         esc_v = ((const float*)a.escale)[(size_t)((cur.b * S + s_) * T + cur.t0 + f_) * a.Cout + co];
     }
+    CSTAMP(1)
     if constexpr (!RES) {
 #pragma unroll 1
       for (int itp = 0; itp < nphase; ++itp) {
         const int ph = itp % NPH;
-        if (itp + 1 < nphase) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);   // buffer bsel^1: last read in phase itp-1
-        if (!CTX || ph == 0) mfma_steps(std::true_type{}, bsel * BUF, AROWS * 64);
-        else mfma_steps(std::false_type{}, bsel * BUF, AROWS * 64);
+        // The copy of the next phase (buffer bsel^1: last read in phase itp-1) is issued by the older half of the waves
+        // BEFORE their MFMAs and by the younger half a few steps INTO theirs.  A buffer_load..lds costs its wave ~100
+        // cycles of issue; with all eight waves issuing at the phase top (they leave the barrier together) the matrix
+        // pipe of every SIMD sat idle for the ~1000 cycles its two waves spent on their ~10 pieces each (stamped: 30 %
+        // of the kernel).  Now one wave of a SIMD feeds the matrix pipe while the other one issues.
+        const bool have_next = itp + 1 < nphase;
+        const bool early = __builtin_amdgcn_readfirstlane(wave) < NW / 2;
+        if (have_next && early) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);
+        auto mid = [&]() __attribute__((always_inline)) {
+          if (have_next && !early) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);
+        };
+        CSTAMP(2)
+        if (!CTX || ph == 0) mfma_steps(std::true_type{}, bsel * BUF, AROWS * 64, mid);
+        else mfma_steps(std::false_type{}, bsel * BUF, AROWS * 64, mid);
+#ifdef CONV_STAMP
+        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(accc[0][0]), "v"(acc[0][0][NT - 1]), "v"(acc[1][0][NT - 1]), "v"(accc[0][NT - 1]));
+#endif
+        CSTAMP(3)
         dma_wait();                        // this wave's share of the next phase has landed ...
+        CSTAMP(4)
         __syncthreads();                   // ... everybody's has; and everybody is done reading buffer bsel
+        CSTAMP(5)
         bsel ^= 1;
       }
     }
@@ -310,7 +345,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     // the next tile goes to buffer bsel, continuing the alternation.  (RES: a dedicated staging area.)
     unsigned char* stg = smem + (RES ? Cfg::RES_EOFF : (bsel ^ 1) * BUF);
     unsigned char* ep = stg + ESC + wave * 32 * EROW;
-    if constexpr (RES) mfma_steps(std::true_type{}, 0, AROWS * 64);       // own phase (all three regions landed at the tile top)
+    if constexpr (RES) mfma_steps(std::true_type{}, 0, AROWS * 64, no_mid);       // own phase (all three regions landed at the tile top)
 
     // -- epilogue inputs must not wait behind the next LDS-DMA (vmcnt is in order, and hipcc waits vmcnt(0) at the
     // first use of an ordinary load issued while DMA is in flight): gate coefficients and emb-scale were fetched at
@@ -330,10 +365,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       // the only one.  (Ordinary loads were consumed above: from here on DMA is always in flight.)
       __syncthreads();                                   // everybody is done reading the own region
       if (more) { nxt = decode(tl_next); set_adesc(nxt); issue(nxt, 0, 0, 0); }
-      mfma_steps(std::false_type{}, BUF, Cfg::SROWS * 64);
+      mfma_steps(std::false_type{}, BUF, Cfg::SROWS * 64, no_mid);
       __syncthreads();
       if (more) issue(nxt, 0, 1, 0);
-      mfma_steps(std::false_type{}, BUF + Cfg::BUFC, Cfg::SROWS * 64);
+      mfma_steps(std::false_type{}, BUF + Cfg::BUFC, Cfg::SROWS * 64, no_mid);
       __syncthreads();
       if (more) issue(nxt, 0, 2, 0);
     } else if (more) {
@@ -445,10 +480,17 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
         }
       }
     }
+    CSTAMP(6)
     if (!more) break;
     cur = nxt;
     tl = tl_next;
   }
+#ifdef CONV_STAMP
+  if (blockIdx.x == 0 && lane == 0 && a.splitk_ws) {
+    unsigned long long* dst = (unsigned long long*)a.splitk_ws + wave * 8;
+    for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
+  }
+#endif
 #endif
 }
 

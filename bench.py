@@ -276,7 +276,7 @@ def main():
         kernels = {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
                            tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in
                    sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-        attn = {k: v for k, v in agg.items() if k.startswith("attn_fwd_kernel<MODE=2")}
+        attn = {k: v for k, v in agg.items() if k.startswith("attn_fwd") and "MODE=2" in k}      # VideoAttention forward
         dom, v = max(((k, v) for k, v in agg.items() if not k.startswith("attn_")), key=lambda kv: kv[1]["ms"])
         achieved = v["flops"] / (v["ms"] * 1e-3)
         roof = dict(bound="mfma", kernel=dom, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
