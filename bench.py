@@ -28,13 +28,14 @@ CS_CFG = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=128
 
 
 def _pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_traffic.json:
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN_pmc_traffic.json of the latest round:
     separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench, summarised by
     scratch/pmc_traffic.py with the gfx950 correction 2*FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be collected
     from inside the timed process, so the number is only as fresh as that file; None when the kernel is not in it."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if not os.path.exists(path):
+    prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    path = next((p for p in (os.path.join(prof, f"r{r:02d}_pmc_traffic.json") for r in range(9, 0, -1)) if os.path.exists(p)), None)
+    if path is None:                                             # (the newest round's passes)
         return None
     try:
         table = json.load(open(path))
