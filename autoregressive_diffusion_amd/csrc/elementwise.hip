@@ -184,6 +184,15 @@ __global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restric
   for (int i = threadIdx.x; i < C; i += 256) atomicAdd(dc + (size_t)n * C + i, acc[i]);
 }
 
+// dc is zeroed by a KERNEL, not by hipMemsetAsync: a memset node captured into a hipGraph was observed (ROCm 7.0/7.2,
+// gfx950) to leave stale values behind from the second replay on -- the 2-D training graph, the only one that takes this
+// path, replayed garbage emb-scale gradients (emb_noise / emb_label / emb_linear / emb_gain) while eager launches and
+// the first replay were right.  (This was the "graph replay nondeterminism" noted in round 1.)
+__global__ void zero_f32_kernel(float* __restrict__ p, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0.f;
+}
+
 extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P,
                                    int C, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
@@ -194,7 +203,8 @@ extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c
   // (every block ends with C global atomics: fewer, longer blocks are faster -- see oniris_gconv_bwd_fused)
   while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < 512) slices *= 2;
   const int ppb = cdiv(P, slices);
-  hipMemsetAsync(dc, 0, sizeof(float) * (size_t)N * C, stream);
+  const size_t ndc = (size_t)N * C;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
   hipLaunchKernelGGL(emb_silu_bwd_kernel, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
                      (bf16*)dy, dc, P, C, ppb);
   ONIRIS_LAUNCH_CHECK();

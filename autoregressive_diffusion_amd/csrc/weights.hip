@@ -219,6 +219,16 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                              float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
                              float bc1, float bc2, float gscale, const float* __restrict__ gnorm_sq, float max_norm,
                              float* __restrict__ ema0, float w0, float* __restrict__ ema1, float w1) {
+  if (bc1 == 0.f) {                             // step 0 = "these parameters had no gradient": only the EMA copies follow
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += stride)
+      for (size_t k = i; k < n && k < i + 4; ++k) {
+        if (ema0) ema0[k] += w0 * (p[k] - ema0[k]);
+        if (ema1) ema1[k] += w1 * (p[k] - ema1[k]);
+      }
+    return;
+  }
   if (gnorm_sq) {                               // torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (norm + 1e-6))
     const float coef = max_norm / (sqrtf(*gnorm_sq) * fabsf(gscale) + 1e-6f);
     if (coef < 1.f) gscale *= coef;
@@ -263,10 +273,11 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 static int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                         float eps, float weight_decay, int step, float grad_scale, const float* gnorm_sq, float max_norm,
                         float* ema0, float w0, float* ema1, float w1, hipStream_t stream) {
-  ONIRIS_CHECK_ARG(p && g && m && v && step >= 1, "adamw: bad arguments");
+  ONIRIS_CHECK_ARG(p && g && m && v && step >= 0, "adamw: bad arguments");
   ONIRIS_CHECK_ARG(!gnorm_sq || max_norm > 0.f, "adamw: clipping needs max_norm > 0");
   if (n == 0) return ONIRIS_OK;
-  const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+  const float bc1 = step ? 1.f - powf(beta1, (float)step) : 0.f, bc2 = step ? 1.f - powf(beta2, (float)step) : 0.f;
+  if (step == 0 && !ema0 && !ema1) return ONIRIS_OK;
   size_t nb = (n / 4 + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (nb == 0) nb = 1;

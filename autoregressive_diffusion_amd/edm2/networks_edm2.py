@@ -220,6 +220,20 @@ class UNet(BetterModule):
         """Weights packed row-concatenated (one GEMM for all): every Block's emb_linear reads the same embedding."""
         return [[b.emb_linear.weight for b in self._emb_blocks()]]
 
+    def _oniris_param_classes(self):
+        """Layout hint for parallel.FlatParams: {id(param): 0 every step | 1 only 3-D steps | 2 never} -- which steps give
+        a parameter its gradient (just_2d skips the context weights and gates, conv.py:60; out_res / emb_time are
+        evaluated but unused, networks_edm2.py:197,205-207)."""
+        cls = {}
+        for m in self.modules():
+            if isinstance(m, MPCausal3DGatedConv):
+                cls[id(m.weight.weight)] = 1
+                for p in m.gating.parameters():
+                    cls[id(p)] = 1
+        for p in list(self.out_res.parameters()) + list(self.emb_time.parameters()):
+            cls[id(p)] = 2
+        return cls
+
     def _oniris_overlap_plan(self, head_frac=0.12):
         """(name of an encoder block, [parameters]) for OnirisDDP's early gradient exchange: the kernel-owned weights
         (their .grad is written by weight_bwd, not by autograd) of every block AFTER the named one are final as soon

@@ -10,7 +10,7 @@ _capture_stream = None
 
 
 class GraphedStep:
-    def __init__(self, fn, warmup=3, params=None):
+    def __init__(self, fn, warmup=3, params=None, flat=None):
         """fn(): runs forward+backward on STATIC input tensors and returns a (loss) tensor.
         params: parameters whose .grad autograd (re)creates inside fn (FlatParams(lazy_small=True) sets them to None
         before every backward): the tensors the CAPTURED backward assigned are the ones every replay writes, so they
@@ -18,6 +18,13 @@ class GraphedStep:
         previous step and the replayed gradients of ~190 small parameters are silently dropped)."""
         self.fn, self.warmup = fn, warmup
         self.params, self._grads = list(params or ()), []
+        # flat: the FlatParams of the net -- which weights the captured backward produced gradients for is host-side
+        # bookkeeping (FlatAdamW skips parameters without gradient like torch.optim); a replay runs no Python, so the
+        # record of the captured backward is re-applied after every replay
+        if flat is None and self.params:
+            from .parallel import FlatParams
+            flat = FlatParams.owner_of(self.params[0])
+        self.flat, self._touched = flat, []
         self.graph, self.out, self.calls = None, None, 0
         # ONE side stream for the warm-up and the capture of EVERY GraphedStep: autograd pins each parameter's
         # AccumulateGrad node to the stream it was first used on; a node living on another stream would run outside
@@ -39,6 +46,8 @@ class GraphedStep:
             cur.wait_stream(self.stream)
             for p, g in self._grads:
                 p.grad = g
+            if self.flat is not None:
+                self.flat.restore_touched(self._touched)
             return self.out
         self.calls += 1
         if self.calls <= self.warmup:              # eager warm-up: builds tables, sets kernel attributes, fills caches
@@ -53,4 +62,6 @@ class GraphedStep:
             out = self.fn()
         self.graph, self.out = g, out
         self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
+        if self.flat is not None:
+            self._touched = self.flat.snapshot_touched()
         return self.__call__()

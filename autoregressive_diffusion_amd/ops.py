@@ -134,7 +134,7 @@ def attn_schedule(weights, n_pairs, device, n_wg=None):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp", "bank", "nsplit_cap", "nsplit", "group", "goff", "members")
+                 "wf", "wb", "dwp", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched")
 
 
 def _nsplit_cap(cin, cout, taps):
@@ -213,6 +213,7 @@ class WeightBank:
         w.perm3, w.gain = bool(perm3), float(gain)
         w.wf = w.wb = w.dwp = w.nsplit = None
         w.group, w.goff, w.members = None, 0, None
+        w.touched = False              # a weight-gradient launch targeted this weight since the last optimizer step
         # split-K slabs of the weight-gradient kernel: same bound as launch_wgrad() in csrc/conv_wgrad.hip
         w.nsplit_cap = _nsplit_cap(w.cin, w.cout, w.taps)
         w.bank = self
@@ -239,6 +240,7 @@ class WeightBank:
         g.CinP, g.CoutPb = roundup(g.cin, 64), roundup(g.cin, 32)
         g.perm3, g.gain, g.param, g.bank = False, 1.0, members[0].param, self
         g.wf = g.wb = g.dwp = g.nsplit = None
+        g.touched = False
         g.nsplit_cap = _nsplit_cap(g.cin, g.cout, 1)
         self.groups.append(g)
         self._dev_table = None
@@ -473,6 +475,10 @@ def _splitk_workspace(device):
 def _wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
     """pw: PackedWeight whose slabs receive the partial sums (taps [tap0, tap0+taps) of its pw.taps-deep slabs)."""
     a = _lib.WgradArgs()
+    pw.touched = True
+    if pw.members is not None:
+        for m_ in pw.members:
+            m_.touched = True
     a.x, a.dy, a.dwp, a.scale = _p(x), _p(dy), _p(pw.dwp), _p(scale)
     a.nsplit_cap, a.taps_total, a.tap0, a.nsplit_out = pw.nsplit_cap, pw.taps, tap0, _p(pw.nsplit)
     a.B, a.T, a.H, a.W, a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = B, T, H, W, Cin, CinP, Cout, CoutP, taps
@@ -1092,23 +1098,30 @@ def dart_loss(F, out_gain, images, noise, sigma, S, sigma_data):
 SQNORM_WS = 1024          # ONIRIS_SQNORM_WS in include/oniris.h
 
 
+def sqnorm_(g, norm_buf):
+    """norm_buf[0] <- sum(g^2) (deterministic two-stage reduction; norm_buf: 1 + SQNORM_WS floats)."""
+    _need_gpu(g, norm_buf)
+    check(lib.oniris_sqnorm(_p(g), g.numel(), _p(norm_buf), _stream()), "sqnorm")
+
+
 def adamw_(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step, grad_scale=1.0, max_norm=None, norm_buf=None,
-           emas=()):
+           emas=(), norm_ready=False):
     """Optimizer side of a training step on flat fp32 buffers (gym_train.py:105-108): optional gradient-norm clipping
     (norm_buf: 1 + SQNORM_WS floats of scratch, receives sum(g^2) in [0]), AdamW, and the power-function EMA update
     of up to two tracked copies -- emas = [(flat_tensor, 1 - beta), ...]."""
     _need_gpu(p, g, m, v)
     global _weights_epoch
     _weights_epoch += 1
-    if max_norm is None and not emas:
+    if max_norm is None and not emas and step >= 1:
         check(lib.oniris_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
                                grad_scale, _stream()), "adamw")
         return
     assert len(emas) <= 2
     gn = None
-    if max_norm is not None:
+    if max_norm is not None and step >= 1:
         assert norm_buf is not None and norm_buf.numel() >= 1 + SQNORM_WS and norm_buf.dtype == torch.float32
-        check(lib.oniris_sqnorm(_p(g), g.numel(), _p(norm_buf), _stream()), "sqnorm")
+        if not norm_ready:             # (norm_ready: the caller ran sqnorm_ over the WHOLE gradient buffer already)
+            check(lib.oniris_sqnorm(_p(g), g.numel(), _p(norm_buf), _stream()), "sqnorm")
         gn = norm_buf
     e = list(emas) + [(None, 0.0)] * (2 - len(emas))
     check(lib.oniris_adamw_clip_ema(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,

@@ -17,6 +17,13 @@ from torch import nn
 class FlatParams:
     """Re-homes every trainable parameter of `module` (and its .grad) as a view into one flat fp32 buffer."""
 
+    _registry = {}                 # id(parameter) -> weakref to the FlatParams that re-homed it (graphs.GraphedStep)
+
+    @classmethod
+    def owner_of(cls, param):
+        ref = cls._registry.get(id(param))
+        return ref() if ref is not None else None
+
     def __init__(self, module, lazy_small=False):
         """lazy_small: gradients of the parameters autograd itself accumulates (everything except the conv weights,
         whose .grad the HIP weight_bwd kernel writes through a raw pointer) are NOT accumulated into their flat slice
@@ -32,12 +39,19 @@ class FlatParams:
         # parameters whose gradient is final early in backward (module._oniris_overlap_plan) go, contiguous, to the
         # END of the buffers: OnirisDDP exchanges [tail_start, numel) while the rest of backward is still running
         plan = module._oniris_overlap_plan() if hasattr(module, "_oniris_overlap_plan") else None
+        # parameters that receive a gradient on the same steps sit next to each other (module hint: 0 = every step,
+        # 1 = 3-D steps only, 2 = never), so that FlatAdamW -- which, like torch.optim, skips parameters without a
+        # gradient -- covers the buffer with a handful of contiguous launches.  Correctness never depends on the hint.
+        cls = module._oniris_param_classes() if hasattr(module, "_oniris_param_classes") else {}
+        by_class = lambda ps: sorted(ps, key=lambda p: cls.get(id(p), 0))          # (stable)
         self.stage_at, ntail = None, 0
         if plan is not None and plan[1]:
             tail = {id(p) for p in plan[1]}
-            head = [p for p in self.params if id(p) not in tail]
-            self.params = head + [p for p in self.params if id(p) in tail]
+            head = by_class([p for p in self.params if id(p) not in tail])
+            self.params = head + by_class([p for p in self.params if id(p) in tail])
             self.stage_at, ntail = plan[0], len(self.params) - len(head)
+        else:
+            self.params = by_class(self.params)
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.dtype == dt and p.device == dev for p in self.params)
         sizes = [p.numel() for p in self.params]
@@ -55,11 +69,20 @@ class FlatParams:
                 v.copy_(p.data)
                 p.data = v
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+        import weakref
+        me = weakref.ref(self)
+        for p in self.params:
+            FlatParams._registry[id(p)] = me
         self._lazy = []
-        if lazy_small:
+        self._owner = {}                   # kernel-owned weight -> its NormalizedWeight module (.pw.touched: a wgrad ran)
+        self._got = set()                  # autograd-owned (lazy) parameters that received a gradient since take_active()
+        try:
             from .edm2.conv import NormalizedWeight
-            kernel_owned = {id(m.weight) for m in module.modules() if isinstance(m, NormalizedWeight)}
-            self._lazy = [(p, p.grad) for p in self.params if id(p) not in kernel_owned]
+            self._owner = {id(m.weight): m for m in module.modules() if isinstance(m, NormalizedWeight)}
+        except ImportError:                # (toy modules in the CPU tests)
+            pass
+        if lazy_small:
+            self._lazy = [(p, p.grad) for p in self.params if id(p) not in self._owner]
             for p, _ in self._lazy:
                 p.grad = None
 
@@ -85,10 +108,40 @@ class FlatParams:
             g = p.grad
             if g is not None and g.data_ptr() != view.data_ptr():
                 src.append(g.reshape(view.shape)); dst.append(view)
+                self._got.add(id(p))
             p.grad = view
         if src:
             with torch.no_grad():
                 torch._foreach_add_(dst, src)
+
+    def take_active(self):
+        """[bool per parameter, flat order]: did it receive a gradient since the last call?  (What torch.optim asks with
+        `p.grad is None`.)  Kernel-owned weights: a weight-gradient launch targeted them (PackedWeight.touched, host
+        side, no device sync); autograd-owned lazy parameters: autograd handed a gradient over (gather()); parameters
+        whose .grad is a permanent view of the flat buffer cannot tell "none" from "zero" and count as active."""
+        self.gather()
+        lazy = {id(p) for p, _ in self._lazy}
+        out = []
+        for p in self.params:
+            m = self._owner.get(id(p))
+            pw = getattr(m, "pw", None) if m is not None else None
+            if m is not None and pw is not None:
+                out.append(bool(pw.touched)); pw.touched = False
+            elif id(p) in lazy:
+                out.append(id(p) in self._got)
+            else:
+                out.append(True)
+        self._got.clear()
+        return out
+
+    def snapshot_touched(self):
+        """Host-side gradient bookkeeping of the backward that just ran (for graphs.GraphedStep: a replay runs no Python)."""
+        return [m.pw for m in self._owner.values() if getattr(m, "pw", None) is not None and m.pw.touched]
+
+    @staticmethod
+    def restore_touched(pws):
+        for pw in pws:
+            pw.touched = True
 
     def check(self):
         """True while every parameter still aliases the flat buffers (a .to()/deepcopy breaks the aliasing)."""
@@ -305,7 +358,8 @@ class FlatAdamW:
                                   maximize=False, params=list(range(len(flat.orig_params))))]
         self.m = torch.zeros_like(flat.flat)
         self.v = torch.zeros_like(flat.flat)
-        self.steps = 0
+        self.steps = 0                       # = max over the per-parameter step counters
+        self.param_steps = [0] * len(flat.params)      # flat order (torch.optim keeps `step` per parameter too)
         self._norm_buf = None
 
     lr = property(lambda self: self.param_groups[0]["lr"], lambda self, v: self.param_groups[0].__setitem__("lr", v))
@@ -317,9 +371,14 @@ class FlatAdamW:
         """torch.optim.AdamW's layout (what gym_train.py:137-138 saves): per-parameter `step` / `exp_avg` /
         `exp_avg_sq`, indexed in module.parameters() order, + param_groups."""
         f = self.flat
-        st = {i: dict(step=torch.tensor(float(self.steps)), exp_avg=f.slice_of(self.m, p).detach().clone(),
-                      exp_avg_sq=f.slice_of(self.v, p).detach().clone()) for i, p in enumerate(f.orig_params)}
-        return dict(state=st if self.steps else {}, param_groups=[dict(g) for g in self.param_groups])
+        pos = {id(p): k for k, p in enumerate(f.params)}
+        st = {}
+        for i, p in enumerate(f.orig_params):
+            n = self.param_steps[pos[id(p)]] if len(self.param_steps) == len(f.params) else self.steps
+            if n > 0:                                  # (torch has no state for a parameter that never had a gradient)
+                st[i] = dict(step=torch.tensor(float(n)), exp_avg=f.slice_of(self.m, p).detach().clone(),
+                             exp_avg_sq=f.slice_of(self.v, p).detach().clone())
+        return dict(state=st, param_groups=[dict(g) for g in self.param_groups])
 
     def load_state_dict(self, state):
         """Accepts its own state_dict() and a torch.optim.AdamW state_dict over the same parameters in the same
@@ -332,40 +391,66 @@ class FlatAdamW:
                 self.param_groups[0][k] = tuple(groups[0][k]) if k == "betas" else groups[0][k]
         st = state["state"]
         self.m.zero_(); self.v.zero_()
-        # torch keeps one step counter per parameter (a parameter whose .grad is None is skipped); the fused kernel
-        # keeps one for the whole buffer: resume from the furthest one
-        self.steps = max((int(float(s["step"])) for s in st.values()), default=0)
+        pos = {id(p): k for k, p in enumerate(f.params)}
+        self.param_steps = [0] * len(f.params)
         with torch.no_grad():
             for i, s in st.items():
                 p = f.orig_params[int(i)]
+                self.param_steps[pos[id(p)]] = int(float(s["step"]))
                 f.slice_of(self.m, p).copy_(s["exp_avg"])
                 f.slice_of(self.v, p).copy_(s["exp_avg_sq"])
+        self.steps = max(self.param_steps, default=0)
 
     @torch.no_grad()
     def step(self, grad_scale=1.0, max_norm=None, ema=None):
         """max_norm: torch.nn.utils.clip_grad_norm_(params, max_norm) before the update (gym_train.py:105);
-        ema: FlatEMA.weights(cur_nimg, batch_size) -> the tracked copies follow the updated parameters (:108)."""
-        self.steps += 1
+        ema: FlatEMA.weights(cur_nimg, batch_size) -> the tracked copies follow the updated parameters (:108).
+        Like torch.optim.AdamW, a parameter WITHOUT a gradient in this step (2-D steps: the context weights and gates;
+        never: out_res.*, emb_time; emb_label without conditioning) is skipped -- no moment decay, no weight decay, its
+        own step counter stands still; only its EMA copies follow.  The flat buffer is covered by one launch per run of
+        consecutive parameters with equal (has gradient, step count)."""
         f = self.flat
-        f.gather()
+        active = f.take_active()
         ema = list(ema or ())
+        if len(self.param_steps) != len(f.params):
+            self.param_steps = [self.steps] * len(f.params)
+        runs = []                                      # (lo, hi, step): step = new Adam step count, 0 = no gradient
+        for i, (p, o) in enumerate(zip(f.params, f.offsets)):
+            if active[i]:
+                self.param_steps[i] += 1
+            st = self.param_steps[i] if active[i] else 0
+            hi = f.offsets[i + 1] if i + 1 < len(f.params) else f.numel
+            if runs and runs[-1][2] == st:
+                runs[-1][1] = hi
+            else:
+                runs.append([o, hi, st])
+        self.steps = max(self.param_steps)
         if f.flat.is_cuda:
             from . import ops
-            if max_norm is not None and self._norm_buf is None:
-                self._norm_buf = torch.zeros(1 + ops.SQNORM_WS, dtype=torch.float32, device=f.flat.device)
-            ops.adamw_(f.flat, f.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps,
-                       self.weight_decay, self.steps, grad_scale, max_norm, self._norm_buf, ema)
+            if max_norm is not None:
+                if self._norm_buf is None:
+                    self._norm_buf = torch.zeros(1 + ops.SQNORM_WS, dtype=torch.float32, device=f.flat.device)
+                ops.sqnorm_(f.grad, self._norm_buf)    # over the whole buffer (parameters without gradient hold zeros)
+            for lo, hi, st in runs:
+                if st == 0 and not ema:
+                    continue
+                ops.adamw_(f.flat[lo:hi], f.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
+                           self.betas[1], self.eps, self.weight_decay, st, grad_scale, max_norm, self._norm_buf,
+                           [(e[lo:hi], w) for e, w in ema], norm_ready=True)
             return
         b1, b2 = self.betas
-        g = f.grad * grad_scale
+        coef = 1.0
         if max_norm is not None:
-            g = g * min(1.0, max_norm / (float(g.norm()) + 1e-6))
-        self.m.mul_(b1).add_(g, alpha=1 - b1)
-        self.v.mul_(b2).addcmul_(g, g, value=1 - b2)
-        mh, vh = self.m / (1 - b1 ** self.steps), self.v / (1 - b2 ** self.steps)
-        f.flat.mul_(1 - self.lr * self.weight_decay).sub_(self.lr * mh / (vh.sqrt() + self.eps))
-        for e, w in ema:
-            e.lerp_(f.flat, w)
+            coef = min(1.0, max_norm / (float((f.grad * grad_scale).norm()) + 1e-6))
+        for lo, hi, st in runs:
+            if st:
+                g = f.grad[lo:hi] * (grad_scale * coef)
+                self.m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
+                self.v[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
+                mh, vh = self.m[lo:hi] / (1 - b1 ** st), self.v[lo:hi] / (1 - b2 ** st)
+                f.flat[lo:hi].mul_(1 - self.lr * self.weight_decay).sub_(self.lr * mh / (vh.sqrt() + self.eps))
+            for e, w in ema:
+                e[lo:hi].lerp_(f.flat[lo:hi], w)
 
     def zero_grad(self):
         self.flat.zero_grad()

@@ -210,7 +210,8 @@ def main():
         else:
             def make(j2d):
                 return lambda: fwd_bwd(j2d)
-        graphed = {False: GraphedStep(make(False), params=flat.params), True: GraphedStep(make(True), params=flat.params)}
+        graphed = {False: GraphedStep(make(False), params=flat.params, flat=flat),
+                   True: GraphedStep(make(True), params=flat.params, flat=flat)}
 
     _only = os.environ.get("ONIRIS_ONLY_MODE")
 

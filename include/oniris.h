@@ -98,7 +98,9 @@ int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float l
 /* The whole optimizer side of a training step in one pass (gym_train.py:105-108): gradient-norm clipping
  * (torch.nn.utils.clip_grad_norm_: gradients scaled by min(1, max_norm / (||grad_scale*g|| + 1e-6)); gnorm_sq = device
  * scalar holding sum(g^2) from oniris_sqnorm, NULL = no clipping), AdamW, and the power-function EMA update of up to
- * two tracked copies (edm2/phema.py:101-106: ema += ema_w * (p_new - ema), ema_w = 1 - beta; NULL = not tracked).  */
+ * two tracked copies (edm2/phema.py:101-106: ema += ema_w * (p_new - ema), ema_w = 1 - beta; NULL = not tracked).
+ * step = the Adam step count of THESE parameters (bias correction); step == 0: the parameters received no gradient
+ * (torch.optim skips a parameter whose .grad is None): p, m, v stay untouched, only the EMA copies follow.             */
 int oniris_adamw_clip_ema(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                           float eps, float weight_decay, int step, float grad_scale, const float* gnorm_sq,
                           float max_norm, float* ema0, float ema_w0, float* ema1, float ema_w1, oniris_stream_t stream);

@@ -129,23 +129,36 @@ def test_flat_adamw_matches_torch():
 
 
 def test_flat_lazy_small_grads():
-    """lazy_small: autograd-owned gradients are gathered into the flat buffer in one call; same result as eager views."""
-    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW
+    """lazy_small: autograd-owned gradients are gathered into the flat buffer in one call, and a parameter that received
+    NO gradient (`unused`: .grad stays None) is skipped by the optimizer exactly like torch.optim.AdamW skips it -- no
+    weight decay, no moment update, no step count -- while its EMA copy still follows."""
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW, FlatEMA
     torch.manual_seed(1)
     a, b = Net(), Net()
     b.load_state_dict(a.state_dict())
-    fa, fb = FlatParams(a, lazy_small=True), FlatParams(b)
+    fa = FlatParams(a, lazy_small=True)
     assert len(fa._lazy) == len(fa.params)            # no HIP-owned conv weights in this toy net
-    oa, ob = FlatAdamW(fa, lr=1e-2), FlatAdamW(fb, lr=1e-2)
+    oa = FlatAdamW(fa, lr=1e-2, weight_decay=0.1)
+    ob = torch.optim.AdamW(list(b.parameters()), lr=1e-2, weight_decay=0.1)
+    ema = FlatEMA(fa, stds=(0.05,))
+    unused0 = a.unused.weight.detach().clone()
     for step in range(3):
         oa.zero_grad(); ob.zero_grad()
         for _ in range(2):                             # two accumulated micro-batches
             x = torch.randn(5, 6)
             a(x)[0].pow(2).mean().backward(); b(x)[0].pow(2).mean().backward()
         fa.gather()
-        assert torch.allclose(fa.grad, fb.grad, atol=1e-7)
-        oa.step(); ob.step()
-    assert torch.allclose(fa.flat, fb.flat, atol=1e-7) and fa.check()
+        for p, q in zip(a.parameters(), b.parameters()):
+            if q.grad is not None:
+                assert torch.allclose(p.grad, q.grad, atol=1e-7)
+        oa.step(ema=ema.weights(8 * (step + 1), 8)); ob.step()
+    for (k, v), (_, w) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert torch.allclose(v, w, atol=1e-6), k
+    assert torch.equal(a.unused.weight, unused0) and fa.check()
+    sd = oa.state_dict()["state"]
+    names = [n for n, _ in a.named_parameters()]
+    assert sorted(names[i] for i in sd) == ["a.bias", "a.weight", "b.bias", "b.weight"]      # torch: no state for `unused`
+    assert all(int(v["step"]) == 3 for v in sd.values())
 
 
 def test_flat_adamw_state_dict_roundtrip_with_torch():

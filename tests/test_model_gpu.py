@@ -586,3 +586,52 @@ def test_hipgraph_gradients_match_eager_after_consecutive_3d_replays():
             worst[kind] = max(worst.get(kind, 0.0), d / (tol + 1e-30))
     print("graph vs eager gradient, worst |diff| / tolerance per class:", {k: round(v, 3) for k, v in worst.items()})
     assert all(v <= 1.0 for v in worst.values()), worst
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_optimizer_skips_parameters_without_gradient(graph):
+    """torch.optim.AdamW skips a parameter whose .grad is None; gym_train.py's 2-D steps (i % 4 == 0) give no gradient
+    to the context weights / gates, nothing ever reaches out_res.* and emb_time.  FlatAdamW reproduces that per
+    parameter (step counters, untouched moments), eagerly and when forward + backward are replayed from a hipGraph."""
+    from edm2.loss import EDM2Loss
+    from edm2.conv import MPCausal3DGatedConv
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW
+    from autoregressive_diffusion_amd.graphs import GraphedStep
+    g = torch.Generator().manual_seed(79)
+    images = torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (1, 4), generator=g).to(DEV)
+    net = build_precond(SMALL_CFG, 57, 1.0).train()
+    unet = net.unet
+    flat = FlatParams(unet, lazy_small=True)
+    opt = FlatAdamW(flat, lr=1e-3, weight_decay=0.1)
+    loss_fn = EDM2Loss(sigma_data=1.0)
+
+    def fwd_bwd(j2d):
+        opt.zero_grad()
+        loss, _ = loss_fn(net, images, labels, just_2d=j2d, sync=False)
+        loss.backward()
+        return loss
+    steps = {j: (GraphedStep(lambda j=j: fwd_bwd(j), params=flat.params, flat=flat, warmup=1) if graph else (lambda j=j: fwd_bwd(j)))
+             for j in (True, False)}
+    ctx_params = [m.weight.weight for m in unet.modules() if isinstance(m, MPCausal3DGatedConv)]
+    ctx_params += [p for m in unet.modules() if isinstance(m, MPCausal3DGatedConv) for p in m.gating.parameters()]
+    never = list(unet.out_res.parameters()) + list(unet.emb_time.parameters())
+    pos = {id(p): i for i, p in enumerate(flat.params)}
+    seq = [True, True, False, True, False] if not graph else [True, True, True, False, False, False, True]
+    n2 = n3 = 0
+    for j2d in seq:
+        steps[j2d]()
+        opt.step(max_norm=0.1)
+        n2 += int(j2d); n3 += int(not j2d)
+        torch.cuda.synchronize()
+        for p in ctx_params:
+            assert opt.param_steps[pos[id(p)]] == n3, "context weights / gates step only on 3-D steps"
+            if n3 == 0:
+                assert float(flat.slice_of(opt.m, p).abs().max()) == 0.0 and float(flat.slice_of(opt.v, p).abs().max()) == 0.0
+        for p in never:
+            assert opt.param_steps[pos[id(p)]] == 0 and float(flat.slice_of(opt.v, p).abs().max()) == 0.0
+        own = unet.enc["32x32_conv"].last_frame_conv.weight.weight
+        assert opt.param_steps[pos[id(own)]] == n2 + n3
+    assert float(flat.slice_of(opt.v, ctx_params[0]).abs().max()) > 0.0
+    sd = opt.state_dict()["state"]
+    assert len(sd) == sum(1 for s_ in opt.param_steps if s_ > 0) < len(flat.params)
