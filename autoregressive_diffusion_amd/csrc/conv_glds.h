@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     if (a.epi == ONIRIS_EPI_EMB_SILU && tid < 2 * FT * BN) {     // emb-scale element [slot][frame][co] of this thread (parked in LDS later)
       const int co = cur.co0 + tid % BN, f_ = (tid / BN) % FT, s_ = tid / (FT * BN);
       if (co < a.Cout && cur.t0 + f_ < T)
-        esc_v = ((const float*)a.escale)[(size_t)((cur.b * S + s_) * T + cur.t0 + f_) * a.Cout + co];
+        esc_v = ((const float*)a.escale)[(size_t)((cur.b * S + s_) * T + cur.t0 + f_) * (a.escale_pitch ? a.escale_pitch : a.Cout) + co];
     }
     CSTAMP(1)
     if constexpr (!RES) {

@@ -421,7 +421,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
         for (int g = 0; g < 4; ++g) {
           const int co = co0 + nt * 32 + 8 * g + 4 * h;
           float4 ev = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (valid && co < a.Cout) ev = *(const float4*)((const float*)a.escale + (size_t)n * a.Cout + co);
+          if (valid && co < a.Cout) ev = *(const float4*)((const float*)a.escale + (size_t)n * (a.escale_pitch ? a.escale_pitch : a.Cout) + co);
           const float cvv[4] = {ev.x, ev.y, ev.z, ev.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {

@@ -150,7 +150,8 @@ extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, c
 // grid = (frames, pixel slices); threads: channel group = tid % G, pixel lane = tid / G
 __global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restrict__ du, const bf16* __restrict__ y,
                                                            const float* __restrict__ c, bf16* __restrict__ dy,
-                                                           float* __restrict__ dc, int P, int C, int pix_per_block) {
+                                                           float* __restrict__ dc, int P, int C, int pix_per_block,
+                                                           int c_pitch) {
   __shared__ float acc[512];
   const int n = blockIdx.x, G = C >> 3;
   const int cg = threadIdx.x % G, pl = threadIdx.x / G, npl = 256 / G;
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restric
 #pragma unroll
   for (int i = 0; i < 8; ++i) { cv[i] = 0.f; part[i] = 0.f; }
   if (pl < npl) {
-    const float4 c0 = *(const float4*)(c + (size_t)n * C + cg * 8), c1 = *(const float4*)(c + (size_t)n * C + cg * 8 + 4);
+    const float4 c0 = *(const float4*)(c + (size_t)n * c_pitch + cg * 8), c1 = *(const float4*)(c + (size_t)n * c_pitch + cg * 8 + 4);
     cv[0] = c0.x; cv[1] = c0.y; cv[2] = c0.z; cv[3] = c0.w; cv[4] = c1.x; cv[5] = c1.y; cv[6] = c1.z; cv[7] = c1.w;
     const int p0 = blockIdx.y * pix_per_block;
     const int p1 = min(P, p0 + pix_per_block);
@@ -194,7 +195,7 @@ __global__ void zero_f32_kernel(float* __restrict__ p, size_t n) {
 }
 
 extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P,
-                                   int C, oniris_stream_t stream_) {
+                                   int C, int c_pitch, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(du && y && c && dy && dc && N > 0 && P > 0 && C > 0 && C % 8 == 0 && C <= 512,
                    "emb_silu_bwd: bad arguments (C %% 8 == 0, C <= 512)");
@@ -205,8 +206,10 @@ extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c
   const int ppb = cdiv(P, slices);
   const size_t ndc = (size_t)N * C;
   hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
+  const int cp = c_pitch > 0 ? c_pitch : C;
+  ONIRIS_CHECK_ARG(cp >= C && cp % 4 == 0, "emb_silu_bwd: c_pitch must be a multiple of 4 and >= C");
   hipLaunchKernelGGL(emb_silu_bwd_kernel, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
-                     (bf16*)dy, dc, P, C, ppb);
+                     (bf16*)dy, dc, P, C, ppb, cp);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __rest
                                                               bf16* __restrict__ dres, bf16* __restrict__ dy3,
                                                               float* __restrict__ dca, float* __restrict__ dcb,
                                                               float* __restrict__ dcs, int T, int P, int C, float ta,
-                                                              float tb, float clip, int pix_per_block) {
+                                                              float tb, float clip, int pix_per_block, int cs_pitch) {
   __shared__ float red[16];
   __shared__ float accs[2][512];
   const int bt = blockIdx.x, b = bt / T, t = bt % T;
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __rest
 #pragma unroll
     for (int i = 0; i < 8; ++i) cv[s][i] = 1.f;
     if (MODE == 1 && pl < npl) {
-      const float4 c0 = *(const float4*)(cs + nn[s] * C + cg * 8), c1 = *(const float4*)(cs + nn[s] * C + cg * 8 + 4);
+      const float4 c0 = *(const float4*)(cs + nn[s] * cs_pitch + cg * 8), c1 = *(const float4*)(cs + nn[s] * cs_pitch + cg * 8 + 4);
       cv[s][0] = c0.x; cv[s][1] = c0.y; cv[s][2] = c0.z; cv[s][3] = c0.w;
       cv[s][4] = c1.x; cv[s][5] = c1.y; cv[s][6] = c1.z; cv[s][7] = c1.w;
     }
@@ -494,7 +494,8 @@ __global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __rest
 extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void* y3, const float* coef_own,
                                       const float* coef_ctx, const float* cscale, const void* xo, void* dout, void* dres,
                                       void* dy3, float* d_coef_own, float* d_coef_ctx, float* d_cscale, int B, int T,
-                                      int P, int C, float ta, float tb, float clip, oniris_stream_t stream_) {
+                                      int P, int C, float ta, float tb, float clip, int cscale_pitch,
+                                      oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG((mode == 1 || mode == 2) && g && raw && y3 && coef_own && coef_ctx && dout && dy3 && d_coef_own &&
                    d_coef_ctx && B > 0 && T > 0 && P > 0 && C % 8 == 0 && C <= 512, "gconv_bwd_fused: bad arguments");
@@ -509,14 +510,16 @@ extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, 
   const int tgt = (mode == 1) ? 512 : 2048;
   while (slices < 32 && P / (slices * 2) >= npl * 2 && (long long)B * T * slices < tgt) slices *= 2;
   const int ppb = cdiv(P, slices);
+  const int csp = cscale_pitch > 0 ? cscale_pitch : C;
+  ONIRIS_CHECK_ARG(csp >= C && csp % 4 == 0, "gconv_bwd_fused: cscale_pitch must be a multiple of 4 and >= C");
   if (mode == 1)
     hipLaunchKernelGGL(gconv_bwd_fused_kernel<1>, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)g,
                        (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
-                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb);
+                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp);
   else
     hipLaunchKernelGGL(gconv_bwd_fused_kernel<2>, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)g,
                        (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
-                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb);
+                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -451,6 +451,8 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = Cin, CinP, Cout, CoutP, taps
     a.ctx_bstride, a.ctx_T, a.coff0, a.coff1, a.ctx_fill = ctx_bstride, ctx_T, coff[0], coff[1], ctx_fill
     a.epi, a.res, a.escale, a.emb_gain, a.out2 = epi, _p(res), _p(escale), _p(emb_gain), _p(out2)
+    if escale is not None:
+        a.escale_pitch = escale.stride(0)
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
     a.big_tile = BIG_TILE
     if SPLITK and B * S * T * H * W <= 64 * 256:      # few tiles (one rollout frame): lend the split-K workspace
@@ -559,6 +561,17 @@ class ConvCfg:
         self.epi, self.ta, self.tb, self.clip, self.need_grad = epi, ta, tb, clip, need_grad
 
 
+def _rows_f32(t):
+    """(N, C) fp32 rows the kernels can read in place: unit stride inside a row, 16-byte aligned rows (a column block of
+    the UNet's one emb-scale matrix qualifies); anything else is copied."""
+    t = t.detach()
+    if t.dtype != torch.float32:
+        t = t.float()
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) % 4 != 0 or t.stride(0) < t.shape[1] or t.data_ptr() % 16 != 0:
+        t = t.contiguous()
+    return t
+
+
 class _ConvOp(torch.autograd.Function):
     """One fused conv op on channels-last bf16 activations.
 
@@ -582,7 +595,7 @@ class _ConvOp(torch.autograd.Function):
         raw = torch.empty((N, H, W, Co), dtype=BF16, device=dev)
         ret = raw
         if cfg.epi == "emb_silu":
-            cs = cscale.detach().float().contiguous()
+            cs = _rows_f32(cscale)
             assert tuple(cs.shape) == (N, Co), (cs.shape, N, Co)
             ret = torch.empty_like(raw)
             kw = dict(epi=_lib.EPI_EMB_SILU, escale=cs, out2=ret)
@@ -605,7 +618,7 @@ class _ConvOp(torch.autograd.Function):
             _conv_launch(x, None, pw2.wf, None, first_out, None, None, 1, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP,
                          pw2.taps, **kw)
         ctx.cfg = cfg
-        ctx.save_for_backward(x, raw, y3, ca32, cb32, cscale.detach().float().contiguous() if cfg.epi == "emb_silu" else None,
+        ctx.save_for_backward(x, raw, y3, ca32, cb32, kw["escale"] if cfg.epi == "emb_silu" else None,
                               ret if (cfg.epi == "mpsum" and cfg.clip > 0) else None)
         return ret
 
@@ -634,11 +647,13 @@ class _ConvOp(torch.autograd.Function):
                 dres = torch.empty_like(g)
             check(lib.oniris_gconv_bwd_fused(1 if cfg.epi == "emb_silu" else 2, _p(g), _p(raw), _p(y3), _p(ca), _p(cb),
                                              _p(cs), _p(xo), _p(dout), _p(dres), _p(dy3), _p(dca), _p(dcb), _p(dcs), B, T,
-                                             H * W, Co, cfg.ta, cfg.tb, cfg.clip, _stream()), "gconv_bwd_fused")
+                                             H * W, Co, cfg.ta, cfg.tb, cfg.clip, cs.stride(0) if cs is not None else 0,
+                                             _stream()), "gconv_bwd_fused")
         elif cfg.epi == "emb_silu":
             dout = torch.empty_like(g)
             dcs = torch.empty((N, Co), dtype=torch.float32, device=dev)
-            check(lib.oniris_emb_silu_bwd(_p(g), _p(raw), _p(cs), _p(dout), _p(dcs), N, H * W, Co, _stream()), "emb_silu_bwd")
+            check(lib.oniris_emb_silu_bwd(_p(g), _p(raw), _p(cs), _p(dout), _p(dcs), N, H * W, Co, cs.stride(0), _stream()),
+                  "emb_silu_bwd")
         elif cfg.epi == "mpsum":
             dres, dout = torch.empty_like(g), torch.empty_like(g)
             check(lib.oniris_mpsum_bwd(_p(g), _p(xo), _p(dres), _p(dout), g.numel(), cfg.ta, cfg.tb, cfg.clip, _stream()),
@@ -730,7 +745,7 @@ def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, t
         kw = dict(epi=_lib.EPI_MPSUM, res=res, ta=ta, tb=tb, clip=clip)
     elif cscale is not None:
         ret = torch.empty_like(out)
-        kw = dict(epi=_lib.EPI_EMB_SILU, escale=cscale.float().contiguous(), out2=ret)
+        kw = dict(epi=_lib.EPI_EMB_SILU, escale=_rows_f32(cscale), out2=ret)
     _conv_launch(x, ctx_frames, pw2.wf, pw3.wf, out, ca, cb, B, 1, t, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
                  ctx_bstride=ctx_T, ctx_T=ctx_T, coff=(0, 1), ctx_fill=0.0, **kw)
     return ret
@@ -818,12 +833,18 @@ def resample(x, mode):
 
 
 class _SplitCols(torch.autograd.Function):
-    """x (N, sum(sizes)) -> contiguous column blocks (one fused copy); backward = one concatenation."""
+    """x (N, sum(sizes)) -> its column blocks as VIEWS (the conv epilogue and the backward pre-pass read a block in place
+    through a row pitch: no copy per block); backward = one concatenation of the blocks' gradients."""
 
     @staticmethod
     def forward(ctx, x, sizes):
         ctx.sizes, ctx.n = tuple(sizes), x.shape[0]
-        return tuple(torch.split_with_sizes_copy(x, list(sizes), dim=1))
+        outs, o = [], 0
+        xd = x.detach()
+        for sz in sizes:
+            outs.append(xd[:, o:o + sz])
+            o += sz
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):

@@ -141,14 +141,15 @@ typedef struct OnirisConvArgs {
   float ctx_fill;
   int32_t epi;
   const void* res;        /* bf16 [B*S*T][H][W][Cout]   (EPI_MPSUM)                                               */
-  const void* escale;     /* fp32 [B*S*T][Cout]         (EPI_EMB_SILU): per-(frame, channel) multiplier           */
+  const void* escale;     /* fp32 [B*S*T][Cout] (row pitch: escale_pitch)  (EPI_EMB_SILU): per-(frame, channel) multiplier */
   const float* emb_gain;  /* reserved (unused)                                                                    */
   void* out2;             /* bf16 like out              (EPI_EMB_SILU: activation; EPI_MPSUM: optional raw output) */
   float ta, tb, clip;
   void* ctx_out;          /* optional bf16 [B*T][H][W][Cout]: the un-gated context product y3 (for d gate)        */
   int32_t big_tile;       /* variant: 0 = 4-wave register-staged kernels, 1/2 = 8-wave ones where they fill the chip /
                            * always, >= 3 = persistent LDS-DMA kernel (csrc/conv_glds.h) wherever the shape allows   */
-  int32_t pad_;
+  int32_t escale_pitch;   /* floats between consecutive rows of escale (0 = Cout): a UNet's emb-scales are column
+                           * blocks of ONE [B*S*T][sum Cout] GEMM output, read in place                            */
   /* Optional split-K workspace (caller-allocated, reusable by consecutive launches on one stream): when given and
    * the launch has <= 64 tiles (a single generated frame in the sampler, edm2/sampler.py:12-85), the
    * K = taps*Cin*(1 or 3 phases) loop of a tile is dealt to several workgroups which write fp32 partial sums here;
@@ -203,7 +204,8 @@ int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, con
 int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void* y3, const float* coef_own,
                            const float* coef_ctx, const float* cscale, const void* xo, void* dout, void* dres, void* dy3,
                            float* d_coef_own, float* d_coef_ctx, float* d_cscale, int B, int T, int P, int C, float ta,
-                           float tb, float clip, oniris_stream_t stream);
+                           float tb, float clip,
+                           int cscale_pitch /* floats between rows of cscale; 0 = C */, oniris_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused magnitude-preserving glue (HBM-bound, one pass each) -- the elementwise chains of Block.forward
@@ -220,7 +222,7 @@ int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sd
 int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
                    int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream);
 int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P, int C,
-                        oniris_stream_t stream);
+                        int c_pitch /* floats between rows of c; 0 = C */, oniris_stream_t stream);
 int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv, int64_t numel, float ta, float tb, float clip,
                      oniris_stream_t stream);
 int oniris_resample(const void* in, void* out, int64_t N, int H, int W, int C, int mode, float scale,
