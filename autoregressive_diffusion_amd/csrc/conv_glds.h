@@ -206,6 +206,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       }
     }
     const int sw = ((t.co0 * a.CinP + c0) + ((ph == 2) ? TAPS * a.CoutP * a.CinP : 0)) * 2;
+#ifdef CONV_STAMP
+    if (a.big_tile & 64) return;          // diagnostic: no weight copies at all (results are garbage): what would resident weights buy?
+#endif
     if (ph == 0) {
 #pragma unroll
       for (int i = 0; i < NIW; ++i)
@@ -322,7 +325,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
         // pipe of every SIMD sat idle for the ~1000 cycles its two waves spent on their ~10 pieces each (stamped: 30 %
         // of the kernel).  Now one wave of a SIMD feeds the matrix pipe while the other one issues.
         const bool have_next = itp + 1 < nphase;
-        const bool early = __builtin_amdgcn_readfirstlane(wave) < NW / 2;
+        const bool early = __builtin_amdgcn_readfirstlane(wave) < NW / 2 || (a.big_tile & 32);      // (bit 5: A/B knob, all waves issue at the phase top)
         if (have_next && early) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);
         auto mid = [&]() __attribute__((always_inline)) {
           if (have_next && !early) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);

@@ -26,7 +26,7 @@ def run(B, T, H, C, Cout, dgrad=False):
     else:
         a.ctx_bstride, a.ctx_T, a.coff0, a.coff1, a.ctx_fill = 2 * T, T, -2, -1, 1.0
         a.ctx_out = y3.data_ptr()
-    a.big_tile = 7 if os.environ.get("NORES") else 4
+    a.big_tile = (7 if os.environ.get("NORES") else 4) | (64 if os.environ.get("NOW") else 0)
     a.splitk_ws, a.splitk_ws_bytes = stamps.data_ptr(), 0
     for _ in range(3): check(lib.oniris_conv_fwd(ctypes.byref(a), ops._stream()), "conv")
     torch.cuda.synchronize()
