@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
     vvo[i] = (row * C + head * 64 + (pp ^ (4 * ((row >> 1) & 1))) * 8) * 2;
   }
   const i32x4 rs_k = make_rsrc((const bf16*)a.k + (size_t)b * Lk * C, Lk * C * 2);
-  const i32x4 rs_v = make_rsrc((const bf16*)a.v + (size_t)b * Lk * C, Lk * C * 2);
+  const i32x4 rs_v = make_rsrc((const bf16*)a.v + (size_t)b * (a.v_bstride ? (size_t)a.v_bstride : (size_t)Lk * C), Lk * C * 2);
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
   auto issue = [&](int key0, int bsel) __attribute__((always_inline)) {
     const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (st * 2 + bsel) * 2 * TB + qwv * 1024);
@@ -741,8 +741,10 @@ __global__ void attn_dkv_reduce_kernel(const float* __restrict__ part, bf16* __r
 // small HBM-bound helpers
 
 // qkv [tok][3C] (channel = s*C + head*64 + c) -> q,k,v [tok][C], each 64-vector normalised: x / (eps + |x|/8)
+// kv_tpb > 0: k and v go to a KV ring -- token r of batch b lands at element b * kv_bstride + (kv_off + r) * C
 __global__ void qkv_norm_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ q, bf16* __restrict__ k,
-                                bf16* __restrict__ v, long long nvec, int C) {
+                                bf16* __restrict__ v, long long nvec, int C, long long kv_tpb, long long kv_bstride,
+                                long long kv_off) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long vec = gid >> 3;
   const int part = (int)(gid & 7);
@@ -761,7 +763,9 @@ __global__ void qkv_norm_kernel(const bf16* __restrict__ qkv, bf16* __restrict__
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = f2bf(f[i] * inv);
   bf16* dst = (s == 0) ? q : (s == 1) ? k : v;
-  *(bf16x8*)(dst + tok * C + hd * 64 + part * 8) = o;
+  long long row = tok * C;
+  if (s != 0 && kv_tpb > 0) row = (tok / kv_tpb) * kv_bstride + (kv_off + tok % kv_tpb) * C;
+  *(bf16x8*)(dst + row + hd * 64 + part * 8) = o;
 }
 
 __global__ void qkv_norm_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dq,
@@ -796,11 +800,11 @@ __global__ __launch_bounds__(256) void rope_kernel(const bf16* __restrict__ x, b
                                                    bf16* __restrict__ xt, const float* __restrict__ cos_t,
                                                    const float* __restrict__ sin_t, const float* __restrict__ scale_t,
                                                    int mode, int L, int P, int C, int heads, int pos_offset,
-                                                   int pos_mod) {
+                                                   int pos_mod, long long x_bstride) {
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   const int tok0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
-  const bf16* xg = x + (size_t)b * L * C + head * 64;
+  const bf16* xg = x + (size_t)b * x_bstride + head * 64;
   {
     const int row = tid >> 2, part = tid & 3;       // 16 channels per thread
     const int tok = tok0 + row;
@@ -939,6 +943,8 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
   int rc = attn_prepare(args, d, "attn_fwd");
   if (rc) return rc;
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.out, "attn_fwd: null pointer");
+  ONIRIS_CHECK_ARG(d.a.v_bstride == 0 || (!d.a.sched && d.a.v_bstride >= (int64_t)d.a.Lk * d.a.C),
+                   "attn_fwd: v_bstride is served by the grid kernel only and must cover a sequence");
   if (d.a.sched) {                                  // persistent, statically balanced, wave-specialised kernel (attention_ws.h)
     ONIRIS_CHECK_ARG(d.a.sched_wgs > 0 && d.a.sched_slots > 0, "attn_fwd: empty schedule");
     ONIRIS_CHECK_ARG(d.a.mask_mode != 0, "attn_fwd: the scheduled kernel serves the table-driven masks");
@@ -1011,13 +1017,18 @@ extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t s
 }
 
 extern "C" int oniris_qkv_norm(const void* qkv, void* q, void* k, void* v, int64_t n_tokens, int C,
+                               int64_t kv_tokens_per_batch, int64_t kv_batch_stride, int64_t kv_token_offset,
                                oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(qkv && q && k && v && n_tokens > 0 && C > 0 && C % 64 == 0, "qkv_norm: bad arguments");
+  ONIRIS_CHECK_ARG(kv_tokens_per_batch == 0 || (kv_tokens_per_batch > 0 && n_tokens % kv_tokens_per_batch == 0 &&
+                   kv_token_offset >= 0 && kv_batch_stride >= (kv_token_offset + kv_tokens_per_batch) * C),
+                   "qkv_norm: bad KV ring description");
   const long long nvec = (long long)n_tokens * 3 * C / 64;
   const long long nthr = nvec * 8;
   hipLaunchKernelGGL(qkv_norm_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
-                     (bf16*)q, (bf16*)k, (bf16*)v, nvec, C);
+                     (bf16*)q, (bf16*)k, (bf16*)v, nvec, C, (long long)kv_tokens_per_batch, (long long)kv_batch_stride,
+                     (long long)kv_token_offset);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -1036,16 +1047,18 @@ extern "C" int oniris_qkv_norm_bwd(const void* qkv, const void* dq, const void* 
 
 extern "C" int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const float* sin_t,
                            const float* scale_t, int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod,
-                           oniris_stream_t stream_) {
+                           int64_t x_batch_stride, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(x && (xr || xt) && B > 0 && frames > 0 && P > 0 && C % 64 == 0 && mode >= 0 && mode <= 4,
                    "rope: bad arguments");
   ONIRIS_CHECK_ARG(mode == 0 || (cos_t && sin_t && scale_t && pos_mod > 0), "rope: tables missing");
   const int L = frames * P;
   ONIRIS_CHECK_ARG(L % 8 == 0, "rope: frames*P must be a multiple of 8");
+  ONIRIS_CHECK_ARG(x_batch_stride == 0 || x_batch_stride >= (int64_t)L * C, "rope: batch stride smaller than a sequence");
   const dim3 grid(cdiv(L, 64), C / 64, B);
   hipLaunchKernelGGL(rope_kernel, grid, dim3(256), 0, stream, (const bf16*)x, (bf16*)xr, (bf16*)xt, cos_t, sin_t,
-                     scale_t, mode, L, P, C, C / 64, pos_offset, pos_mod > 0 ? pos_mod : 1);
+                     scale_t, mode, L, P, C, C / 64, pos_offset, pos_mod > 0 ? pos_mod : 1,
+                     (long long)(x_batch_stride > 0 ? x_batch_stride : (int64_t)L * C));
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -1058,6 +1071,6 @@ extern "C" int oniris_attn_bwd_prep(const void* dout, const void* out, float* de
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)dout, (const bf16*)out, delta, nvec, L, C, heads);
   ONIRIS_LAUNCH_CHECK();
-  if (doutt) return oniris_rope(dout, nullptr, doutt, nullptr, nullptr, nullptr, 0, B, L, 1, C, 0, 1, stream_);
+  if (doutt) return oniris_rope(dout, nullptr, doutt, nullptr, nullptr, nullptr, 0, B, L, 1, C, 0, 1, 0, stream_);
   return ONIRIS_OK;
 }

@@ -278,8 +278,13 @@ class UNet(BetterModule):
                 kv = (cache.get((side, name)) or {}).get("attn") if isinstance(block, Block) else None
                 if att is None or kv is None or not hasattr(att, "rope") or "_tokens_per_frame" not in att.__dict__:
                     continue
-                nk = kv[0].shape[1] // att.__dict__["_tokens_per_frame"] + 1
+                P = att.__dict__["_tokens_per_frame"]
+                nk = kv[0].shape[1] // P + 1
                 ops.rope_tables(att.rope.inv_freq, att.rope.scale, nk, dev)
+                # room for the next frame in the layer's KV ring (grown here, never inside a capture)
+                ring = ops.KVRing.of(kv, kv[0].shape[0], P, kv[0].shape[2], 1, dev)
+                if ring is not getattr(kv[0], "_oniris_ring", None):
+                    cache[(side, name)]["attn"] = ring.views()
 
     def _gate_layers(self, cache):
         convs, caches = [], []

@@ -914,10 +914,10 @@ def rope_tables(inv_freq, scale_vec, n_pos, device, scale_base=64):
     return _rope_cache[key]
 
 
-def _rope(x, xr, xt, tabs, mode, B, frames, P, C, pos_offset, pos_mod):
+def _rope(x, xr, xt, tabs, mode, B, frames, P, C, pos_offset, pos_mod, x_bstride=0):
     cs, sn, sc = tabs if tabs is not None else (None, None, None)
     check(lib.oniris_rope(_p(x), _p(xr), _p(xt), _p(cs), _p(sn), _p(sc), mode, B, frames, P, C, pos_offset, pos_mod,
-                          _stream()), "rope")
+                          x_bstride, _stream()), "rope")
 
 
 def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mode, P, T):
@@ -958,7 +958,7 @@ class _AttentionFn(torch.autograd.Function):
         dev = qkv.device
         q = torch.empty((N, P, C), dtype=BF16, device=dev)
         k, v = torch.empty_like(q), torch.empty_like(q)
-        check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, _stream()), "qkv_norm")
+        check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, 0, 0, 0, _stream()), "qkv_norm")
         if kind == "video":
             frames = N // B
             Bq, L = B, frames * P
@@ -1033,6 +1033,45 @@ def attention_train(qkv, kind, B, T, heads, rope_bufs=None):
     return _AttentionFn.apply(qkv, kind, B, T, heads, rope_bufs, torch.is_grad_enabled())
 
 
+class KVRing:
+    """Preallocated K / V storage of one VideoAttention layer during a rollout: [B][cap frames * P][C]
+    bf16 each, `n` committed frames.  The cache entry the modules hand around stays the reference's (K, V) pair of
+    (B, n*P, C) tensors -- they are VIEWS of the ring (`K._oniris_ring`), so nothing is concatenated or copied per
+    evaluation: the qkv kernel writes the new frames' k, v straight behind the committed ones (an evaluation with
+    update_cache=False leaves them uncommitted: the next one overwrites them), RoPE reads the ring through a batch
+    stride, the decode kernel reads V in place.  Appending in place is only done for the cache that owns the ring's
+    latest state; a continuation from an older (K, V) pair -- two futures from one cache -- gets a ring of its own."""
+
+    def __init__(self, B, P, C, cap, device):
+        self.B, self.P, self.C, self.cap, self.n = B, P, C, cap, 0
+        self.K = torch.empty((B, cap * P, C), dtype=BF16, device=device)
+        self.V = torch.empty((B, cap * P, C), dtype=BF16, device=device)
+
+    def views(self):
+        k, v = self.K[:, :self.n * self.P], self.V[:, :self.n * self.P]
+        k._oniris_ring = self
+        k._oniris_n = self.n
+        return k, v
+
+    @staticmethod
+    def of(kv_cache, B, P, C, t_new, device, grow=True):
+        """The ring that holds kv_cache (None: empty) with room for t_new more frames -- the cache's own ring when it is
+        its latest state and large enough, else a new one (the old frames are copied once)."""
+        n = 0 if kv_cache is None else kv_cache[0].shape[1] // P
+        ring = getattr(kv_cache[0], "_oniris_ring", None) if kv_cache is not None else None
+        if (ring is not None and ring.n == n and getattr(kv_cache[0], "_oniris_n", -1) == n and ring.cap >= n + t_new
+                and ring.B == B and ring.P == P and ring.C == C):
+            return ring
+        if not grow:
+            return None
+        new = KVRing(B, P, C, max(16, 2 * (n + t_new)), device)
+        if n:
+            new.K[:, :n * P].copy_(kv_cache[0])
+            new.V[:, :n * P].copy_(kv_cache[1])
+        new.n = n
+        return new
+
+
 @torch.no_grad()
 def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     """Eval-mode VideoAttention core (attention_modules.py:51-77): qkv (B*t, P, 3C) of the NEW frames.
@@ -1041,20 +1080,23 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     C = C3 // 3
     dev = qkv.device
     t = N // B
+    ring = KVRing.of(kv_cache, B, P, C, t, dev)
+    n = ring.n
     q = torch.empty((N, P, C), dtype=BF16, device=dev)
-    k, v = torch.empty_like(q), torch.empty_like(q)
-    check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, _stream()), "qkv_norm")
-    k, v = k.reshape(B, t * P, C), v.reshape(B, t * P, C)
-    if kv_cache is not None:
-        k = torch.cat([kv_cache[0], k], dim=1)
-        v = torch.cat([kv_cache[1], v], dim=1)
-    new_cache = (k, v) if update_cache else kv_cache
-    nk = k.shape[1] // P
+    bstride = ring.cap * P * C
+    check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(ring.K), _p(ring.V), N * P, C, t * P, bstride, n * P, _stream()), "qkv_norm")
+    nk = n + t
+    if update_cache:
+        ring.n = nk
+        new_cache = ring.views()
+    else:
+        new_cache = kv_cache
     Lq, Lk = t * P, nk * P
     tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], nk, dev)
-    qr, kr = torch.empty_like(q), torch.empty_like(k)
+    qr = torch.empty_like(q)
+    kr = torch.empty((B, Lk, C), dtype=BF16, device=dev)
     _rope(q, qr, None, tabs_r, 1, B, t, P, C, nk - t, nk)
-    _rope(k, kr, None, tabs_r, 2, B, nk, P, C, 0, nk)
+    _rope(ring.K, kr, None, tabs_r, 2, B, nk, P, C, 0, nk, x_bstride=bstride)
     out = torch.empty((N, P, C), dtype=BF16, device=dev)
     if t == 1:
         mask_mode, tabs = 0, None                               # one new frame: dense SDPA over all keys (:69-70)
@@ -1063,7 +1105,8 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
         tabs = device_tables("infer", t, P, dev)
     else:
         raise NotImplementedError("The inference mask is not implemented for this case")
-    a = _attn_args(qr, kr, v.contiguous(), None, None, None, out, None, tabs, B, heads, Lq, Lk, C, mask_mode, P, 0)
+    a = _attn_args(qr, kr, ring.V, None, None, None, out, None, tabs, B, heads, Lq, Lk, C, mask_mode, P, 0)
+    a.v_bstride = bstride
     check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
     return out, new_cache
 

@@ -240,11 +240,16 @@ int oniris_resample(const void* in, void* out, int64_t N, int H, int W, int C, i
  * [B][heads][64][L] (the k-contiguous operand layout of the PV / dK / dQ MFMA products).  mode 0: copy only.
  * mode 3/4: adjoint of mode 1/2 (backward).
  */
-int oniris_qkv_norm(const void* qkv, void* q, void* k, void* v, int64_t n_tokens, int C, oniris_stream_t stream);
+/* kv_tokens_per_batch > 0: k and v are written into a KV ring (edm2/sampler.py rollout): token r of batch b goes to
+ * element b * kv_batch_stride + (kv_token_offset + r) * C of k / v; 0: dense [n_tokens][C] like q.                 */
+int oniris_qkv_norm(const void* qkv, void* q, void* k, void* v, int64_t n_tokens, int C, int64_t kv_tokens_per_batch,
+                    int64_t kv_batch_stride, int64_t kv_token_offset, oniris_stream_t stream);
 int oniris_qkv_norm_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv,
                         int64_t n_tokens, int C, oniris_stream_t stream);
 int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const float* sin_t, const float* scale_t,
-                int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod, oniris_stream_t stream);
+                int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod,
+                int64_t x_batch_stride /* elements between the sequences of x (KV ring); 0 = frames*P*C */,
+                oniris_stream_t stream);
 
 /* Block-sparse flash attention forward (replaces compiled_flex_attention / F.scaled_dot_product_attention,
  * attention_modules.py:41,66,70,75,115).  q [B][Lq][C], k,v [B][Lk][C] bf16 (head h = channels 64h..64h+63),
@@ -281,6 +286,7 @@ typedef struct OnirisAttnArgs {
    * entry = (pair << 16) | block with pair = b * heads + head, or -1.  NULL: one workgroup per block (grid kernels).   */
   const int32_t* sched;
   int32_t sched_wgs, sched_slots;
+  int64_t v_bstride;                      /* elements between the sequences of v (a KV ring); 0 = Lk*C (forward only) */
 } OnirisAttnArgs;
 
 /* Static load balancing of block-sparse attention [host]: n_pairs (batch, head) pairs x n_blocks work items per pair

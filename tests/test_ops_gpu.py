@@ -378,6 +378,28 @@ def test_attention_eval_prefill_and_decode():
         print("attention_eval t0 =", t0, e)
         assert e[0] < 1e-2 and e[1] < 1e-2
         assert c2[0].shape[1] == (t0 + 1) * P
+    # KV ring semantics (ops.KVRing): the cache pair is a view of preallocated storage -- an evaluation that does not
+    # update the cache leaves it untouched, and two continuations of ONE cache (two futures) do not see each other
+    a0 = bfr(torch.randn(B * 4, 3 * C, H, H))
+    _, c4 = hip(a0, 4, None, True)
+    k4 = c4[0].float().clone()
+    assert getattr(c4[0], "_oniris_ring", None) is not None and c4[0]._oniris_ring.cap >= 5
+    fa, fb = bfr(torch.randn(B, 3 * C, H, H)), bfr(torch.randn(B, 3 * C, H, H))
+    o_a0, c_same = hip(fa, 1, c4, False)                       # (writes the ring's uncommitted slot)
+    assert c_same is c4 and torch.equal(c4[0].float(), k4)
+    o_a, ca = hip(fa, 1, c4, True)
+    assert torch.equal(o_a, o_a0) and ca[0].data_ptr() == c4[0].data_ptr()            # appended in place
+    ka = ca[0].float().clone()
+    o_b, cb = hip(fb, 1, c4, True)                             # a second future from the OLD cache: a ring of its own
+    assert cb[0].data_ptr() != ca[0].data_ptr()
+    assert torch.equal(ca[0].float(), ka) and torch.equal(cb[0][:, :4 * P].float(), k4)
+    assert not torch.equal(cb[0][:, 4 * P:].float(), ka[:, 4 * P:])
+    r_b, _ = ref(fb, 1, ref(a0, 4, None, True)[1], True)
+    assert rel(o_b, r_b) < 1e-2
+    c = ca
+    for _ in range(14):                                        # grow past the first capacity (16 frames)
+        _, c = hip(bfr(torch.randn(B, 3 * C, H, H)), 1, c, True)
+    assert c[0].shape[1] == 19 * P and torch.equal(c[0][:, :5 * P].float(), ka)
 
 
 def test_adamw():
