@@ -105,6 +105,9 @@ _SIGS = {
     "oniris_resample": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "oniris_qkv_norm": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int64, c_void_p]),
     "oniris_qkv_norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "oniris_precond_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                   c_void_p]),
+    "oniris_gates": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "oniris_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_int64, c_void_p]),
     "oniris_attn_fwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),

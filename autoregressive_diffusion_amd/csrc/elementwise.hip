@@ -320,13 +320,17 @@ __global__ __launch_bounds__(256) void dart_input_kernel(const float* __restrict
   const float sg = sigma[b * S * T + st];
   const float cin = 1.f / sqrtf(sd * sd + sg * sg);
   const float* ip = img + (size_t)(b * T + t) * C * HW;
-  const float* np_ = noise + (size_t)(b * S * T + st) * C * HW;
+  const bool has_noise = noise != nullptr;        // NULL: no noise term (Precond's input side in eval)
+  const float* np_ = has_noise ? noise + (size_t)(b * S * T + st) * C * HW : ip;      // (aliases ip: never a null load)
   for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
     bf16 o[16];
 #pragma unroll
     for (int c = 0; c < 16; ++c) {
       float v = 0.f;
-      if (c < C) v = cin * __fadd_rn(ip[(size_t)c * HW + p], __fmul_rn(sg, np_[(size_t)c * HW + p]));
+      if (c < C) {
+        const float xi = ip[(size_t)c * HW + p];
+        v = has_noise ? cin * __fadd_rn(xi, __fmul_rn(sg, np_[(size_t)c * HW + p])) : cin * xi;
+      }
       else if (c == C) v = 1.f;
       o[c] = f2bf(v);
     }
@@ -386,7 +390,7 @@ __global__ __launch_bounds__(256) void dart_loss_kernel(const bf16* __restrict__
 extern "C" int oniris_dart_input(const float* images, const float* noise, const float* sigma, void* xcl, int B, int S,
                                  int T, int C, int H, int W, float sigma_data, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ONIRIS_CHECK_ARG(images && noise && sigma && xcl && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 && C < 16 && H > 0 && W > 0,
+  ONIRIS_CHECK_ARG(images && sigma && xcl && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 && C < 16 && H > 0 && W > 0,
                    "dart_input: bad arguments");
   const int HW = H * W;
   int gx = cdiv(HW, 256);
@@ -417,6 +421,70 @@ extern "C" int oniris_dart_loss_bwd(const void* F, const float* images, const fl
                    T > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "dart_loss_bwd: bad arguments");
   hipLaunchKernelGGL(dart_loss_kernel<true>, dim3(B * S * T), dim3(256), 0, stream, (const bf16*)F, images, noise, sigma,
                      out_gain, dlosses, (float*)nullptr, (bf16*)dF, dgain_part, S, T, C, H * W, sigma_data);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Precond.forward's output side in eval (networks_edm2.py:293-297): D = c_skip * x + c_out * out_gain * F, with F the raw
+// channels-last bf16 UNet output [N][HW][8] and x, D fp32 [N][C][HW] (one block column per frame)
+__global__ __launch_bounds__(256) void precond_out_kernel(const bf16* __restrict__ F, const float* __restrict__ x,
+                                                          const float* __restrict__ sigma, const float* __restrict__ out_gain,
+                                                          float* __restrict__ D, int C, int HW, float sd) {
+  const int n = blockIdx.y;
+  const float sg = sigma[n], og = out_gain[0];
+  const float den = sg * sg + sd * sd;
+  const float cskip = sd * sd / den, cout = sg * sd / sqrtf(den) * og;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+    const bf16x8 f = *(const bf16x8*)(F + ((size_t)n * HW + p) * 8);
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (c < C) {
+        const size_t o = ((size_t)n * C + c) * HW + p;
+        D[o] = cskip * x[o] + cout * bf2f(f[c]);
+      }
+  }
+}
+
+extern "C" int oniris_precond_out(const void* F, const float* x, const float* sigma, const float* out_gain, float* D,
+                                  int N, int C, int H, int W, float sigma_data, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(F && x && sigma && out_gain && D && N > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "precond_out: bad arguments");
+  int gx = cdiv(H * W, 256);
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(precond_out_kernel, dim3(gx, N), dim3(256), 0, stream, (const bf16*)F, x, sigma, out_gain, D, C, H * W,
+                     sigma_data);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// All Gating modules of a net in one launch (edm2/conv.py:113-127, eval): for layer l and frame slot n
+//   g = lo + (1 - lo) * hi * sigmoid(c_noise[n] * mult0 + off0 + log1p(n % T + nctx[l]) * mult1 + off1),
+//   lo = sigmoid(min_gating), hi = sigmoid(max_gating);   ca = (1 - g) / sqrt((1 - g)^2 + g^2),  cb = g / sqrt(...)
+// params [L][6] = mult0, mult1, off0, off1, min_gating, max_gating.  (Training keeps the torch autograd formulation.)
+__global__ void gates_kernel(const float* __restrict__ c_noise, const float* __restrict__ params,
+                             const int* __restrict__ nctx, float* __restrict__ ca, float* __restrict__ cb, int N, int T) {
+  const int l = blockIdx.y;
+  const float* p = params + l * 6;
+  const float lo = 1.f / (1.f + expf(-p[4])), hi = 1.f / (1.f + expf(-p[5]));
+  const float nc = nctx ? (float)nctx[l] : 0.f;
+  for (int n = blockIdx.x * blockDim.x + threadIdx.x; n < N; n += gridDim.x * blockDim.x) {
+    const float pos = log1pf((float)(n % T) + nc);
+    const float sv = c_noise[n] * p[0] + p[2] + pos * p[1] + p[3];
+    const float g = lo + (1.f - lo) * hi * (1.f / (1.f + expf(-sv)));
+    const float r = rsqrtf((1.f - g) * (1.f - g) + g * g);
+    ca[(size_t)l * N + n] = (1.f - g) * r;
+    cb[(size_t)l * N + n] = g * r;
+  }
+}
+
+extern "C" int oniris_gates(const float* c_noise, const float* params, const int32_t* nctx, float* ca, float* cb, int L,
+                            int N, int T, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(c_noise && params && ca && cb && L > 0 && N > 0 && T > 0, "gates: bad arguments");
+  hipLaunchKernelGGL(gates_kernel, dim3(cdiv(N, 256) > 64 ? 64 : cdiv(N, 256), L), dim3(256), 0, stream, c_noise, params,
+                     (const int*)nctx, ca, cb, N, T);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -123,6 +123,38 @@ def nctx_tensor(n_ctx, dev):
     return _nctx_cache[key]
 
 
+_gate_param_cache = {}
+
+
+def _packed_gate_params(convs, dev):
+    """(L, 6) fp32 = mult0, mult1, off0, off1, min_gating, max_gating of every gating layer; cached until a parameter
+    changes (torch writes bump ._version; the raw-pointer optimizer bumps ops._weights_epoch)."""
+    ps = [p for m in convs for p in (m.gating.mult, m.gating.offset, m.gating.min_gating, m.gating.max_gating)]
+    key = (id(convs[0]), len(convs), str(dev))
+    sig = (ops._weights_epoch, tuple(p._version for p in ps), tuple(p.data_ptr() for p in ps))
+    hit = _gate_param_cache.get(key)
+    if hit is None or hit[0] != sig:
+        with torch.no_grad():
+            packed = torch.stack([torch.cat([m.gating.mult.reshape(2), m.gating.offset.reshape(2), m.gating.min_gating.reshape(1),
+                                             m.gating.max_gating.reshape(1)]) for m in convs]).float().contiguous().to(dev)
+        if len(_gate_param_cache) > 16:
+            _gate_param_cache.clear()
+        hit = _gate_param_cache[key] = (sig, packed)
+    return hit[1]
+
+
+_nctx_i32_cache = {}
+
+
+def _nctx_i32(n_ctx, dev):
+    key = (tuple(n_ctx), str(dev))
+    if key not in _nctx_i32_cache:
+        if len(_nctx_i32_cache) > 64:
+            _nctx_i32_cache.clear()
+        _nctx_i32_cache[key] = torch.tensor(list(n_ctx), dtype=torch.int32, device=dev)
+    return _nctx_i32_cache[key]
+
+
 def batched_gates(convs, c_noise, caches, training):
     """All Gating modules of a net in ONE vectorised evaluation (identical math to Gating.forward, conv.py:113-127):
     replaces ~60 x 20 tiny elementwise launches per step by ~20.  Returns per-layer (ca, cb, n_new)."""
@@ -130,6 +162,12 @@ def batched_gates(convs, c_noise, caches, training):
     T = tt // 2 if training else tt
     dev = c_noise.device
     n_ctx = [int(c.get("n_context_frames", 0)) if c else 0 for c in caches]
+    if not training and not torch.is_grad_enabled() and c_noise.is_cuda:
+        # eval: one HIP launch (oniris_gates) instead of ~20 torch ones; the packed gating parameters are rebuilt only
+        # when a parameter changed, the frame counters are the cached device vector of nctx_tensor
+        params = _packed_gate_params(convs, dev)
+        ca, cb = ops.gates_eval(c_noise.float().contiguous(), params, _nctx_i32(n_ctx, dev) if any(n_ctx) else None, T)
+        return [(a, b, n + T) for a, b, n in zip(ca.unbind(0), cb.unbind(0), n_ctx)]
     mult = torch.stack([m.gating.mult for m in convs])            # (L,2)
     off = torch.stack([m.gating.offset for m in convs])           # (L,2)
     lo = torch.sigmoid(torch.stack([m.gating.min_gating for m in convs]))[:, None, None]

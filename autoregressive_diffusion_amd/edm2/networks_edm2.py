@@ -266,12 +266,14 @@ class UNet(BetterModule):
         """Build, OUTSIDE any hipGraph capture, the small per-frame-count device tables the next cached one-frame
         evaluation will ask for (RoPE tables for the grown key length, the gates' frame-counter vector): they are
         host->device uploads and must not happen inside a capture (edm2/sampler.py _GraphedDenoiser)."""
-        from .conv import nctx_tensor
+        from .conv import nctx_tensor, _nctx_i32, _packed_gate_params
         dev = self.out_gain.device
         convs, caches = self._gate_layers(cache)
         n_ctx = [int(c.get("n_context_frames", 0)) if c else 0 for c in caches]
         if any(n_ctx):
             nctx_tensor(n_ctx, dev)
+            _nctx_i32(n_ctx, dev)
+        _packed_gate_params(convs, dev)
         for side, blocks in (("enc", self.enc), ("dec", self.dec)):
             for name, block in blocks.items():
                 att = getattr(block, "attn", None)
@@ -354,6 +356,16 @@ class Precond(BetterModule):
             cache = {}
         cache["shape"] = x.shape
         x = x.to(torch.float32)
+        if (not torch.is_grad_enabled() and x.is_cuda and x.is_contiguous() and x.shape[2] <= 8 and sigma.shape == x.shape[:2]
+                and getattr(self.unet, "_oniris_cl_io", False) and getattr(self.unet, "img_channels", -1) == x.shape[2]):
+            # eval (the sampler's 31 evaluations per frame): the sigma-preconditioning around the UNet as two HIP passes
+            # instead of ~25 tiny torch launches -- c_in * x packed channels-last with the ones channel, and
+            # D = c_skip * x + c_out * out_gain * F read straight from the raw channels-last output
+            sg = sigma.to(torch.float32).contiguous()
+            xcl = ops.dart_input(x, None, sg, 1, self.sigma_data)
+            Fcl, cache = self.unet.forward(xcl, sg.log() / 4, conditioning, cache, update_cache, just_2d,
+                                           _cl_io=tuple(x.shape[:2]))
+            return ops.precond_out(Fcl, x, sg, self.unet.out_gain, self.sigma_data), cache
         sigma = sigma.to(torch.float32)[:, :, None, None, None]
         sd = self.sigma_data
         c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)

@@ -1117,12 +1117,36 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
 def dart_input(images, noise, sigma, S, sigma_data):
     """Packed UNet input of a DART training step (oniris_dart_input): images (B,T,C,H,W), noise (B,S*T,C,H,W), sigma
     (B,S*T) fp32 -> (B*S*T, H, W, 16) bf16 = c_in * (images + sigma*noise) with the ones channel."""
-    _need_gpu(images, noise, sigma)
+    _need_gpu(images, noise, sigma)                 # (noise None: c_in * images, Precond's input side in eval)
     B, T, C, H, W = images.shape
     xcl = torch.empty((B * S * T, H, W, 16), dtype=BF16, device=images.device)
     check(lib.oniris_dart_input(_p(images), _p(noise), _p(sigma), _p(xcl), B, S, T, C, H, W, float(sigma_data), _stream()),
           "dart_input")
     return xcl
+
+
+@torch.no_grad()
+def precond_out(F, x, sigma, out_gain, sigma_data):
+    """D = c_skip * x + c_out * out_gain * F (Precond.forward's output side, eval): F (N,H,W,8) bf16 raw UNet output,
+    x (B,t,C,H,W) fp32, sigma (B,t) -> D like x."""
+    _need_gpu(F, x, sigma)
+    B, t, C, H, W = x.shape
+    assert F.dtype == BF16 and F.shape == (B * t, H, W, 8) and F.is_contiguous() and x.dtype == torch.float32 and x.is_contiguous()
+    D = torch.empty_like(x)
+    og = out_gain.detach().float().reshape(1)
+    check(lib.oniris_precond_out(_p(F), _p(x), _p(sigma.float().contiguous()), _p(og), _p(D), B * t, C, H, W,
+                                 float(sigma_data), _stream()), "precond_out")
+    return D
+
+
+@torch.no_grad()
+def gates_eval(c_noise, params, nctx, T):
+    """(ca, cb) [L][N] for all gating layers in one launch (oniris_gates); params (L,6) fp32, nctx (L,) int32 or None."""
+    _need_gpu(c_noise, params)
+    L, N = params.shape[0], c_noise.numel()
+    out = torch.empty((2, L, N), dtype=torch.float32, device=c_noise.device)
+    check(lib.oniris_gates(_p(c_noise), _p(params), _p(nctx), _p(out[0]), _p(out[1]), L, N, T, _stream()), "gates")
+    return out[0], out[1]
 
 
 class _DartLoss(torch.autograd.Function):

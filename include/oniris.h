@@ -92,6 +92,18 @@ int oniris_dart_loss_bwd(const void* F, const float* images, const float* noise,
                          const float* out_gain, const float* dlosses, void* dF, float* dgain_part, int B, int S, int T,
                          int C, int H, int W, float sigma_data, oniris_stream_t stream);
 
+/* Eval-side counterparts (edm2/sampler.py: 31 evaluations per generated frame, every launch counts):
+ * oniris_dart_input with noise == NULL packs c_in * x (Precond.forward's input side, networks_edm2.py:287-291);
+ * oniris_precond_out: D [N][C][H][W] fp32 = c_skip * x + c_out * out_gain * F  (F = raw channels-last UNet output
+ *   [N][H][W][8] bf16, x fp32 like D, sigma [N]; networks_edm2.py:293-297);
+ * oniris_gates: every Gating module of a net in one launch (edm2/conv.py:113-127): params [L][6] = mult0, mult1, off0,
+ *   off1, min_gating, max_gating; nctx [L] frame counters (NULL = 0); c_noise [N]; position of slot n = n % T;
+ *   outputs the gate coefficients ca, cb [L][N] of mp_sum(y2, y3, g) (utils.py:118-123).                              */
+int oniris_precond_out(const void* F, const float* x, const float* sigma, const float* out_gain, float* D, int N, int C,
+                       int H, int W, float sigma_data, oniris_stream_t stream);
+int oniris_gates(const float* c_noise, const float* params, const int32_t* nctx, float* ca, float* cb, int L, int N, int T,
+                 oniris_stream_t stream);
+
 /* Fused AdamW over flat fp32 buffers (the optimizer step of gym_train.py:105-106 / cs_train.py:117-118).       */
 int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream);
