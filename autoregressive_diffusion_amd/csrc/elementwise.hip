@@ -488,3 +488,52 @@ extern "C" int oniris_gates(const float* c_noise, const float* params, const int
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The UNet's embedding in eval (networks_edm2.py:204-216) in one launch, fp32 throughout:
+//   f = sqrt(2) * cos(c_noise[n] * freqs + phases)                              (MPFourier, utils.py:139-150)
+//   e = What_noise . f,   What = w / (eps + |w_row| / sqrt(fan)) / sqrt(fan)    (MPConv in eval, conv.py:14-21,36-42)
+//   with labels: e = mp_sum(e, What_label[:, label[n]] * sqrt(L), t = 1/3)      (one-hot input)
+//   emb[n] = silu(e) / 0.596  -> bf16 [N][cemb]
+// One block per frame slot; a thread owns output channels co = tid, tid + 256, ...
+__global__ __launch_bounds__(256) void embed_eval_kernel(const float* __restrict__ c_noise, const long long* __restrict__ labels,
+                                                         const float* __restrict__ freqs, const float* __restrict__ phases,
+                                                         const float* __restrict__ w_noise, const float* __restrict__ w_label,
+                                                         bf16* __restrict__ emb, int cn, int cemb, int L) {
+  __shared__ float four[512];
+  const int n = blockIdx.x;
+  const float x = c_noise[n];
+  for (int i = threadIdx.x; i < cn; i += 256) four[i] = 1.4142135623730951f * cosf(x * freqs[i] + phases[i]);
+  __syncthreads();
+  const long long lab = (labels && w_label) ? labels[n] : -1;
+  for (int co = threadIdx.x; co < cemb; co += 256) {
+    const float* wr = w_noise + (size_t)co * cn;
+    float dot = 0.f, ss = 0.f;
+    for (int i = 0; i < cn; ++i) { const float w = wr[i]; dot += w * four[i]; ss += w * w; }
+    const float rs = rsqrtf((float)cn);
+    float e = dot * rs / (1e-4f + sqrtf(ss) * rs);
+    if (lab >= 0 && lab < L) {
+      const float* wl = w_label + (size_t)co * L;
+      float sl = 0.f;
+      for (int i = 0; i < L; ++i) sl += wl[i] * wl[i];
+      const float rl = rsqrtf((float)L);
+      const float el = wl[lab] * sqrtf((float)L) * rl / (1e-4f + sqrtf(sl) * rl);
+      const float t = 1.f / 3.f;
+      e = (e + (el - e) * t) * rsqrtf((1.f - t) * (1.f - t) + t * t);
+    }
+    emb[(size_t)n * cemb + co] = f2bf(e * sigmoid_fast(e) * (1.f / 0.596f));
+  }
+}
+
+extern "C" int oniris_embed_eval(const float* c_noise, const int64_t* labels, const float* freqs, const float* phases,
+                                 const float* w_noise, const float* w_label, void* emb, int N, int cnoise, int cemb,
+                                 int label_dim, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(c_noise && freqs && phases && w_noise && emb && N > 0 && cnoise > 0 && cnoise <= 512 && cemb > 0,
+                   "embed_eval: bad arguments (cnoise <= 512)");
+  ONIRIS_CHECK_ARG(!labels || !w_label || label_dim > 0, "embed_eval: label_dim missing");
+  hipLaunchKernelGGL(embed_eval_kernel, dim3(N), dim3(256), 0, stream, c_noise, (const long long*)labels, freqs, phases,
+                     w_noise, w_label, (bf16*)emb, cnoise, cemb, label_dim);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}

@@ -1140,6 +1140,19 @@ def precond_out(F, x, sigma, out_gain, sigma_data):
 
 
 @torch.no_grad()
+def embed_eval(c_noise, labels, fourier, w_noise, w_label, label_dim):
+    """(N, 1, 1, cemb) bf16 embedding of the UNet in eval, one launch (oniris_embed_eval)."""
+    _need_gpu(c_noise, w_noise)
+    N, (cemb, cn) = c_noise.numel(), w_noise.shape
+    emb = torch.empty((N, 1, 1, cemb), dtype=BF16, device=c_noise.device)
+    lab = labels.reshape(-1).to(torch.int64).contiguous() if (labels is not None and w_label is not None) else None
+    check(lib.oniris_embed_eval(_p(c_noise), _p(lab), _p(fourier.freqs.float()), _p(fourier.phases.float()), _p(w_noise),
+                                _p(w_label if lab is not None else None), _p(emb), N, cn, cemb, int(label_dim), _stream()),
+          "embed_eval")
+    return emb
+
+
+@torch.no_grad()
 def gates_eval(c_noise, params, nctx, T):
     """(ca, cb) [L][N] for all gating layers in one launch (oniris_gates); params (L,6) fp32, nctx (L,) int32 or None."""
     _need_gpu(c_noise, params)

@@ -101,6 +101,12 @@ int oniris_dart_loss_bwd(const void* F, const float* images, const float* noise,
  *   outputs the gate coefficients ca, cb [L][N] of mp_sum(y2, y3, g) (utils.py:118-123).                              */
 int oniris_precond_out(const void* F, const float* x, const float* sigma, const float* out_gain, float* D, int N, int C,
                        int H, int W, float sigma_data, oniris_stream_t stream);
+ /* oniris_embed_eval: the UNet's noise / label embedding (networks_edm2.py:204-216) in one fp32 launch: emb [N][cemb] bf16
+ *   = mp_silu(mp_sum(MPConv_noise(MPFourier(c_noise)), MPConv_label(onehot(labels) * sqrt(L)), 1/3)); w_noise [cemb][cnoise],
+ *   w_label [cemb][L] are the RAW fp32 parameters (normalised per row inside); labels / w_label NULL: no label term.      */
+int oniris_embed_eval(const float* c_noise, const int64_t* labels, const float* freqs, const float* phases,
+                      const float* w_noise, const float* w_label, void* emb, int N, int cnoise, int cemb, int label_dim,
+                      oniris_stream_t stream);
 int oniris_gates(const float* c_noise, const float* params, const int32_t* nctx, float* ca, float* cb, int L, int N, int T,
                  oniris_stream_t stream);
 

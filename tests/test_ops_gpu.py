@@ -529,3 +529,61 @@ def test_conv_epilogues(gated, H):
         print("conv epilogue", epi, "gated" if gated else "plain", e)
         assert e["y"] < 1e-2 and e["dx"] < 1.5e-2 and e["dw2"] < 2e-2
         assert all(v_ < 3e-2 for v_ in e.values()), e
+
+
+def test_eval_side_kernels_match_torch_formulation():
+    """oniris_gates / oniris_embed_eval / oniris_precond_out (+ oniris_dart_input without noise) against the torch
+    formulation of the same reference lines (conv.py:113-127, networks_edm2.py:204-216, :278-297)."""
+    from autoregressive_diffusion_amd import ops
+    from edm2.conv import Gating
+    from edm2.utils import MPFourier, mp_sum, mp_silu
+    torch.manual_seed(11)
+    # gates: 5 layers, B = 2, t = 3, frame counters 0 / 7
+    B, t, L = 2, 3, 5
+    gs = [Gating().to(DEV) for _ in range(L)]
+    for g_ in gs:
+        for p in g_.parameters():
+            p.data.add_(torch.randn_like(p) * 0.5)
+    c_noise = torch.randn(B, t, device=DEV)
+    nctx = [0, 7, 7, 0, 3]
+    params = torch.stack([torch.cat([g_.mult, g_.offset, g_.min_gating.reshape(1), g_.max_gating.reshape(1)]) for g_ in gs]).detach()
+    ca, cb = ops.gates_eval(c_noise.contiguous(), params.contiguous(), torch.tensor(nctx, dtype=torch.int32, device=DEV), t)
+    for l, g_ in enumerate(gs):
+        g_.eval()
+        with torch.no_grad():
+            gate, _ = g_(c_noise, nctx[l])
+        wa, wb = ops.gate_coefs(gate.reshape(-1))
+        assert torch.allclose(ca[l], wa, atol=2e-6, rtol=1e-5) and torch.allclose(cb[l], wb, atol=2e-6, rtol=1e-5)
+    # embedding: cnoise 16, cemb 64, 4 labels (fp32 kernel vs fp32 torch math on the normalised weights)
+    N, cn, cemb, Ld = 6, 16, 64, 4
+    four = MPFourier(cn).to(DEV)
+    wn, wl = torch.randn(cemb, cn, device=DEV), torch.randn(cemb, Ld, device=DEV)
+    cnz, lab = torch.randn(N, device=DEV), torch.randint(0, Ld, (N,), device=DEV)
+
+    def what(w):
+        fan = w.shape[1]
+        return w / (1e-4 + w.norm(dim=1, keepdim=True) / fan ** 0.5) / fan ** 0.5
+    e = four(cnz) @ what(wn).t()
+    oh = torch.nn.functional.one_hot(lab, Ld).float() * Ld ** 0.5
+    want = mp_silu(mp_sum(e, oh @ what(wl).t(), t=1 / 3))
+    got = ops.embed_eval(cnz, lab, four, wn, wl, Ld).reshape(N, cemb).float()
+    assert rel(got, want) < 4e-3                                      # (bf16 output rounding)
+    got0 = ops.embed_eval(cnz, None, four, wn, None, Ld).reshape(N, cemb).float()
+    assert rel(got0, mp_silu(e)) < 4e-3
+    # preconditioning around the UNet
+    Bx, tx, C, H = 2, 3, 4, 16
+    x = torch.randn(Bx, tx, C, H, H, device=DEV)
+    sg = (torch.randn(Bx, tx, device=DEV) * 0.8).exp()
+    sd = 0.5
+    xcl = ops.dart_input(x, None, sg, 1, sd)
+    cin = 1 / (sd ** 2 + sg ** 2).sqrt()
+    want_in = (cin[:, :, None, None, None] * x).reshape(Bx * tx, C, H, H).permute(0, 2, 3, 1)
+    assert rel(xcl[..., :C], want_in) < 4e-3 and torch.equal(xcl[..., C].float(), torch.ones_like(xcl[..., C].float()))
+    assert float(xcl[..., C + 1:].abs().max()) == 0.0
+    Fcl = torch.randn(Bx * tx, H, H, 8, device=DEV).to(torch.bfloat16)
+    og = torch.tensor(0.7, device=DEV)
+    D = ops.precond_out(Fcl, x, sg, og, sd)
+    den = sg ** 2 + sd ** 2
+    Fn = Fcl[..., :C].float().permute(0, 3, 1, 2).reshape(Bx, tx, C, H, H) * og
+    wantD = (sd ** 2 / den)[:, :, None, None, None] * x + (sg * sd / den.sqrt())[:, :, None, None, None] * Fn
+    assert torch.allclose(D, wantD, atol=1e-5, rtol=1e-5)
