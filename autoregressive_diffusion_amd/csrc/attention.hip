@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][rr], SCALE_LOG2, -SOFTMAX_OFF));
+          float p = __builtin_amdgcn_exp2f(s[kt][rr] - SOFTMAX_OFF);            // (q carries log2(e)/8: qkv_norm_kernel)
           if constexpr (MASKED) {
             const int key = key0 + kt * 32 + mfma_row(rr, lane);
             if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
         constexpr bool MASKED = decltype(masked_)::value;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
-          float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rr], SCALE_LOG2, -lse));
+          float p = __builtin_amdgcn_exp2f(s[rr] - lse);                     // (q carries log2(e)/8: qkv_norm_kernel)
           if constexpr (MASKED) {
             const int key = key0 + kt * 32 + mfma_row(rr, lane);
             if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
@@ -661,7 +661,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const int rr = 4 * g4 + k;
-            float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s[rr], SCALE_LOG2, -lsv[k]));
+            float p = __builtin_amdgcn_exp2f(s[rr] - lsv[k]);                // (q carries log2(e)/8: qkv_norm_kernel)
             if constexpr (MASKED) {
               const int qtok = q0 + qb4 + k;
               if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
@@ -707,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
     for (int g = 0; g < 4; ++g) {
       bf16x4 o1, o2;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { o1[k] = f2bf(dk[dt][4 * g + k]); o2[k] = f2bf(dv[dt][4 * g + k]); }
+      for (int k = 0; k < 4; ++k) { o1[k] = f2bf(dk[dt][4 * g + k] * (1.f / SCALE_LOG2)); o2[k] = f2bf(dv[dt][4 * g + k]); }   // dK^T was summed against q' = c q
       *(bf16x4*)(dkg + dt * 32 + 8 * g + 4 * h) = o1;
       *(bf16x4*)(dvg + dt * 32 + 8 * g + 4 * h) = o2;
     }
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
 
 // dk|dv = sum over the chunks (in chunk order) of the fp32 partials; 8 elements per thread
 __global__ void attn_dkv_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ dk, bf16* __restrict__ dv,
-                                       size_t n8, int nch) {
+                                       size_t n8, int nch) {      // (dk partials were summed against q' = c q: * 1/c here)
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= 2 * n8) return;
   const int which = i >= n8;
@@ -731,9 +731,10 @@ __global__ void attn_dkv_reduce_kernel(const float* __restrict__ part, bf16* __r
     acc[0] += u.x; acc[1] += u.y; acc[2] += u.z; acc[3] += u.w;
     acc[4] += w.x; acc[5] += w.y; acc[6] += w.z; acc[7] += w.w;
   }
+  const float sc = which ? 1.f : (1.f / SCALE_LOG2);
   bf16x8 o;
 #pragma unroll
-  for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k]);
+  for (int k = 0; k < 8; ++k) o[k] = f2bf(acc[k] * sc);
   *(bf16x8*)((which ? dv : dk) + e) = o;
 }
 
@@ -758,7 +759,9 @@ __global__ void qkv_norm_kernel(const bf16* __restrict__ qkv, bf16* __restrict__
 #pragma unroll
   for (int i = 0; i < 8; ++i) { f[i] = bf2f(x[i]); ss += f[i] * f[i]; }
   ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
-  const float inv = 1.f / (1e-4f + sqrtf(ss) * 0.125f);
+  // q leaves with the softmax scale folded in (one rounding): q' = log2(e)/8 * normalised q, so that every attention kernel
+  // gets its log2-domain scores straight out of the MFMA (exp2(q'.k - lse), no multiply per score element)
+  const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
   bf16x8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) o[i] = f2bf(f[i] * inv);

@@ -19,8 +19,8 @@
 // of VALU issue: the loop is built to keep both busy, not to hide one behind the other).  K / V fragments are read
 // from LDS two slots before their first use (two register sets each).
 //
-// q is scaled by log2(e)/8 when its fragments are loaded; no running maximum and no offset: q, k are unit vectors
-// times 8 (qkv normalisation), |score| <= 11.6 in the log2 domain, so exp2 stays far inside fp32 / bf16 range.
+// q arrives with log2(e)/8 folded in (qkv_norm_kernel); no running maximum and no offset: q, k are unit vectors times
+// 8 (qkv normalisation), |score| <= 11.6 in the log2 domain, so exp2 stays far inside fp32 / bf16 range.
 // Only the LAST block of a list is partially masked (diagonal / own noisy block): its mask enters as the initial
 // accumulator of the S^T MFMAs (0 / -1e30), the softmax code is the same everywhere.
 // LDS: ring 4 x 32 KB + two Q tiles 2 x 16 KB = 160 KB.  Barriers per item: one per block + two in the epilogue,
@@ -243,9 +243,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws_kernel(const AttnDev d) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const int row = 64 * qw + 32 * x + r_;
-          const bf16x8 xx = *(const bf16x8*)(Qt + row * 128 + (((2 * ks + h_) ^ ((row >> 1) & 7)) << 4));
-#pragma unroll
-          for (int e = 0; e < 8; ++e) qf[x][ks][e] = f2bf(bf2f(xx[e]) * SCALE_LOG2);
+          qf[x][ks] = *(const bf16x8*)(Qt + row * 128 + (((2 * ks + h_) ^ ((row >> 1) & 7)) << 4));   // (q carries log2(e)/8)
         }
     }
     // register sets: kA = K fragments of half kt = 0, kB of kt = 1; vA = V^T fragments of kt = 0, vB of kt = 1;

@@ -251,7 +251,9 @@ int oniris_resample(const void* in, void* out, int64_t N, int H, int W, int C, i
  *
  * oniris_qkv_norm: splits the 1x1-conv output qkv [N][P][3C] (channel = s*C + head*64 + c, see perm3) into
  * q,k,v [N][P][C], each normalised per token and head over its 64 channels (normalize(dim=-1),
- * attention_modules.py:38,49).  oniris_qkv_norm_bwd: the adjoint (dq,dk,dv -> dqkv).
+ * attention_modules.py:38,49); q additionally carries the softmax scale, q' = log2(e)/sqrt(64) * q: the attention
+ * entry points below expect that (their scores are log2-domain straight out of the MFMA) and return dq with respect to
+ * the UNSCALED normalised q, which is what oniris_qkv_norm_bwd (the adjoint: dq,dk,dv -> dqkv) takes.
  * oniris_rope: rotates q (mode 1: * scale) or k (mode 2: / scale) over the FRAME index with host-built fp32
  * tables cos/sin/scale [n_pos][64] (built from fp16-rounded angles exactly like RoPe.py:21-32), position of
  * frame f = pos_offset + (f % pos_mod); writes the rotated tensor [B][L][C] and/or the transposed copy
