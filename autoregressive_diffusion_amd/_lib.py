@@ -110,6 +110,13 @@ _SIGS = {
     "oniris_embed_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_int, c_void_p]),
     "oniris_gates": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "oniris_gates_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "oniris_emb_scale": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "oniris_emb_scale_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "oniris_embed_pre": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
+    "oniris_embed_post": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
+    "oniris_embed_post_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "oniris_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_int64, c_void_p]),
     "oniris_attn_fwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
@@ -128,6 +135,26 @@ for _name, (_res, _args) in _SIGS.items():
     _fn.restype = _res
     _fn.argtypes = _args
 
+
+if os.environ.get("ONIRIS_HOST_TIMING") == "2":          # diagnostic: wall time spent inside every C-ABI call
+    import time as _time
+    call_stats = {}
+
+    def _timed(name, fn):
+        def w(*a):
+            t0 = _time.perf_counter()
+            r = fn(*a)
+            st = call_stats.setdefault(name, [0, 0.0])
+            st[0] += 1; st[1] += _time.perf_counter() - t0
+            return r
+        return w
+
+    class _TimedLib:
+        pass
+    _tl = _TimedLib()
+    for _name in _SIGS:
+        setattr(_tl, _name, _timed(_name, getattr(lib, _name)))
+    lib = _tl
 
 _sz = (c_int32 * 4)()
 lib.oniris_struct_sizes(_sz)

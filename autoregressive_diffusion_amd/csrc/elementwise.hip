@@ -537,3 +537,185 @@ extern "C" int oniris_embed_eval(const float* c_noise, const int64_t* labels, co
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training-side conditioning prelude (gates, embedding, emb scales) as a handful of fused launches with explicit
+// adjoints, instead of ~130 forward / ~150 backward torch elementwise launches on kilobyte-sized tensors per step
+// (the host cannot enqueue those faster than the GPU drains them: ~2 ms of idle GPU per step around the optimizer).
+
+// Adjoint of gates_kernel: dparams [L][6] (mult0, mult1, off0, off1, min_gating, max_gating) from dca, dcb [L][N].
+//   d ca / d g = -g r^3,  d cb / d g = (1 - g) r^3   (r = ((1-g)^2 + g^2)^-1/2);   one block per layer.
+__global__ __launch_bounds__(256) void gates_bwd_kernel(const float* __restrict__ c_noise, const float* __restrict__ params,
+                                                        const int* __restrict__ nctx, const float* __restrict__ dca,
+                                                        const float* __restrict__ dcb, float* __restrict__ dparams, int N, int T) {
+  __shared__ float red[6][4];
+  const int l = blockIdx.x;
+  const float* p = params + l * 6;
+  const float lo = 1.f / (1.f + expf(-p[4])), hi = 1.f / (1.f + expf(-p[5]));
+  const float nc = nctx ? (float)nctx[l] : 0.f;
+  float acc[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // dmult0, dmult1, d(off0 + off1), -, dlo, dhi
+  for (int n = threadIdx.x; n < N; n += 256) {
+    const float cn = c_noise[n];
+    const float pos = log1pf((float)(n % T) + nc);
+    const float sv = cn * p[0] + p[2] + pos * p[1] + p[3];
+    const float s = 1.f / (1.f + expf(-sv));
+    const float g = lo + (1.f - lo) * hi * s;
+    const float r = rsqrtf((1.f - g) * (1.f - g) + g * g);
+    const float r3 = r * r * r;
+    const float dg = r3 * ((1.f - g) * dcb[(size_t)l * N + n] - g * dca[(size_t)l * N + n]);
+    const float dsv = dg * (1.f - lo) * hi * s * (1.f - s);
+    acc[0] += dsv * cn; acc[1] += dsv * pos; acc[2] += dsv;
+    acc[4] += dg * (1.f - hi * s); acc[5] += dg * (1.f - lo) * s;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) t[k] = (red[k][0] + red[k][1]) + (red[k][2] + red[k][3]);
+    float* o = dparams + l * 6;
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[2];
+    o[4] = t[4] * lo * (1.f - lo); o[5] = t[5] * hi * (1.f - hi);
+  }
+}
+
+extern "C" int oniris_gates_bwd(const float* c_noise, const float* params, const int32_t* nctx, const float* dca,
+                                const float* dcb, float* dparams, int L, int N, int T, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(c_noise && params && dca && dcb && dparams && L > 0 && N > 0 && T > 0, "gates_bwd: bad arguments");
+  hipLaunchKernelGGL(gates_bwd_kernel, dim3(L), dim3(256), 0, stream, c_noise, params, (const int*)nctx, dca, dcb, dparams, N, T);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// c[n][j] = 1 + c_all[n][j] * gain[seg[j]]   (networks_edm2.py:78, every Block at once: c_all = the row-concatenated
+// emb_linear GEMM [N][Ctot] bf16, seg[j] = the Block column j belongs to, gain = the Blocks' emb_gain); fp32 out.
+__global__ void emb_scale_kernel(const bf16* __restrict__ c_all, const float* __restrict__ gain, const int* __restrict__ seg,
+                                 float* __restrict__ c, int N, int Ctot) {
+  const size_t total = (size_t)N * Ctot;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int j = (int)(i % Ctot);
+    c[i] = 1.f + bf2f(c_all[i]) * gain[seg[j]];
+  }
+}
+
+// adjoint: dc_all = dc * gain[seg] (bf16), dgain[k] = sum over n and the columns [start[k], start[k+1]) of dc * c_all;
+// one block per Block k (no atomics: deterministic)
+__global__ __launch_bounds__(256) void emb_scale_bwd_kernel(const float* __restrict__ dc, const bf16* __restrict__ c_all,
+                                                            const float* __restrict__ gain, const int* __restrict__ start,
+                                                            bf16* __restrict__ dc_all, float* __restrict__ dgain, int N, int Ctot) {
+  __shared__ float red[4];
+  const int k = blockIdx.x;
+  const int j0 = start[k], w = start[k + 1] - j0;
+  const float g = gain[k];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < N * w; i += 256) {
+    const int n = i / w, j = j0 + (i - n * w);
+    const size_t at = (size_t)n * Ctot + j;
+    const float d = dc[at];
+    acc += d * bf2f(c_all[at]);
+    dc_all[at] = f2bf(d * g);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dgain[k] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+extern "C" int oniris_emb_scale(const void* c_all, const float* gain, const int32_t* seg, float* c, int N, int Ctot,
+                                oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(c_all && gain && seg && c && N > 0 && Ctot > 0, "emb_scale: bad arguments");
+  const size_t total = (size_t)N * Ctot;
+  hipLaunchKernelGGL(emb_scale_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16*)c_all, gain, (const int*)seg, c, N, Ctot);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_emb_scale_bwd(const float* dc, const void* c_all, const float* gain, const int32_t* start, void* dc_all,
+                                    float* dgain, int N, int Ctot, int K, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(dc && c_all && gain && start && dc_all && dgain && N > 0 && Ctot > 0 && K > 0, "emb_scale_bwd: bad arguments");
+  hipLaunchKernelGGL(emb_scale_bwd_kernel, dim3(K), dim3(256), 0, stream, dc, (const bf16*)c_all, gain, (const int*)start,
+                     (bf16*)dc_all, dgain, N, Ctot);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// Inputs of the two embedding linears (networks_edm2.py:204-212): four [N][cnP] bf16 = sqrt(2) cos(c_noise f + phi)
+// (MPFourier, utils.py:139-150; zero-padded to cnP), onehot [N][LP] bf16 = sqrt(L) at the label, else 0 (NULL: no labels).
+__global__ void embed_pre_kernel(const float* __restrict__ c_noise, const long long* __restrict__ labels,
+                                 const float* __restrict__ freqs, const float* __restrict__ phases, bf16* __restrict__ four,
+                                 bf16* __restrict__ onehot, int N, int cn, int cnP, int L, int LP) {
+  const int n = blockIdx.x;
+  const float x = c_noise[n];
+  for (int i = threadIdx.x; i < cnP; i += blockDim.x)
+    four[(size_t)n * cnP + i] = f2bf(i < cn ? 1.4142135623730951f * cosf(x * freqs[i] + phases[i]) : 0.f);
+  if (onehot) {
+    const long long lab = labels[n];
+    for (int i = threadIdx.x; i < LP; i += blockDim.x) onehot[(size_t)n * LP + i] = f2bf(i == lab ? sqrtf((float)L) : 0.f);
+  }
+}
+
+extern "C" int oniris_embed_pre(const float* c_noise, const int64_t* labels, const float* freqs, const float* phases, void* four,
+                                void* onehot, int N, int cnoise, int cnoiseP, int label_dim, int labelP, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(c_noise && freqs && phases && four && N > 0 && cnoise > 0 && cnoiseP >= cnoise, "embed_pre: bad arguments");
+  ONIRIS_CHECK_ARG(!onehot || (labels && label_dim > 0 && labelP >= label_dim), "embed_pre: labels missing");
+  hipLaunchKernelGGL(embed_pre_kernel, dim3(N), dim3(64), 0, stream, c_noise, (const long long*)labels, freqs, phases,
+                     (bf16*)four, (bf16*)onehot, N, cnoise, cnoiseP, label_dim, labelP);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// emb = mp_silu(mp_sum(e1, e2, t)) (utils.py:118-123,101-102; e2 NULL: emb = mp_silu(e1)), bf16 in / out, fp32 inside;
+// the adjoint recomputes the pre-activation from e1, e2.
+__global__ void embed_post_kernel(const bf16* __restrict__ e1, const bf16* __restrict__ e2, bf16* __restrict__ emb, size_t n,
+                                  float t) {
+  const float den = rsqrtf((1.f - t) * (1.f - t) + t * t);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float e = bf2f(e1[i]);
+    if (e2) e = (e + (bf2f(e2[i]) - e) * t) * den;
+    emb[i] = f2bf(e * sigmoid_fast(e) * (1.f / 0.596f));
+  }
+}
+
+__global__ void embed_post_bwd_kernel(const bf16* __restrict__ demb, const bf16* __restrict__ e1, const bf16* __restrict__ e2,
+                                      bf16* __restrict__ de1, bf16* __restrict__ de2, size_t n, float t) {
+  const float den = rsqrtf((1.f - t) * (1.f - t) + t * t);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float e = bf2f(e1[i]);
+    if (e2) e = (e + (bf2f(e2[i]) - e) * t) * den;
+    const float s = sigmoid_fast(e);
+    const float de = bf2f(demb[i]) * (1.f / 0.596f) * s * (1.f + e * (1.f - s));
+    if (e2) { de1[i] = f2bf(de * (1.f - t) * den); de2[i] = f2bf(de * t * den); }
+    else de1[i] = f2bf(de);
+  }
+}
+
+extern "C" int oniris_embed_post(const void* e1, const void* e2, void* emb, size_t n, float t, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(e1 && emb && n > 0, "embed_post: bad arguments");
+  hipLaunchKernelGGL(embed_post_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16*)e1, (const bf16*)e2, (bf16*)emb, n, t);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_embed_post_bwd(const void* demb, const void* e1, const void* e2, void* de1, void* de2, size_t n, float t,
+                                     oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(demb && e1 && de1 && n > 0 && (!e2 || de2), "embed_post_bwd: bad arguments");
+  hipLaunchKernelGGL(embed_post_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16*)demb, (const bf16*)e1, (const bf16*)e2, (bf16*)de1, (bf16*)de2, n, t);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}

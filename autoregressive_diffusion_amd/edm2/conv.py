@@ -19,8 +19,8 @@ def _bank_of(root):
     mods = root.__dict__.get("_oniris_mods")          # the module tree of a built net is fixed: walk it once
     if mods is None:                                   # (~0.5 ms of host time per forward for the gym net otherwise)
         mods = root.__dict__["_oniris_mods"] = [m for m in root.modules() if isinstance(m, NormalizedWeight)]
-    if bank is None or bank._n_mods != len(mods) or any(m.pw is None or m.pw.param is not m.weight or m.pw.bank is not bank
-                                                        for m in mods):
+    if bank is None or bank._n_mods != len(mods) or any(m.pw is None or m.pw.param is not m._parameters["weight"] or
+                                                        m.pw.bank is not bank for m in mods):
         bank = ops.WeightBank()
         for m in mods:
             m.pw = bank.add(m.weight, perm3=m.perm3)
@@ -167,6 +167,26 @@ def batched_gates(convs, c_noise, caches, training):
         # when a parameter changed, the frame counters are the cached device vector of nctx_tensor
         params = _packed_gate_params(convs, dev)
         ca, cb = ops.gates_eval(c_noise.float().contiguous(), params, _nctx_i32(n_ctx, dev) if any(n_ctx) else None, T)
+        return [(a, b, n + T) for a, b, n in zip(ca.unbind(0), cb.unbind(0), n_ctx)]
+    if ops.FUSED_PRELUDE and c_noise.is_cuda:
+        # one forward and one backward launch (oniris_gates / oniris_gates_bwd) around an (L, 6) pack of the parameters;
+        # the torch formulation below costs ~28 forward and ~60 backward launches on (L, B, tt) = 15 K-element tensors
+        pack = None
+        if torch.is_grad_enabled():        # parameters in one FlatParams: gathered from / delivered into its flat buffers
+            gp = convs[0].__dict__.get("_oniris_gate_params")      # (module attribute lookups: ~1 us each, 300 of them)
+            if gp is None or len(gp) != 4 * len(convs) or gp[0] is not convs[0].gating._parameters["mult"]:
+                gp = convs[0].__dict__["_oniris_gate_params"] = [p for m in convs for p in (
+                    m.gating.mult, m.gating.offset, m.gating.min_gating, m.gating.max_gating)]
+            pack = ops.direct_pack(gp, convs[0], "_gate_pack")
+        if pack is not None:
+            P, anchor = pack.values().view(len(convs), 6), convs[0].gating.mult
+        else:
+            P = torch.cat([torch.stack([m.gating.mult for m in convs]), torch.stack([m.gating.offset for m in convs]),
+                           torch.stack([m.gating.min_gating for m in convs])[:, None],
+                           torch.stack([m.gating.max_gating for m in convs])[:, None]], dim=1).float()
+            anchor = None
+        ca, cb = ops.gates_train(c_noise.float().reshape(-1).contiguous(), P, _nctx_i32(n_ctx, dev) if any(n_ctx) else None, T,
+                                 pack, anchor)
         return [(a, b, n + T) for a, b, n in zip(ca.unbind(0), cb.unbind(0), n_ctx)]
     mult = torch.stack([m.gating.mult for m in convs])            # (L,2)
     off = torch.stack([m.gating.offset for m in convs])           # (L,2)

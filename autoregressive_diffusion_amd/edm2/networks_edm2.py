@@ -160,7 +160,8 @@ class UNet(BetterModule):
         with weights_ready(self):
             B, tt = x.shape[:2] if _cl_io is None else _cl_io
             n_ctx = cache.get("n_context_frames", 0)
-            _, n_new = self.out_res(c_noise, n_ctx, just_2d)              # frame counter (value unused, :197)
+            n_new = n_ctx + (tt // 2 if self.training else tt)           # out_res(...)'s frame counter; its gate value is
+                                                                         # unused in the reference too (:197), not evaluated here
             if update_cache:
                 cache["n_context_frames"] = n_new
             c_noise = c_noise.float()
@@ -171,6 +172,13 @@ class UNet(BetterModule):
                 # in ONE fp32 launch (~28 tiny launches otherwise, 31 times per generated frame)
                 emb = ops.embed_eval(cn.contiguous(), conditioning if self.emb_label is not None else None, self.emb_fourier_sigma,
                                      wn, self.emb_label.weight.weight if self.emb_label is not None else None, self.label_dim)
+            elif ops.FUSED_PRELUDE and cn.is_cuda and wn.shape[0] % 8 == 0:
+                # training: Fourier features + one-hot in one launch, the two linears on the packed weights, mp_sum +
+                # mp_silu in one launch (and one for their adjoint) instead of ~40 + ~50 tiny torch launches
+                with_label = self.emb_label is not None and conditioning is not None
+                emb = ops.embed_train(cn.contiguous(), conditioning if with_label else None, self.emb_fourier_sigma,
+                                      self.emb_noise.weight.pw, self.emb_label.weight.pw if with_label else None,
+                                      self.label_dim)
             else:
                 # embedding (fp32 in torch for the tiny Fourier features, bf16 through the linear kernels)
                 emb = self.emb_noise.forward(self.emb_fourier_sigma(cn))
@@ -189,9 +197,14 @@ class UNet(BetterModule):
                 xcl = x
             if not just_2d:
                 self._prime_gates(c_noise, cache)
-            blocks = self._emb_blocks()
-            cs = dict(zip(map(id, blocks), ops.emb_scales(emb, self.__dict__["_oniris_groups"][0],
-                                                          [b.emb_gain for b in blocks])))
+            eb = self.__dict__.get("_oniris_emb_blocks")
+            if eb is None:
+                blocks = self._emb_blocks()
+                eb = self.__dict__["_oniris_emb_blocks"] = (blocks, [b.emb_gain for b in blocks])
+            blocks, gains = eb
+            if gains[0] is not blocks[0]._parameters["emb_gain"]:           # (a parameter object was replaced)
+                gains = eb[1][:] = [b.emb_gain for b in blocks]
+            cs = dict(zip(map(id, blocks), ops.emb_scales(emb, self.__dict__["_oniris_groups"][0], gains)))
             skips = []
             stage_cb = self.__dict__.get("_oniris_stage_cb")
             stage_at = self.__dict__.get("_oniris_stage_at") if stage_cb is not None else None
@@ -313,19 +326,30 @@ class UNet(BetterModule):
 
     def _prime_gates(self, c_noise, cache):
         """Evaluate the gates of all gated convs at once and hand each layer its (ca, cb, counter)."""
-        convs, caches = [], []
+        plan = self.__dict__.get("_oniris_gate_plan")          # the module tree of a built net is fixed: walk it once
+        if plan is None:
+            plan = []                                          # (conv, key of its block's cache, key inside it | None)
 
-        def visit(mod, c):
-            if isinstance(mod, MPCausal3DGatedConv):
-                convs.append(mod); caches.append(c)
-            else:
-                c = c or {}
-                convs.extend([mod.conv_res0, mod.conv_res1]); caches.extend([c.get("conv_res0"), c.get("conv_res1")])
-        for name, block in self.enc.items():
-            visit(block, cache.get(("enc", name)))
-        for name, block in self.dec.items():
-            visit(block, cache.get(("dec", name)))
-        visit(self.out_conv, cache.get("out_conv"))
+            def visit(mod, key):
+                if isinstance(mod, MPCausal3DGatedConv):
+                    plan.append((mod, key, None))
+                else:
+                    plan.extend([(mod.conv_res0, key, "conv_res0"), (mod.conv_res1, key, "conv_res1")])
+            for name, block in self.enc.items():
+                visit(block, ("enc", name))
+            for name, block in self.dec.items():
+                visit(block, ("dec", name))
+            visit(self.out_conv, "out_conv")
+            self.__dict__["_oniris_gate_plan"] = plan
+            self.__dict__["_oniris_gate_convs"] = [m for m, _, _ in plan]
+        convs = self.__dict__["_oniris_gate_convs"]
+        if cache:
+            caches = []
+            for _, key, sub in plan:
+                c = cache.get(key)
+                caches.append(c if sub is None else (c or {}).get(sub))
+        else:
+            caches = [None] * len(convs)
         for m, pre in zip(convs, batched_gates(convs, c_noise, caches, self.training)):
             m.__dict__["_gate_pre"] = pre
 

@@ -24,7 +24,7 @@ class GraphedStep:
         if flat is None and self.params:
             from .parallel import FlatParams
             flat = FlatParams.owner_of(self.params[0])
-        self.flat, self._touched = flat, []
+        self.flat, self._touched = flat, ([], [])
         self.graph, self.out, self.calls = None, None, 0
         # ONE side stream for the warm-up and the capture of EVERY GraphedStep: autograd pins each parameter's
         # AccumulateGrad node to the stream it was first used on; a node living on another stream would run outside

@@ -303,17 +303,24 @@ class WeightBank:
         self._sig = self._signature()
 
     def _ensure(self):
-        device = self.items[0][0].param.device
-        _need_gpu(self.items[0][0].param)
-        for w, _ in self.items:
-            if w.param.requires_grad and w.param.grad is None:
-                self._sig = None
-        if self._dev_table is None or self._sig != self._signature():
-            self._build(device)
+        p0 = self.items[0][0].param
+        _need_gpu(p0)
+        sig, ok = [], self._dev_table is not None
+        for w, _ in self.items:                        # ONE pass (this runs at the start of every step, on the critical
+            p = w.param                                # path of the host: ~150 us for the 184 weights of the gym net)
+            g = p.grad
+            if g is None:
+                ok = ok and not p.requires_grad
+                sig.append((p.data_ptr(), 0))
+            else:
+                sig.append((p.data_ptr(), g.data_ptr()))
+        if not ok or self._sig != tuple(sig):
+            self._build(p0.device)
 
     def prepare(self, training):
         """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
         self._ensure()
+        self._fresh = True                             # backward() of the same step need not re-validate the table
         if training or torch.is_grad_enabled():        # (a no_grad evaluation -- the rollout -- never takes from the arena)
             self.zero_arena.reset(self.items[0][0].param.device)   # the previous step's backward is done with its accumulators
         global _weights_epoch
@@ -332,7 +339,9 @@ class WeightBank:
 
     def backward(self):
         """Packed fp32 weight gradients (from the wgrad kernels) -> parameter .grad (accumulated); one launch."""
-        self._ensure()
+        if not getattr(self, "_fresh", False):
+            self._ensure()
+        self._fresh = False
         join_side_stream()                             # every wgrad kernel (possibly on the side stream) is ordered before
         check(lib.oniris_weight_bwd(_p(self._dev_table), len(self.items), self.total_rows, _stream()), "weight_bwd")
         self.nsplit_all.zero_()        # the slabs are consumed: a second backward() must not add them again
@@ -860,6 +869,143 @@ class _SplitCols(torch.autograd.Function):
         return torch.cat(parts, dim=1), None
 
 
+FUSED_PRELUDE = int(_os.environ.get("ONIRIS_FUSED_PRELUDE", "1"))   # 0: torch-autograd formulation of gates / embedding / emb scales (A/B, tests)
+
+
+def direct_pack(params, holder, name):
+    """parallel.ParamPack over `params` when ONE FlatParams owns them all (their values are then gathered from, and their
+    gradients added into, the flat buffers without any autograd node), else None.  Cached per (holder, name)."""
+    from .parallel import FlatParams
+    p0 = params[0]
+    flat = FlatParams.owner_of(p0)
+    if flat is None:
+        return None
+    hit = _pack_cache.get((id(holder), name))
+    if hit is not None and hit.flat is flat and len(hit.ids) == len(params) and hit.ids[0] == id(p0) and \
+            hit.ids[-1] == id(params[-1]) and p0.data_ptr() == flat.flat.data_ptr() + 4 * flat.offset_of(p0):
+        return hit
+    base = flat.flat.data_ptr()
+    for p in params:
+        if FlatParams.owner_of(p) is not flat or p.dtype != torch.float32 or p.data_ptr() != base + 4 * flat.offset_of(p):
+            return None
+    if len(_pack_cache) > 64:
+        _pack_cache.clear()
+    hit = _pack_cache[(id(holder), name)] = flat.direct_pack(params)
+    return hit
+
+
+_pack_cache = {}
+
+
+class _EmbScaleFn(torch.autograd.Function):
+    """c = 1 + c_all * gain[seg]  (oniris_emb_scale / oniris_emb_scale_bwd).  sink (parallel.ParamPack or None): where the
+    gain gradient goes when `gain` has no autograd history."""
+
+    @staticmethod
+    def forward(ctx, c_all, gain, seg, start, sink=None):
+        N, Ctot = c_all.shape
+        c = torch.empty((N, Ctot), dtype=torch.float32, device=c_all.device)
+        check(lib.oniris_emb_scale(_p(c_all), _p(gain), _p(seg), _p(c), N, Ctot, _stream()), "emb_scale")
+        ctx.save_for_backward(c_all, gain, start)
+        ctx.sink = sink
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        c_all, gain, start = ctx.saved_tensors
+        N, Ctot = c_all.shape
+        dc = dc.contiguous()
+        dc_all = torch.empty_like(c_all)
+        dgain = torch.empty_like(gain)
+        check(lib.oniris_emb_scale_bwd(_p(dc), _p(c_all), _p(gain), _p(start), _p(dc_all), _p(dgain), N, Ctot, gain.numel(),
+                                       _stream()), "emb_scale_bwd")
+        if ctx.sink is not None:
+            ctx.sink.deliver(dgain)
+            dgain = None
+        return dc_all, dgain, None, None, None
+
+
+class _EmbedPostFn(torch.autograd.Function):
+    """emb = mp_silu(mp_sum(e1, e2, t)) on bf16 (N, C) rows  (oniris_embed_post / _bwd); e2 may be None."""
+
+    @staticmethod
+    def forward(ctx, e1, e2, t):
+        emb = torch.empty_like(e1)
+        check(lib.oniris_embed_post(_p(e1), _p(e2), _p(emb), e1.numel(), t, _stream()), "embed_post")
+        ctx.save_for_backward(e1, e2)
+        ctx.t = t
+        return emb
+
+    @staticmethod
+    def backward(ctx, demb):
+        e1, e2 = ctx.saved_tensors
+        demb = demb.contiguous()
+        de1 = torch.empty_like(e1)
+        de2 = torch.empty_like(e2) if e2 is not None else None
+        check(lib.oniris_embed_post_bwd(_p(demb), _p(e1), _p(e2), _p(de1), _p(de2), e1.numel(), ctx.t, _stream()),
+              "embed_post_bwd")
+        return de1, de2, None
+
+
+def embed_train(c_noise, labels, fourier, pw_noise, pw_label, label_dim, t=1 / 3):
+    """The UNet's embedding with gradients to the two linear weights (networks_edm2.py:204-212): one launch builds the
+    bf16 inputs of both linears (Fourier features, scaled one-hot), the linears run on the packed weights, one launch
+    does mp_sum + mp_silu.  Returns emb (N, 1, 1, cemb) bf16."""
+    _need_gpu(c_noise)
+    N, dev = c_noise.numel(), c_noise.device
+    cn = fourier.freqs.numel()
+    cnP = roundup(cn, 8)
+    four = torch.empty((N, 1, 1, cnP), dtype=BF16, device=dev)
+    oh, LP = None, 0
+    if labels is not None and pw_label is not None:
+        LP = roundup(label_dim, 8)
+        oh = torch.empty((N, 1, 1, LP), dtype=BF16, device=dev)
+        labels = labels.reshape(-1).contiguous()
+    freqs, phases = fourier.freqs, fourier.phases
+    if freqs.dtype != torch.float32:
+        freqs, phases = freqs.float(), phases.float()
+    check(lib.oniris_embed_pre(_p(c_noise), _p(labels) if oh is not None else None, _p(freqs), _p(phases), _p(four), _p(oh), N,
+                               cn, cnP, label_dim, LP, _stream()), "embed_pre")
+    e1 = conv(four, pw_noise)
+    e2 = conv(oh, pw_label) if oh is not None else None
+    return _EmbedPostFn.apply(e1, e2, float(t))
+
+
+class _GatesFn(torch.autograd.Function):
+    """(ca, cb) [L][N] of all gating layers (oniris_gates) with the adjoint to the packed parameters (oniris_gates_bwd)."""
+
+    @staticmethod
+    def forward(ctx, c_noise, params, nctx, T, sink=None, anchor=None):
+        L, N = params.shape[0], c_noise.numel()
+        out = torch.empty((2, L, N), dtype=torch.float32, device=c_noise.device)
+        params = params.contiguous()
+        check(lib.oniris_gates(_p(c_noise), _p(params), _p(nctx), _p(out[0]), _p(out[1]), L, N, T, _stream()), "gates")
+        ctx.save_for_backward(c_noise, params, nctx)
+        ctx.T, ctx.sink = T, sink
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, dca, dcb):
+        c_noise, params, nctx = ctx.saved_tensors
+        L, N = params.shape[0], c_noise.numel()
+        dca, dcb = dca.contiguous(), dcb.contiguous()
+        dparams = torch.empty_like(params)
+        check(lib.oniris_gates_bwd(_p(c_noise), _p(params), _p(nctx), _p(dca), _p(dcb), _p(dparams), L, N, ctx.T, _stream()),
+              "gates_bwd")
+        if ctx.sink is not None:
+            ctx.sink.deliver(dparams)
+            dparams = None
+        return None, dparams, None, None, None, None
+
+
+def gates_train(c_noise, params, nctx, T, sink=None, anchor=None):
+    """Training counterpart of gates_eval: params (L, 6) fp32 (mult0, mult1, off0, off1, min_gating, max_gating per layer)
+    either WITH autograd history, or gathered by a parallel.ParamPack `sink` that also receives the gradient (`anchor`:
+    any tensor that requires grad, so that autograd schedules the node); c_noise (N,) fp32 contiguous; returns ca, cb (L, N)."""
+    _need_gpu(c_noise, params)
+    return _GatesFn.apply(c_noise, params, nctx, T, sink, anchor)
+
+
 def emb_scales(emb, gpw, gains):
     """All `c = emb_linear(emb) * emb_gain + 1` of a UNet (networks_edm2.py:78 in every Block) at once:
     emb (N,1,1,Cemb) bf16, gpw the row-concatenated emb_linear group (WeightBank.add_group), gains the emb_gain
@@ -867,6 +1013,35 @@ def emb_scales(emb, gpw, gains):
     N = emb.shape[0]
     c_all = conv(emb, gpw).reshape(N, gpw.cout)
     dev = emb.device
+    if FUSED_PRELUDE and c_all.is_cuda:
+        key = ("fused", id(gpw), str(dev))
+        cache = _emb_idx_cache.get(key)
+        if cache is None:
+            sizes, seg, start = [], [], [0]
+            for k, m in enumerate(gpw.members):
+                w = roundup(m.cout, 64)
+                sizes.append(m.cout)
+                if w != m.cout:
+                    sizes.append(w - m.cout)
+                seg += [k] * w
+                start.append(start[-1] + w)
+            assert start[-1] == gpw.cout, (start[-1], gpw.cout)
+            cache = _emb_idx_cache[key] = (tuple(sizes), torch.tensor(seg, dtype=torch.int32, device=dev),
+                                           torch.tensor(start, dtype=torch.int32, device=dev))
+        sizes, seg, start = cache
+        pack = direct_pack(gains, gpw, "_gain_pack") if torch.is_grad_enabled() else None
+        if pack is not None:
+            g = pack.values()
+        else:
+            g = torch.cat([x.reshape(1) for x in gains])
+            if g.dtype != torch.float32:
+                g = g.float()
+        outs = _SplitCols.apply(_EmbScaleFn.apply(c_all, g, seg, start, pack), sizes)
+        res, j = [], 0
+        for m in gpw.members:
+            res.append(outs[j])
+            j += 2 if roundup(m.cout, 64) != m.cout else 1
+        return res
     sizes, seg = [], []
     for k, m in enumerate(gpw.members):
         sizes.append(m.cout)

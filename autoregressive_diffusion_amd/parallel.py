@@ -14,6 +14,21 @@ import torch.distributed as dist
 from torch import nn
 
 
+class ParamPack:
+    """See FlatParams.direct_pack."""
+
+    def __init__(self, flat, idx, ids):
+        self.flat, self.idx, self.ids = flat, idx, ids
+
+    def values(self):
+        return self.flat.flat.index_select(0, self.idx)
+
+    def deliver(self, grad):
+        """grad: flat fp32 tensor in pack order; accumulates like autograd would."""
+        self.flat.grad.index_add_(0, self.idx, grad.reshape(-1))
+        self.flat._got.update(self.ids)
+
+
 class FlatParams:
     """Re-homes every trainable parameter of `module` (and its .grad) as a view into one flat fp32 buffer."""
 
@@ -81,10 +96,30 @@ class FlatParams:
             self._owner = {id(m.weight): m for m in module.modules() if isinstance(m, NormalizedWeight)}
         except ImportError:                # (toy modules in the CPU tests)
             pass
+        self._direct = {}                  # id(parameter) -> True: a fused backward kernel adds its gradient into self.grad
         if lazy_small:
             self._lazy = [(p, p.grad) for p in self.params if id(p) not in self._owner]
             for p, _ in self._lazy:
                 p.grad = None
+
+    def direct_pack(self, params):
+        """A ParamPack over `params` (all re-homed here): their values as one gathered vector, their gradients added
+        straight into the flat gradient buffer by one index_add_ -- no autograd node, no AccumulateGrad, no per-parameter
+        Python work per step (the ~270 scalar parameters of the gates and emb_gain's cost ~2 ms of host time per step
+        that way).  Their .grad stays the permanent view into the flat buffer (like the kernel-owned conv weights)."""
+        offs = []
+        for p in params:
+            o = self.offset_of(p)
+            offs.extend(range(o, o + p.numel()))
+        idx = torch.tensor(offs, dtype=torch.int64, device=self.flat.device)
+        ids = [id(p) for p in params]
+        views = {id(p): v for p, v in self._lazy}
+        for p in params:
+            self._direct[id(p)] = True
+            if id(p) in views:
+                p.grad = views[id(p)]
+        self._lazy = [(p, v) for p, v in self._lazy if id(p) not in self._direct]
+        return ParamPack(self, idx, ids)
 
     def zero_grad(self):
         self.grad.zero_()
@@ -120,28 +155,34 @@ class FlatParams:
         side, no device sync); autograd-owned lazy parameters: autograd handed a gradient over (gather()); parameters
         whose .grad is a permanent view of the flat buffer cannot tell "none" from "zero" and count as active."""
         self.gather()
-        lazy = {id(p) for p, _ in self._lazy}
-        out = []
-        for p in self.params:
-            m = self._owner.get(id(p))
-            pw = getattr(m, "pw", None) if m is not None else None
-            if m is not None and pw is not None:
+        kinds = getattr(self, "_kinds", None)
+        if kinds is None or kinds[0] != (len(self._lazy), len(self._direct)):
+            lazy = {id(p) for p, _ in self._lazy}
+            kinds = self._kinds = ((len(self._lazy), len(self._direct)),
+                                   [(self._owner.get(id(p)), id(p), id(p) in lazy or id(p) in self._direct) for p in self.params])
+        out, got = [], self._got
+        for m, pid, tracked in kinds[1]:                       # (runs every step between backward and the optimizer launch)
+            pw = m.pw if m is not None else None
+            if pw is not None:
                 out.append(bool(pw.touched)); pw.touched = False
-            elif id(p) in lazy:
-                out.append(id(p) in self._got)
+            elif tracked:
+                out.append(pid in got)
             else:
                 out.append(True)
-        self._got.clear()
+        got.clear()
         return out
 
     def snapshot_touched(self):
-        """Host-side gradient bookkeeping of the backward that just ran (for graphs.GraphedStep: a replay runs no Python)."""
-        return [m.pw for m in self._owner.values() if getattr(m, "pw", None) is not None and m.pw.touched]
+        """Host-side gradient bookkeeping of the backward that just ran (for graphs.GraphedStep: a replay runs no Python):
+        the weights a weight-gradient launch targeted and the parameters a fused backward delivered into the flat buffer."""
+        return ([m.pw for m in self._owner.values() if getattr(m, "pw", None) is not None and m.pw.touched],
+                [i for i in self._got if i in self._direct])
 
-    @staticmethod
-    def restore_touched(pws):
+    def restore_touched(self, snap):
+        pws, got = snap
         for pw in pws:
             pw.touched = True
+        self._got.update(got)
 
     def check(self):
         """True while every parameter still aliases the flat buffers (a .to()/deepcopy breaks the aliasing)."""

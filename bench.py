@@ -191,10 +191,19 @@ def main():
     latents = torch.randn(B, T, 8, res, res, device=dev, generator=g)
     actions = None if cs else torch.randint(0, 4, (B, T), device=dev, generator=g)      # cs_train.py:103 conditioning=None
 
+    _host_t = [0.0, 0.0, 0.0] if os.environ.get("ONIRIS_HOST_TIMING") else None
     def fwd_bwd(just_2d):
         opt.zero_grad()
+        if _host_t is None:
+            loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
+            loss.backward()
+            return loss
+        ta, ca_ = time.perf_counter(), time.thread_time()         # ONIRIS_HOST_TIMING: host enqueue time, forward / backward
         loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
+        tb = time.perf_counter()
+        _host_t[2] += time.thread_time() - ca_                   # CPU time of the forward (wall - CPU = blocked, not computing)
         loss.backward()
+        _host_t[0] += tb - ta; _host_t[1] += time.perf_counter() - tb
         return loss
 
     use_graph = bool(args.graph)
@@ -242,6 +251,8 @@ def main():
         if dbg:
             print("warmup", i, float(l_.item()), file=sys.stderr)
     fence()
+    if _host_t:
+        _host_t[0] = _host_t[1] = _host_t[2] = 0.0
     t0 = time.perf_counter()
     hist = []
     for i in range(args.steps):
@@ -260,8 +271,15 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss_val = float(last.item())
+    if os.environ.get("ONIRIS_HOST_TIMING") == "2":
+        from autoregressive_diffusion_amd import _lib as _l
+        tot = sum(v[1] for v in _l.call_stats.values())
+        print(f"C-ABI calls: {sum(v[0] for v in _l.call_stats.values())} calls, {tot * 1e3:.1f} ms in total (whole process)", file=sys.stderr)
+        for k, v in sorted(_l.call_stats.items(), key=lambda kv: -kv[1][1])[:8]:
+            print(f"   {k:28s} n={v[0]:6d}  {v[1] / v[0] * 1e6:7.1f} us/call", file=sys.stderr)
     if os.environ.get("ONIRIS_HOST_TIMING"):
-        print(f"host enqueue {t_enq / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f} ms/step", file=sys.stderr)
+        print(f"host enqueue {t_enq / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f} ms/step "
+              f"(forward {_host_t[0] / args.steps * 1e3:.2f} [cpu {_host_t[2] / args.steps * 1e3:.2f}], backward {_host_t[1] / args.steps * 1e3:.2f})", file=sys.stderr)
 
     # per-mode step times (one 3-D and one 2-D step, timed separately, not part of `value`)
     per_mode = {}

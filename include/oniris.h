@@ -110,6 +110,28 @@ int oniris_embed_eval(const float* c_noise, const int64_t* labels, const float* 
 int oniris_gates(const float* c_noise, const float* params, const int32_t* nctx, float* ca, float* cb, int L, int N, int T,
                  oniris_stream_t stream);
 
+/* Training-side conditioning prelude with explicit adjoints (a few fused launches instead of ~280 torch elementwise
+ * launches on kilobyte-sized tensors per step):
+ * oniris_gates_bwd: adjoint of oniris_gates, dparams [L][6] from dca, dcb [L][N] (Gating, edm2/conv.py:113-127);
+ * oniris_emb_scale: c [N][Ctot] fp32 = 1 + c_all * gain[seg[j]] for every Block at once (networks_edm2.py:78; c_all
+ *   [N][Ctot] bf16 = the row-concatenated emb_linear GEMM, seg [Ctot] = Block of column j, gain [K] = the emb_gain's);
+ *   oniris_emb_scale_bwd: dc_all bf16 and dgain [K] from dc (start [K+1] = first column of each Block);
+ * oniris_embed_pre: the inputs of the embedding linears, four [N][cnoiseP] bf16 = MPFourier(c_noise) (utils.py:139-150),
+ *   onehot [N][labelP] bf16 = one_hot(labels) * sqrt(L) (networks_edm2.py:209; NULL = no labels), zero-padded columns;
+ * oniris_embed_post: emb = mp_silu(mp_sum(e1, e2, t)) (networks_edm2.py:210-212; e2 NULL: mp_silu(e1)), bf16 [n];
+ *   oniris_embed_post_bwd: its adjoint (de1, de2 from demb).                                                          */
+int oniris_gates_bwd(const float* c_noise, const float* params, const int32_t* nctx, const float* dca, const float* dcb,
+                     float* dparams, int L, int N, int T, oniris_stream_t stream);
+int oniris_emb_scale(const void* c_all, const float* gain, const int32_t* seg, float* c, int N, int Ctot,
+                     oniris_stream_t stream);
+int oniris_emb_scale_bwd(const float* dc, const void* c_all, const float* gain, const int32_t* start, void* dc_all,
+                         float* dgain, int N, int Ctot, int K, oniris_stream_t stream);
+int oniris_embed_pre(const float* c_noise, const int64_t* labels, const float* freqs, const float* phases, void* four,
+                     void* onehot, int N, int cnoise, int cnoiseP, int label_dim, int labelP, oniris_stream_t stream);
+int oniris_embed_post(const void* e1, const void* e2, void* emb, size_t n, float t, oniris_stream_t stream);
+int oniris_embed_post_bwd(const void* demb, const void* e1, const void* e2, void* de1, void* de2, size_t n, float t,
+                          oniris_stream_t stream);
+
 /* Fused AdamW over flat fp32 buffers (the optimizer step of gym_train.py:105-106 / cs_train.py:117-118).       */
 int oniris_adamw(float* p, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2,
                  float eps, float weight_decay, int step, float grad_scale, oniris_stream_t stream);

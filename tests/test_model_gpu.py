@@ -230,6 +230,51 @@ def test_fused_dart_loss_matches_eager_path(mode, monkeypatch):
     assert abs(og1 - og0) <= 2e-2 * abs(og0) + 1e-6
 
 
+@pytest.mark.parametrize("mode", ["3d", "2d"])
+def test_fused_prelude_matches_torch_formulation(mode, monkeypatch):
+    """Gates / embedding / emb scales through the fused launches with hand-written adjoints (oniris_gates[_bwd],
+    oniris_embed_pre / _post[_bwd], oniris_emb_scale[_bwd]) against the torch-autograd formulation of the same math:
+    loss and every gradient, the scalar parameters (gating, emb_gain) included."""
+    from autoregressive_diffusion_amd import ops
+    import edm2.loss as L
+    g = torch.Generator().manual_seed(5)
+    B, Tn = 2, 4
+    images = torch.randn(B, Tn, 8, 64, 64, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (B, Tn), generator=g).to(DEV)
+    n = Tn if mode == "2d" else 2 * Tn
+    sigma = (torch.randn(B, n, generator=g) + 0.4).exp().to(DEV)
+    eps = torch.randn(B, n, 8, 64, 64, generator=g).to(DEV)
+    res = {}
+    for fused in (1, 0):
+        monkeypatch.setattr(ops, "FUSED_PRELUDE", fused)
+        net = build_precond(C1_CFG, 33, 1.0).train()
+        gp = torch.Generator().manual_seed(6)
+        with torch.no_grad():                      # away from the initial values: every adjoint term is exercised
+            for k, p in net.named_parameters():
+                if "gating" in k or k.endswith("emb_gain"):
+                    p.add_(torch.randn(p.shape, generator=gp).to(DEV) * 0.5)
+        loss, unw = L.EDM2Loss(sigma_data=1.0)(net, images, labels, sigma=sigma, just_2d=(mode == "2d"), noise=eps)
+        loss.backward()
+        res[fused] = (loss.item(), {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None})
+    assert abs(res[1][0] - res[0][0]) <= 2e-3 * abs(res[0][0]), (res[1][0], res[0][0])
+    assert set(res[1][1]) == set(res[0][1]), set(res[1][1]) ^ set(res[0][1])
+    small = {k: v for k, v in res[0][1].items() if v.numel() <= 2}
+    smax = {kind: max(float(v.abs().max()) for k, v in small.items() if kind in k) for kind in ("gating", "emb_gain")
+            if any(kind in k for k in small)}
+    worst = {}
+    for k, v in res[0][1].items():
+        if v.numel() > 2:
+            if float(v.abs().max()) > 0:
+                worst["weights"] = max(worst.get("weights", 0.0), rel(res[1][1][k], v))
+        else:
+            kind = "gating" if "gating" in k else "emb_gain" if "emb_gain" in k else "other"
+            scale = smax.get(kind, float(v.abs().max()) + 1e-12)
+            worst[kind] = max(worst.get(kind, 0.0), float((res[1][1][k] - v).abs().max()) / scale)
+    print("fused prelude vs torch formulation", mode, "loss", res[1][0], res[0][0], "worst", worst)
+    assert worst["weights"] < 2e-2, worst
+    assert all(v < 2e-2 for k, v in worst.items() if k != "weights"), worst        # of the largest gradient of the class
+
+
 def test_g9_sampler_rollout():
     from edm2.sampler import edm_sampler_with_mse
     z = load("g9_sampler")
@@ -593,8 +638,10 @@ def test_hipgraph_gradients_match_eager_after_consecutive_3d_replays():
         for k, gk in enumerate(got):
             d = (gk[o:o + p.numel()] - w).abs().max().item()
             # fp32 atomics re-order between launches, nothing more; the scalar parameters (gates, emb_gain) are sums of
-            # cancelling terms (3 % class tolerance) -- a missing arena fill shows as 100 %, 200 % ...
-            tol = (2e-2 if kind in ("gating", "emb_gain") else 2e-3) * w.abs().max().item() + 1e-5 * scale
+            # cancelling terms (3 % class tolerance) -- a missing arena fill shows as 100 %, 200 % ...;
+            # the embedding weights sit behind bf16 roundings of atomically summed values (dc -> dc_all -> demb): a
+            # re-ordered sum flips a few bf16 ulps
+            tol = (2e-2 if kind in ("gating", "emb_gain") else 5e-3 if kind == "emb_linear" else 2e-3) * w.abs().max().item() + 1e-5 * scale
             worst[kind] = max(worst.get(kind, 0.0), d / (tol + 1e-30))
     print("graph vs eager gradient, worst |diff| / tolerance per class:", {k: round(v, 3) for k, v in worst.items()})
     assert all(v <= 1.0 for v in worst.values()), worst
