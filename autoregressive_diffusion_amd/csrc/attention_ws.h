@@ -152,9 +152,14 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws_kernel(const AttnDev d) {
   f32x16 zero16;
 #pragma unroll
   for (int i = 0; i < 16; ++i) zero16[i] = 0.f;
-  bf16x8 sel[2];                                   // row selectors of the row-sum MFMA (see pv below)
+  // A operand of the row-sum MFMA (see pv below): a 16x16x32 MFMA reads the P fragment of a 32x32x16 B operand (lane =
+  // (query n, key half kb)) as k-block 2 kb + n / 16 of column n % 16; rows 4 g .. 4 g + 3 of A select the k-blocks with
+  // parity g & 1, so that D row-group g of column n' holds sum_k P[k][n' + 16 (g & 1)] -- and D row-group g is what lanes
+  // 16 g .. 16 g + 15 receive: every lane gets the row sum of its own query lane & 31.
+  bf16x8 sel16;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { sel[0][e] = f2bf(r < 16 ? 1.f : 0.f); sel[1][e] = f2bf(r < 16 ? 0.f : 1.f); }
+  for (int e = 0; e < 8; ++e) sel16[e] = f2bf((((lane >> 4) ^ ((lane & 15) >> 2)) & 1) ? 0.f : 1.f);
+  typedef __attribute__((ext_vector_type(4))) float f32x4_;
 
   int item = item_at(0);
   WS_STAMP_DECL
@@ -174,9 +179,12 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws_kernel(const AttnDev d) {
     const int last_e = __builtin_amdgcn_readfirstlane(a.kv_idx[(size_t)trow * a.tab_cols + ((nblk - 1) >> d.tshift)]);
     const int last_key0 = ((last_e << d.tshift) + ((nblk - 1) & tmask)) * 128 + 64 * st;
 
-    f32x16 o[2][2], osum;                           // osum: row sums of P (rows 0..15: query block 0, 16..31: block 1)
+    f32x16 o[2][2];
+    f32x4_ osum[2];                                 // row sums of P of query block x (all four registers hold the lane's row)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][0][i] = 0.f; o[0][1][i] = 0.f; o[1][0][i] = 0.f; o[1][1][i] = 0.f; osum[i] = 0.f; }
+    for (int i = 0; i < 16; ++i) { o[0][0][i] = 0.f; o[0][1][i] = 0.f; o[1][0][i] = 0.f; o[1][1][i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { osum[0][i] = 0.f; osum[1][i] = 0.f; }
 
     auto load_k = [&](bf16x8 (&kf)[4], const unsigned char* S0, int kt) __attribute__((always_inline)) {
 #pragma unroll
@@ -220,16 +228,16 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws_kernel(const AttnDev d) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) pb[s2][e] = f2bf(__builtin_amdgcn_exp2f(s[8 * s2 + e]));
     };
-    // P.V of a micro-step + its row sums ON THE MATRIX PIPE: the A operand `sel[x]` is all ones in rows 16 x .. 16 x + 15
-    // and zero elsewhere, so rows 16 x .. of osum accumulate sum_k P[k][query] -- the 16 adds per lane and micro-step
-    // they replace (hipcc pairs them into v_pk_add_f32, ~4x the issue cost of a plain add beside MFMAs) were a third
-    // of the VALU issue time of the loop, and the matrix pipe has the room (40 instead of 32 MFMAs per block).
+    // P.V of a micro-step + its row sums ON THE MATRIX PIPE (a 4-pass 16x16x32 MFMA against the selector `sel16`): the 16
+    // adds per lane and micro-step they replace (hipcc pairs them into v_pk_add_f32, ~4x the issue cost of a plain add
+    // beside MFMAs) were a third of the VALU issue time of the loop, and the matrix pipe has the room (32 full + 8 half
+    // MFMAs per block).
     auto pv = [&](bf16x8 (&vf)[2][2], bf16x8 (&pb)[2], int x) __attribute__((always_inline)) {
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) o[x][dt] = mfma32(vf[s2][dt], pb[s2], o[x][dt]);
-        osum = mfma32(sel[x], pb[s2], osum);
+        osum[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(sel16, pb[s2], osum[x], 0, 0, 0);
       }
     };
 
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(512, 2) void attn_fwd_ws_kernel(const AttnDev d) {
 
     // ---- epilogue: wave (qw, st) finishes query block x = st; the other one's partial (O, l) goes to its SIMD-pair
     // partner (qw, 1 - st) through ring slot 3 (8 KB per wave) / the item's Q tile (row sums)
-    const float l[2] = {osum[0], osum[8]};          // accumulator rows 0..3 (+4h) / 16..19 (+4h): any row of the block
+    const float l[2] = {osum[0][0], osum[1][0]};
     float* red = (float*)(smem + 3 * SLOT) + wave * 2048 + le;        // this wave's 32 x 64 floats
     float* lred = (float*)(smem + QOFF + (it & 1) * QTILE) + le;      // [4 waves][64]
     __syncthreads();                               // E1: every compute wave is done with the ring and the Q tile
