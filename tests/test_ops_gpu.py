@@ -587,3 +587,69 @@ def test_eval_side_kernels_match_torch_formulation():
     Fn = Fcl[..., :C].float().permute(0, 3, 1, 2).reshape(Bx, tx, C, H, H) * og
     wantD = (sd ** 2 / den)[:, :, None, None, None] * x + (sg * sd / den.sqrt())[:, :, None, None, None] * Fn
     assert torch.allclose(D, wantD, atol=1e-5, rtol=1e-5)
+
+
+def test_prelude_kernels_and_adjoints_match_torch_autograd():
+    """oniris_gates_bwd, oniris_emb_scale[_bwd], oniris_embed_pre / _post[_bwd] against torch autograd on the reference
+    formulas (conv.py:113-127 training layout, networks_edm2.py:78, :204-212): values and every gradient."""
+    from autoregressive_diffusion_amd import ops
+    from edm2.utils import MPFourier, mp_sum, mp_silu
+    torch.manual_seed(12)
+    # ---- gates, training layout: B = 2, 2T = 8 slots, T = 4 positions, 5 layers, frame counters 0 / 3
+    B, T, L = 2, 4, 5
+    P = (torch.randn(L, 6, device=DEV) * 0.7).requires_grad_(True)         # mult0, mult1, off0, off1, min, max
+    c_noise = torch.randn(B, 2 * T, device=DEV)
+    nctx = torch.tensor([0, 3, 0, 3, 1], dtype=torch.int32, device=DEV)
+    ca, cb = ops.gates_train(c_noise.reshape(-1).contiguous(), P, nctx, T)
+    ra, rb = torch.randn_like(ca), torch.randn_like(cb)
+    (ca * ra + cb * rb).sum().backward()
+    got_g, P.grad = P.grad.clone(), None
+    pos = ((torch.arange(B * 2 * T, device=DEV) % T)[None] + nctx[:, None]).float().log1p()
+    sv = c_noise.reshape(1, -1) * P[:, 0:1] + P[:, 2:3] + pos * P[:, 1:2] + P[:, 3:4]
+    lo, hi = torch.sigmoid(P[:, 4:5]), torch.sigmoid(P[:, 5:6])
+    g = lo + (1 - lo) * hi * torch.sigmoid(sv)
+    wa, wb = ops.gate_coefs(g)
+    assert torch.allclose(ca, wa, atol=2e-6, rtol=1e-5) and torch.allclose(cb, wb, atol=2e-6, rtol=1e-5)
+    (wa * ra + wb * rb).sum().backward()
+    assert torch.allclose(got_g, P.grad, atol=1e-5, rtol=1e-4), (got_g - P.grad).abs().max()
+    # ---- emb scales: 3 blocks of 64 / 128 / 64 columns (64-aligned: no pad columns), N = 7 rows
+    N, widths = 7, [64, 128, 64]
+    Ct, K = sum(widths), len(widths)
+    seg = torch.tensor([k for k, w in enumerate(widths) for _ in range(w)], dtype=torch.int32, device=DEV)
+    start = torch.tensor([0, 64, 192, 256], dtype=torch.int32, device=DEV)
+    c_all = torch.randn(N, Ct, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    gain = torch.randn(K, device=DEV).requires_grad_(True)
+    c = ops._EmbScaleFn.apply(c_all, gain, seg, start)
+    rc = torch.randn_like(c)
+    (c * rc).sum().backward()
+    got_dc, got_dg = c_all.grad.clone(), gain.grad.clone()
+    c_all.grad = gain.grad = None
+    want = 1 + c_all.float() * gain[seg.long()][None]
+    assert torch.allclose(c, want, atol=1e-6, rtol=1e-6)
+    (want * rc).sum().backward()
+    assert rel(got_dc, c_all.grad) < 4e-3 and torch.allclose(got_dg, gain.grad, atol=1e-4, rtol=1e-4)
+    # ---- embedding pre / post
+    Ne, cn, Ld = 6, 12, 4                                               # (cn, Ld not multiples of 8: padded columns)
+    four = MPFourier(cn).to(DEV)
+    cnz, lab = torch.randn(Ne, device=DEV), torch.randint(0, Ld, (Ne,), device=DEV)
+    f_ = torch.empty(Ne, 16, dtype=torch.bfloat16, device=DEV)
+    oh = torch.empty(Ne, 8, dtype=torch.bfloat16, device=DEV)
+    from autoregressive_diffusion_amd._lib import lib, check
+    check(lib.oniris_embed_pre(cnz.data_ptr(), lab.data_ptr(), four.freqs.data_ptr(), four.phases.data_ptr(), f_.data_ptr(),
+                               oh.data_ptr(), Ne, cn, 16, Ld, 8, ops._stream()), "embed_pre")
+    assert rel(f_[:, :cn], four(cnz)) < 4e-3 and float(f_[:, cn:].abs().max()) == 0.0
+    assert torch.equal(oh[:, :Ld].float(), torch.nn.functional.one_hot(lab, Ld).float() * 2.0) and float(oh[:, Ld:].abs().max()) == 0.0
+    for with_e2 in (True, False):
+        e1 = torch.randn(Ne, 64, device=DEV).to(torch.bfloat16).requires_grad_(True)
+        e2 = torch.randn(Ne, 64, device=DEV).to(torch.bfloat16).requires_grad_(True) if with_e2 else None
+        emb = ops._EmbedPostFn.apply(e1, e2, 1 / 3)
+        re_ = torch.randn(Ne, 64, device=DEV).to(torch.bfloat16)
+        (emb.float() * re_.float()).sum().backward()
+        g1, g2 = e1.grad.clone(), (e2.grad.clone() if with_e2 else None)
+        e1.grad = None
+        if with_e2:
+            e2.grad = None
+        want = mp_silu(mp_sum(e1.float(), e2.float(), t=1 / 3)) if with_e2 else mp_silu(e1.float())
+        assert rel(emb, want) < 4e-3
+        (want * re_.float()).sum().backward()
+        assert rel(g1, e1.grad) < 6e-3 and (not with_e2 or rel(g2, e2.grad) < 6e-3)
