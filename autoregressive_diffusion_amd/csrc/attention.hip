@@ -798,6 +798,90 @@ __global__ void qkv_norm_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __
   *(bf16x8*)(dqkv + tok * 3 * C + (size_t)vi * 64 + part * 8) = o;
 }
 
+// qkv_norm_kernel + the rotary embedding of q and k in one pass (training: position = (token / P) mod pos_mod; tables
+// [pos][64] fp32: cos, sin, scale, scale duplicated over the two halves like RoPe.py:21-32).  The rotation partner of
+// channel c is c ^ 32 = the same register of lane ^ 4 (8 lanes x 8 channels cover a head).  The normalised value is
+// rotated in fp32: q, k are rounded to bf16 once (the two-kernel path rounds the normalised vector first).
+//   q' = log2(e)/8 * (u cos + rot(u) sin) * scale,   k' = (u cos + rot(u) sin) / scale,   v' = u      (u = x/(eps+|x|/8))
+__global__ void qkv_norm_rope_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ q, bf16* __restrict__ k,
+                                     bf16* __restrict__ v, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                     const float* __restrict__ scale_t, long long nvec, int C, int P, int pos_mod) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vec = gid >> 3;
+  const int part = (int)(gid & 7);
+  if (vec >= nvec) return;                            // (nvec * 8 is a multiple of 64: whole waves leave together)
+  const int hpt = 3 * C / 64;
+  const long long tok = vec / hpt;
+  const int vi = (int)(vec % hpt);
+  const int s = vi / (C / 64), hd = vi % (C / 64);
+  const bf16x8 x = *(const bf16x8*)(qkv + tok * 3 * C + (size_t)vi * 64 + part * 8);
+  float f[8], ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { f[i] = bf2f(x[i]); ss += f[i] * f[i]; }
+  ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+  const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
+  const size_t tb = (size_t)((tok / P) % pos_mod) * 64 + part * 8;
+  const float sg = (part < 4) ? -1.f : 1.f;          // rotate_half: [-x2, x1]
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float u = f[i] * inv;
+    const float up = __shfl_xor(u, 4);                // (every lane of the 8-lane group takes part: no divergence above)
+    float val = u;
+    if (s != 2) {
+      val = u * cos_t[tb + i] + sg * up * sin_t[tb + i];
+      const float scl = scale_t[tb + i];
+      val = (s == 0) ? val * scl : val / scl;
+    }
+    o[i] = f2bf(val);
+  }
+  bf16* dst = (s == 0) ? q : (s == 1) ? k : v;
+  *(bf16x8*)(dst + tok * C + hd * 64 + part * 8) = o;
+}
+
+// adjoint of qkv_norm_rope_kernel: dq (w.r.t. the UNSCALED rotated q, as the attention backward returns it), dk, dv ->
+// dqkv.  R^T g = g cos - rot(g sin) and the scale vector is equal in both halves, so it commutes with the rotation.
+__global__ void qkv_norm_rope_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dq,
+                                         const bf16* __restrict__ dk, const bf16* __restrict__ dv, bf16* __restrict__ dqkv,
+                                         const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+                                         const float* __restrict__ scale_t, long long nvec, int C, int P, int pos_mod) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vec = gid >> 3;
+  const int part = (int)(gid & 7);
+  if (vec >= nvec) return;
+  const int hpt = 3 * C / 64;
+  const long long tok = vec / hpt;
+  const int vi = (int)(vec % hpt);
+  const int s = vi / (C / 64), hd = vi % (C / 64);
+  const bf16x8 x = *(const bf16x8*)(qkv + tok * 3 * C + (size_t)vi * 64 + part * 8);
+  const bf16* gsrc = (s == 0) ? dq : (s == 1) ? dk : dv;
+  const bf16x8 g = *(const bf16x8*)(gsrc + tok * C + hd * 64 + part * 8);
+  const size_t tb = (size_t)((tok / P) % pos_mod) * 64 + part * 8;
+  const float sg = (part < 4) ? 1.f : -1.f;          // adjoint of rotate_half
+  float f[8], gg[8], ss = 0.f, dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    f[i] = bf2f(x[i]);
+    float gv = bf2f(g[i]);
+    if (s != 2) {
+      const float scl = scale_t[tb + i];
+      gv = (s == 0) ? gv * scl : gv / scl;
+    }
+    const float gs = (s != 2) ? gv * sin_t[tb + i] : 0.f;
+    const float gp = __shfl_xor(gs, 4);               // (g sin) of the partner channel
+    gg[i] = (s != 2) ? gv * cos_t[tb + i] + sg * gp : gv;
+    ss += f[i] * f[i]; dot += f[i] * gg[i];
+  }
+  ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+  dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+  const float n = sqrtf(ss), sden = 1e-4f + n * 0.125f;
+  const float k1 = 1.f / sden, k2 = (n > 0.f) ? dot * 0.125f / (sden * sden * n) : 0.f;
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f2bf(gg[i] * k1 - f[i] * k2);
+  *(bf16x8*)(dqkv + tok * 3 * C + (size_t)vi * 64 + part * 8) = o;
+}
+
 // rotary embedding over the frame index (+ optional transposed copy); one workgroup = 64 tokens x 1 head
 __global__ __launch_bounds__(256) void rope_kernel(const bf16* __restrict__ x, bf16* __restrict__ xr,
                                                    bf16* __restrict__ xt, const float* __restrict__ cos_t,
@@ -1016,6 +1100,31 @@ extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t s
                        (const float*)d.a.dkv_part, (bf16*)d.a.dk, (bf16*)d.a.dv, n8, nch);
     ONIRIS_LAUNCH_CHECK();
   }
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_qkv_norm_rope(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,
+                                    const float* scale_t, int64_t n_tokens, int C, int P, int pos_mod, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(qkv && q && k && v && cos_t && sin_t && scale_t && n_tokens > 0 && C > 0 && C % 64 == 0 && P > 0 && pos_mod > 0,
+                   "qkv_norm_rope: bad arguments");
+  const long long nvec = (long long)n_tokens * 3 * C / 64;
+  hipLaunchKernelGGL(qkv_norm_rope_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
+                     (bf16*)q, (bf16*)k, (bf16*)v, cos_t, sin_t, scale_t, nvec, C, P, pos_mod);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_qkv_norm_rope_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv,
+                                        const float* cos_t, const float* sin_t, const float* scale_t, int64_t n_tokens, int C,
+                                        int P, int pos_mod, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(qkv && dq && dk && dv && dqkv && cos_t && sin_t && scale_t && n_tokens > 0 && C > 0 && C % 64 == 0 && P > 0 &&
+                   pos_mod > 0, "qkv_norm_rope_bwd: bad arguments");
+  const long long nvec = (long long)n_tokens * 3 * C / 64;
+  hipLaunchKernelGGL(qkv_norm_rope_bwd_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
+                     (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (bf16*)dqkv, cos_t, sin_t, scale_t, nvec, C, P, pos_mod);
+  ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
 

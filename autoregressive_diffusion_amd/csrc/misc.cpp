@@ -19,7 +19,7 @@ void oniris_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* oniris_last_error(void) { return g_err; }
-extern "C" int oniris_abi_version(void) { return 5; }
+extern "C" int oniris_abi_version(void) { return 6; }
 
 // ---- mask tables (reference: edm2/attention/attention_masking.py:27-53, 64-90); 128 = flex default block
 static const int kFlexBlock = 128;

@@ -367,6 +367,7 @@ class WeightBank:
 
 import os as _os
 WGRAD_SIDE_STREAM = int(_os.environ.get("ONIRIS_WGRAD_STREAM", "0"))   # opt-in: weight-gradient kernels on a second HIP stream (measured: 1-2 % slower, the LDS-filling kernels cannot share a CU)
+FUSED_ROPE = int(_os.environ.get("ONIRIS_FUSED_ROPE", "1"))        # 0: qkv normalisation and the two rotations as three launches (A/B, tests)
 ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
 ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
 WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
@@ -1133,7 +1134,9 @@ class _AttentionFn(torch.autograd.Function):
         dev = qkv.device
         q = torch.empty((N, P, C), dtype=BF16, device=dev)
         k, v = torch.empty_like(q), torch.empty_like(q)
-        check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, 0, 0, 0, _stream()), "qkv_norm")
+        fused_rope = kind == "video" and FUSED_ROPE
+        if not fused_rope:
+            check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, 0, 0, 0, _stream()), "qkv_norm")
         if kind == "video":
             frames = N // B
             Bq, L = B, frames * P
@@ -1145,7 +1148,12 @@ class _AttentionFn(torch.autograd.Function):
         else:
             frames, Bq, L = 1, N, P
             tabs_r, mask_mode, tabs = None, 0, None
-        if kind == "video":
+        if fused_rope:              # normalisation + rotation in one pass over qkv (frames = 2T: position = frame mod T)
+            cs_, sn_, sc_ = tabs_r
+            check(lib.oniris_qkv_norm_rope(_p(qkv), _p(q), _p(k), _p(v), _p(cs_), _p(sn_), _p(sc_), N * P, C, P, T, _stream()),
+                  "qkv_norm_rope")
+            qr, kr = q, k
+        elif kind == "video":
             qr, kr = torch.empty_like(q), torch.empty_like(k)
             _rope(q, qr, None, tabs_r, 1, Bq, frames, P, C, 0, T)
             _rope(k, kr, None, tabs_r, 2, Bq, frames, P, C, 0, T)
@@ -1192,14 +1200,19 @@ class _AttentionFn(torch.autograd.Function):
             a.dkv_part, a.dkv_chunks = _p(part), nch
         _profiled(f"attn_bwd_dkv_kernel<MODE={mask_mode}>", 2.0 * fl,
                   lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))     # (+ the partial-sum reduce)
+        dqkv = torch.empty_like(qkv)
+        N = qkv.shape[0]
+        if kind == "video" and FUSED_ROPE:
+            cs_, sn_, sc_ = ctx.tabs_r
+            check(lib.oniris_qkv_norm_rope_bwd(_p(qkv), _p(dq), _p(dk), _p(dv), _p(dqkv), _p(cs_), _p(sn_), _p(sc_), N * P, C, P, T,
+                                               _stream()), "qkv_norm_rope_bwd")
+            return dqkv, None, None, None, None, None, None
         if kind == "video":
             dqn, dkn = torch.empty_like(dq), torch.empty_like(dk)
             _rope(dq, dqn, None, ctx.tabs_r, 3, Bq, frames, P, C, 0, T)
             _rope(dk, dkn, None, ctx.tabs_r, 4, Bq, frames, P, C, 0, T)
         else:
             dqn, dkn = dq, dk
-        dqkv = torch.empty_like(qkv)
-        N = qkv.shape[0]
         check(lib.oniris_qkv_norm_bwd(_p(qkv), _p(dqn), _p(dkn), _p(dv), _p(dqkv), N * P, C, _stream()), "qkv_norm_bwd")
         return dqkv, None, None, None, None, None, None
 

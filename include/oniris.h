@@ -288,6 +288,14 @@ int oniris_qkv_norm(const void* qkv, void* q, void* k, void* v, int64_t n_tokens
                     int64_t kv_batch_stride, int64_t kv_token_offset, oniris_stream_t stream);
 int oniris_qkv_norm_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv,
                         int64_t n_tokens, int C, oniris_stream_t stream);
+/* The same with the rotary embedding of q and k fused in (VideoAttention in training, RoPe.py:43-68: position of a token
+ * = (token / P) mod pos_mod; cos / sin / scale tables [pos][64] fp32): q, k leave rotated (q also carries the softmax
+ * scale), one bf16 rounding; the _bwd takes the attention backward's dq, dk, dv and returns dqkv.                       */
+int oniris_qkv_norm_rope(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,
+                         const float* scale_t, int64_t n_tokens, int C, int P, int pos_mod, oniris_stream_t stream);
+int oniris_qkv_norm_rope_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv,
+                             const float* cos_t, const float* sin_t, const float* scale_t, int64_t n_tokens, int C, int P,
+                             int pos_mod, oniris_stream_t stream);
 int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const float* sin_t, const float* scale_t,
                 int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod,
                 int64_t x_batch_stride /* elements between the sequences of x (KV ring); 0 = frames*P*C */,

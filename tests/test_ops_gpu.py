@@ -317,6 +317,29 @@ def test_video_attention_core_train(B, T, H, m, chunks, persistent, monkeypatch)
     assert e[0] < 1e-2 and e[1] < 2.5e-2
 
 
+def test_fused_qkv_norm_rope_matches_three_launch_path(monkeypatch):
+    """oniris_qkv_norm_rope[_bwd] (normalisation + both rotations in one pass, one bf16 rounding) against oniris_qkv_norm +
+    2 x oniris_rope (+ their adjoints): same attention output and qkv gradient up to the skipped intermediate rounding."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(8)
+    B, T, H, m = 2, 8, 8, 2
+    C, P, N = 64 * m, H * H, B * 2 * T
+    inv = (1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))).to(DEV)
+    sc = ((torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)).to(DEV)
+    x0 = torch.randn(N, P, 3 * C, device=DEV).to(torch.bfloat16)
+    go = torch.randn(N, P, C, device=DEV).to(torch.bfloat16)
+    res = {}
+    for fused in (1, 0):
+        monkeypatch.setattr(ops, "FUSED_ROPE", fused)
+        x = x0.clone().requires_grad_(True)
+        out = ops.attention_train(x, "video", B, T, m, (inv, sc))
+        out.backward(go)
+        res[fused] = (out.detach().float(), x.grad.float())
+    e = (rel(res[1][0], res[0][0]), rel(res[1][1], res[0][1]))
+    print("fused qkv_norm+rope vs three launches: rel out / dqkv", e)
+    assert e[0] < 6e-3 and e[1] < 1e-2
+
+
 def test_frame_attention_core_train():
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(6)
