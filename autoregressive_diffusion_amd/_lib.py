@@ -70,6 +70,8 @@ _SIGS = {
     "oniris_last_error": (C.c_char_p, []),
     "oniris_abi_version": (c_int, []),
     "oniris_struct_sizes": (c_int, [c_void_p]),
+    "oniris_profile_arm": (c_int, [c_void_p, c_void_p]),
+    "oniris_profile_disarm": (c_int, []),
     "oniris_train_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_infer_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_mask_transpose": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

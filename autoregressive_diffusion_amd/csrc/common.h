@@ -1,6 +1,7 @@
 // Shared device/host helpers for liboniris_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -39,6 +40,20 @@ void oniris_set_error(const char* fmt, ...);
       return ONIRIS_ELAUNCH;                                             \
     }                                                                    \
   } while (0)
+
+// Measurement aid (oniris_profile_arm, misc.cpp): when a start / stop event pair is armed, the next kernel this thread
+// launches through oniris_launch records its OWN begin and end into them (hipExtLaunchKernel: the timestamps of the
+// dispatch itself, what rocprofv3 reports) -- bracketing events on the stream also time the ~2 us of kernel boundary.
+extern thread_local hipEvent_t oniris_prof_ev[2];
+template <typename K, typename... A>
+static inline void oniris_launch(K kern, dim3 grid, dim3 block, hipStream_t stream, A... args) {
+  if (oniris_prof_ev[0]) {
+    hipExtLaunchKernelGGL(kern, grid, block, 0, stream, oniris_prof_ev[0], oniris_prof_ev[1], 0, args...);
+    oniris_prof_ev[0] = oniris_prof_ev[1] = nullptr;
+  } else {
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, args...);
+  }
+}
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return cdiv(a, b) * b; }

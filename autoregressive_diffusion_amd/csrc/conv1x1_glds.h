@@ -233,7 +233,7 @@ static int launch_conv1x1_glds(const OnirisConvArgs& a, hipStream_t stream) {
       ncu = 256;
   }
   const long long nblk = ntiles < ncu ? ntiles : ncu;
-  hipLaunchKernelGGL(conv1x1_glds_kernel, dim3((unsigned)nblk), dim3(C1Cfg::NTHR), 0, stream, d);
+  oniris_launch(conv1x1_glds_kernel, dim3((unsigned)nblk), dim3(C1Cfg::NTHR), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

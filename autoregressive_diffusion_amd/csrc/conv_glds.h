@@ -516,7 +516,7 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
   }
   const long long nblk = ntiles < ncu ? ntiles : ncu;
   auto kern = conv_glds_kernel<NT, PW, NW, MT, WC, CTX, RES>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
+  oniris_launch(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

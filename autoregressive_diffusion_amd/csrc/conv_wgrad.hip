@@ -289,13 +289,13 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
     if (use_glds) {
       constexpr int NG = 2;
       auto kern = conv_wgrad_glds_kernel<CT, IT, NG, PW>;
-      hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256 * NG), 0, stream, d);
+      oniris_launch(kern, dim3(gx_tot, gy), dim3(256 * NG), stream, d);
       ONIRIS_LAUNCH_CHECK();
       return ONIRIS_OK;
     }
   }
   auto kern = conv_wgrad_kernel<TAPS, PW, CT, IT>;
-  hipLaunchKernelGGL(kern, dim3(gx_tot, gy), dim3(256), 0, stream, d);
+  oniris_launch(kern, dim3(gx_tot, gy), dim3(256), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -19,7 +19,20 @@ void oniris_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* oniris_last_error(void) { return g_err; }
-extern "C" int oniris_abi_version(void) { return 6; }
+
+thread_local hipEvent_t oniris_prof_ev[2] = {nullptr, nullptr};
+extern "C" int oniris_profile_arm(void* start_event, void* stop_event) {
+  ONIRIS_CHECK_ARG(start_event && stop_event, "profile_arm: null event");
+  oniris_prof_ev[0] = (hipEvent_t)start_event;
+  oniris_prof_ev[1] = (hipEvent_t)stop_event;
+  return ONIRIS_OK;
+}
+extern "C" int oniris_profile_disarm(void) {          // 1: the pair was still armed (no launch consumed it), 0: consumed
+  const int armed = oniris_prof_ev[0] != nullptr;
+  oniris_prof_ev[0] = oniris_prof_ev[1] = nullptr;
+  return armed;
+}
+extern "C" int oniris_abi_version(void) { return 7; }
 
 // ---- mask tables (reference: edm2/attention/attention_masking.py:27-53, 64-90); 128 = flex default block
 static const int kFlexBlock = 128;

@@ -169,7 +169,7 @@ static int launch_wgrad1x1_glds(const OnirisWgradArgs& a, hipStream_t stream) {
   if (gx * NG > ntiles) gx = (ntiles + NG - 1) / NG;
   if (gx < 1) gx = 1;
   auto kern = wgrad1x1_glds_kernel<NG>;
-  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(256 * NG), 0, stream, d);
+  oniris_launch(kern, dim3(gx, gy), dim3(256 * NG), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

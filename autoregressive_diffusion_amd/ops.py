@@ -375,8 +375,8 @@ BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (
 
 
 class KernelProfile:
-    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg).  Events are recorded on
-    the stream the kernel is launched on (torch's current stream)."""
+    """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg), on the stream the kernel is
+    launched on (torch's current stream): see _timed_launch."""
     enabled = False
     records = []          # (key, algorithmic flops, start_event, end_event)
 
@@ -398,14 +398,27 @@ class KernelProfile:
         return agg
 
 
-def _profiled(key, flops, fn):
-    """Run fn() (a kernel launch on the current stream); when KernelProfile is on, bracket it with HIP events."""
-    if not KernelProfile.enabled:
-        return fn()
+def _timed_launch(fn):
+    """fn() = ONE kernel launch on the current stream; returns (start, end) HIP events.  The pair is armed in the library
+    (oniris_profile_arm): launch sites with the hook record the dispatch's own begin / end into it (what rocprofv3 reports
+    as the kernel's duration); entry points without the hook leave it armed and get events recorded around the call."""
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    fn()
-    e1.record()
+    e1.record()                                    # (creates the handles; both are recorded again below)
+    check(lib.oniris_profile_arm(e0.cuda_event, e1.cuda_event), "profile_arm")
+    try:
+        fn()
+    finally:
+        if lib.oniris_profile_disarm():
+            e1.record()
+    return e0, e1
+
+
+def _profiled(key, flops, fn):
+    """Run fn() (a kernel launch on the current stream); when KernelProfile is on, time it with HIP events."""
+    if not KernelProfile.enabled:
+        return fn()
+    e0, e1 = _timed_launch(fn)
     KernelProfile.records.append((key, flops, e0, e1))
 
 
@@ -443,15 +456,13 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
             key = "conv1x1_glds_kernel"
         else:
             key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         KernelProfile.enabled = False
         try:
-            _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP, Cout, CoutP, taps,
-                         ctx_bstride, ctx_T, coff, ctx_fill, epi, res, escale, emb_gain, out2, ta, tb, clip, ctx_out)
+            e0, e1 = _timed_launch(lambda: _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP,
+                                                        Cout, CoutP, taps, ctx_bstride, ctx_T, coff, ctx_fill, epi, res, escale,
+                                                        emb_gain, out2, ta, tb, clip, ctx_out))
         finally:
             KernelProfile.enabled = True
-        e1.record()
         KernelProfile.records.append((key, flops, e0, e1))
         return
     a = _lib.ConvArgs()
@@ -514,14 +525,11 @@ def _wgrad_launch_group(arglist, keep=None):
         else:
             key = f"conv_wgrad_kernel<TAPS={a0.taps},PW={_patch_w(a0.W)},CT={tile},IT={tile}>"
         flops = sum(2.0 * a.B * a.T * a.H * a.W * a.Cout * a.Cin * a.taps for a in arglist)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
         KernelProfile.enabled = False
         try:
-            _wgrad_launch_group(arglist)          # (profiled launches stay on the main stream)
+            e0, e1 = _timed_launch(lambda: _wgrad_launch_group(arglist))          # (profiled launches stay on the main stream)
         finally:
             KernelProfile.enabled = True
-        e1.record()
         KernelProfile.records.append((key, flops, e0, e1))
         return
     arr = (_lib.WgradArgs * len(arglist))(*arglist)

@@ -24,6 +24,12 @@ typedef void* oniris_stream_t;
 
 const char* oniris_last_error(void);
 int oniris_abi_version(void);
+/* Measurement aid: arm a pair of HIP events (hipEvent_t created with timing); the next MFMA conv / weight-gradient /
+ * scheduled attention-forward kernel this THREAD launches records its own begin and end into them (hipExtLaunchKernel:
+ * the dispatch's timestamps, as rocprofv3 reports them; events recorded around a launch also time the kernel boundary).
+ * oniris_profile_disarm returns 1 when the pair was not consumed (the entry point took a path without the hook).       */
+int oniris_profile_arm(void* start_event, void* stop_event);
+int oniris_profile_disarm(void);
 /* sizeof(OnirisWeightDesc, OnirisConvArgs, OnirisWgradArgs, OnirisAttnArgs) for binding self-checks */
 int oniris_struct_sizes(int32_t* out4 /* [host] */);
 
