@@ -366,7 +366,7 @@ class WeightBank:
 # convolution
 
 import os as _os
-WGRAD_SIDE_STREAM = int(_os.environ.get("ONIRIS_WGRAD_STREAM", "0"))   # opt-in: weight-gradient kernels on a second HIP stream (measured: 1-2 % slower, the LDS-filling kernels cannot share a CU)
+WGRAD_SIDE_STREAM = int(_os.environ.get("ONIRIS_WGRAD_STREAM", "0"))   # opt-in: weight-gradient kernels on a second HIP stream (round 1: 1-2 % slower; end of round 2: +1.0-1.3 % in same-box A/Bs, but one unexplained failure of a graph-vs-eager test in four runs of the suite with it on -- stays off until that is understood)
 FUSED_ROPE = int(_os.environ.get("ONIRIS_FUSED_ROPE", "1"))        # 0: qkv normalisation and the two rotations as three launches (A/B, tests)
 ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
 ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
