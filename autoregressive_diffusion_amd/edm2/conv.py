@@ -79,6 +79,9 @@ class MPConv(nn.Module):
                 y = self._cl(xin)[:, 0, 0, :].to(x.dtype)
             else:
                 y = from_cl(self._cl(to_cl(x, pad_to=-(-x.shape[1] // 8) * 8)), x.dtype)
+                if self.weight.perm3:          # attn_qkv: the packed rows are (s m c); the public output keeps the
+                    n, c3, h, w = y.shape      # reference's channel order (m c s) (attention_modules.py:48)
+                    y = y.reshape(n, 3, c3 // 3, h, w).transpose(1, 2).reshape(n, c3, h, w)
             return y * gain
 
     @torch.no_grad()

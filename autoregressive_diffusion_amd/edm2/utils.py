@@ -26,6 +26,16 @@ def from_cl(x, dtype=torch.float32):
     return x.permute(0, 3, 1, 2).to(dtype).contiguous()
 
 
+def normalize(x, dim=None, eps=EPS):
+    """x / (eps + |x|_dim * sqrt(n_norm / n_x)): the reference's magnitude normalisation (utils.py:83-88), part of its
+    public utils surface (its tests import it); the hot path runs it inside the HIP kernels."""
+    if dim is None:
+        dim = list(range(1, x.ndim))
+    norm = torch.linalg.vector_norm(x, dim=dim, keepdim=True, dtype=torch.float32)
+    norm = eps + norm * math.sqrt(norm.numel() / x.numel())
+    return x / norm.to(x.dtype)
+
+
 def normalize_cl(x):
     """pixel norm over the channel (last) dim: x / (eps + |x| / sqrt(C))   (utils.py:83-88 with dim=1)."""
     n = torch.linalg.vector_norm(x.float(), dim=-1, keepdim=True)
