@@ -1139,6 +1139,8 @@ class _AttentionFn(torch.autograd.Function):
         _need_gpu(qkv)
         N, P, C3 = qkv.shape
         C = C3 // 3
+        if C != 64 * heads:
+            raise NotImplementedError(f"attention kernels: head dimension 64 only (got {C} channels / {heads} heads)")
         dev = qkv.device
         q = torch.empty((N, P, C), dtype=BF16, device=dev)
         k, v = torch.empty_like(q), torch.empty_like(q)
@@ -1272,6 +1274,8 @@ class KVRing:
 def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     """Eval-mode VideoAttention core (attention_modules.py:51-77): qkv (B*t, P, 3C) of the NEW frames.
     kv_cache: (K, V) normalised, un-rotated, (B, t_cached*P, C) or None.  Returns out (B*t,P,C), new cache."""
+    if qkv.shape[-1] != 3 * 64 * heads:
+        raise NotImplementedError(f"attention kernels: head dimension 64 only (got {qkv.shape[-1] // 3} channels / {heads} heads)")
     N, P_, C3 = qkv.shape
     C = C3 // 3
     dev = qkv.device

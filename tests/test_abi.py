@@ -97,3 +97,16 @@ def test_attn_schedule_is_a_balanced_partition():
     tab = np.zeros((256, 1), np.int32)
     assert _lib.lib.oniris_attn_schedule(8, len(w), w.ctypes.data_as(ctypes.c_void_p), 256,
                                          tab.ctypes.data_as(ctypes.c_void_p), 1) < 0
+
+
+def test_attention_modules_refuse_other_head_dimensions():
+    """The reference's unit tests build 4 heads of 16 channels (consistency_test.py:39,61); the kernels serve head
+    dimension 64 (every shipped configuration, networks_edm2.py:28,39) and must say so instead of computing garbage."""
+    import pytest
+    import autoregressive_diffusion_amd  # noqa: F401
+    from edm2.attention import VideoAttention, FrameAttention
+    for cls in (VideoAttention, FrameAttention):
+        with pytest.raises(NotImplementedError):
+            cls(channels=64, num_heads=4)
+        cls(channels=128, num_heads=2)
+        cls(channels=64, num_heads=0)
