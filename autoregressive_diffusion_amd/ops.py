@@ -997,7 +997,10 @@ class _GatesFn(torch.autograd.Function):
     def backward(ctx, dca, dcb):
         c_noise, params, nctx = ctx.saved_tensors
         L, N = params.shape[0], c_noise.numel()
-        dca, dcb = dca.contiguous(), dcb.contiguous()
+        if dca is None and dcb is None:
+            return None, None, None, None, None, None
+        dca = torch.zeros((L, N), dtype=torch.float32, device=params.device) if dca is None else dca.contiguous()
+        dcb = torch.zeros((L, N), dtype=torch.float32, device=params.device) if dcb is None else dcb.contiguous()
         dparams = torch.empty_like(params)
         check(lib.oniris_gates_bwd(_p(c_noise), _p(params), _p(nctx), _p(dca), _p(dcb), _p(dparams), L, N, ctx.T, _stream()),
               "gates_bwd")
