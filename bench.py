@@ -15,6 +15,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this platform needs dmabuf IPC (RCCL otherwise fails with `hipIpcGetMemHandle: invalid argument`);
+# the environment normally exports it already -- set before anything touches the GPU, never overridden
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
