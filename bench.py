@@ -114,6 +114,49 @@ def rollout(args):
                       "finite": bool(torch.isfinite(x).all())}))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher around it: start the N ranks the way the reference's cs_train.py
+    is started (cs_train.py:164-174: LOCAL_RANK / init_process_group("nccl", "env://") under torchrun) -- as a CHILD
+    process, `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` on 127.0.0.1 and a free
+    port.  The children inherit stdout / stderr, so rank 0's JSON line is this process's output; the exit code is
+    theirs.  This parent must not initialise the GPU (and does not even import torch)."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    sys.stdout.flush()
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args, rank, world):
+    """--dry-run: only the multi-rank plumbing of this script (rendezvous, barrier, max-over-ranks timing, rank 0's JSON
+    line) on the gloo backend with no GPU -- what the CPU test of the launcher path runs (tests/test_bench_launch.py)."""
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", init_method="env://")
+    dist.barrier()
+    if os.environ.get("ONIRIS_DRY_RUN_FAIL_RANK") == str(rank):     # (test hook: a rank that dies after the rendezvous)
+        os._exit(3)
+    t0 = time.perf_counter()
+    tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ranks = [None] * world
+    dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher plumbing only, NOT a measurement)", "value": 0.0, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "rccl_world": dist.get_world_size(), "backend": "gloo",
+                          "ranks": ranks, "max_over_ranks": float(tt.item()), "dry_run": True,
+                          "ms_per_step": (time.perf_counter() - t0) * 1e3}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -133,11 +176,14 @@ def main():
     ap.add_argument("--mode", choices=["train", "rollout"], default="train",
                     help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
     ap.add_argument("--gen-frames", type=int, default=8)
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 64 if args.net == "gym" else 32
     if args.mode == "rollout":
         return rollout(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        sys.exit(self_launch(args))              # (this process never imports torch, never touches a GPU)
 
     import torch
     import torch.distributed as dist
@@ -146,8 +192,9 @@ def main():
     force_dist = bool(os.environ.get("ONIRIS_FORCE_DIST"))          # debug: run the RCCL/DDP path with a single rank
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with python -m torch.distributed.run "
-                         f"--nproc-per-node {args.gpus} bench.py ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     # debug aid (NOT a measurement): ONIRIS_SHARE_GPU=1 runs every rank on cuda:0 with the gloo backend, so that the
     # multi-rank control flow of this script (collective matching, staged exchange) can be exercised on a 1-GPU box
     share = bool(os.environ.get("ONIRIS_SHARE_GPU"))
@@ -162,6 +209,11 @@ def main():
             dist.init_process_group("gloo", init_method="env://")
         else:
             dist.init_process_group("nccl", init_method="env://", device_id=dev)
+    rccl_world, devices = 1, [torch.cuda.current_device()]
+    if world > 1 or force_dist:                    # what the collective library itself saw (goes into the JSON line)
+        rccl_world = dist.get_world_size()
+        devices = [None] * rccl_world
+        dist.all_gather_object(devices, torch.cuda.current_device())
 
     from edm2.networks_edm2 import UNet, Precond
     from edm2.loss import EDM2Loss
@@ -329,6 +381,8 @@ def main():
                "value": frames / dt, "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "rccl_world": rccl_world, "devices": sorted(set(devices)),
+               "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
                "config": {"workload": (f"Counter-Strike latents {T}-frame seq, EDM2 UNet 310.0M (cs_train.py:35-45), " if cs else
                                        f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), ") +
                                       f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
