@@ -422,10 +422,18 @@ def _profiled(key, flops, fn):
     KernelProfile.records.append((key, flops, e0, e1))
 
 
+def train_frame_pairs(T, P):
+    """Unmasked (query frame, key frame) pairs of the DART training mask = table AND mask_mod (reference
+    attention_masking.py:32-53): clean rows T(T+1)/2, noised row f sees clean frames < fpb*floor(f/fpb) and itself,
+    fpb = max(1, 128 // P) frames per 128-token mask block (4128 at T=64, P=64; 944 at T=32, P=16)."""
+    fpb = max(1, 128 // P)
+    return T * (T + 1) // 2 + sum(1 + fpb * (f // fpb) for f in range(T))
+
+
 def _attn_flops(kind, B, T, heads, L, P):
     """Algorithmic FLOPs of ONE product pair (QK^T + PV) over the unmasked token pairs: video training mask
-    T(T+1) frame pairs x P^2, dense per-frame attention L^2 per frame."""
-    pairs = (T * (T + 1) * P * P * B) if kind == "video" else (B * L * L)
+    train_frame_pairs(T, P) x P^2, dense per-frame attention L^2 per frame."""
+    pairs = (train_frame_pairs(T, P) * P * P * B) if kind == "video" else (B * L * L)
     return 4.0 * 64 * heads * pairs
 
 

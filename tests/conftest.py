@@ -10,6 +10,7 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: a minute or more (full-size CPU-oracle comparisons); still part of -m gpu")
 
 
 def pytest_collection_modifyitems(config, items):

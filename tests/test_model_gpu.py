@@ -331,7 +331,10 @@ GYM_FULL = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=3
 
 
 @pytest.mark.parametrize("tag,cfg,Tn,labelled", [("cs-shaped", CS_SMALL, 8, False), ("cs-full-net", CS_FULL, 8, False),
-                                                 ("gym-full-net", GYM_FULL, 8, True)])
+                                                 ("gym-full-net", GYM_FULL, 8, True),
+                                                 # BASELINE configs[1] itself: 64 frames, L = 8192 tokens per VideoAttention
+                                                 # layer (the oracle needs ~25 GB and about a minute on the GPU box's host)
+                                                 pytest.param("gym-full-net-T64", GYM_FULL, 64, True, marks=pytest.mark.slow)])
 def test_cs_shaped_unet_vs_oracle(tag, cfg, Tn, labelled):
     """One 3-D training step (loss + every weight gradient) against the fp32 oracle on the same parameters and noise.
     cs-shaped: Counter-Strike topology (cs_train.py:35-45) at reduced width: 32x32 latents, video attention at 4x4
@@ -467,6 +470,33 @@ def test_full_size_cached_equals_uncached():
     print("cached vs uncached (full gym net): frame-by-frame", e1, "prefill 5", e2, "then decode", errs)
     assert cache["n_context_frames"] == t
     assert e1 < 1e-2 and e2 < 1e-2 and max(errs) < 1e-2
+
+
+def test_cached_decode_at_rollout_depth_equals_uncached():
+    """BASELINE configs[4] depth (8 context + 256 generated frames, generation_code.py:83-95) on the FULL gym net: the
+    reference's cached == non-cached property (consistency_test.py:129-146) for frame 264 -- denoised alone against the KV /
+    activation caches of 263 frames (decode kernel over 16.8 K keys, ring storage, RoPE tables for 264 positions) versus
+    all 264 frames in one causal call (prefill table with 132 blocks per row)."""
+    from edm2.networks_edm2 import UNet, Precond
+    torch.manual_seed(17)
+    net = Precond(UNet(**GYM_FULL), sigma_data=1.0).to(DEV).eval()
+    for m in net.modules():
+        if hasattr(m, "emb_gain"):
+            torch.nn.init.constant_(m.emb_gain, 0.3)
+    torch.nn.init.constant_(net.unet.out_gain, 1.0)
+    g = torch.Generator().manual_seed(18)
+    t = 264
+    x = torch.randn(1, t, 8, 64, 64, generator=g).to(DEV)
+    sigma = (torch.randn(1, t, generator=g) * 0.5).exp().to(DEV)
+    lab = torch.randint(0, 4, (1, t), generator=g).to(DEV)
+    with torch.no_grad():
+        full, _ = net(x, sigma, lab)
+        _, cache = net(x[:, :t - 1], sigma[:, :t - 1], lab[:, :t - 1], update_cache=True)
+        last, cache = net(x[:, t - 1:], sigma[:, t - 1:], lab[:, t - 1:], cache=cache, update_cache=True)
+    e = rel(last, full[:, t - 1:].cpu().numpy())
+    print("frame 264: cached decode vs one causal call", e)
+    assert torch.isfinite(full).all() and cache["n_context_frames"] == t
+    assert e < 1e-2
 
 
 def _ddp_worker(q):

@@ -317,6 +317,109 @@ def test_video_attention_core_train(B, T, H, m, chunks, persistent, monkeypatch)
     assert e[0] < 1e-2 and e[1] < 2.5e-2
 
 
+_c2_oracle = {}
+
+
+def _c2_attention_oracle(B, T, H, m, seed):
+    """Dense `table AND mask_mod` SDPA oracle (O.train_allowed_tokens) forward + backward at a size where the score matrix
+    of ONE (sequence, head) pair is L x L fp32 = 268 MB (L = 8192): evaluated pair by pair so the host never holds more than
+    a few of them.  Cached: the persistent and the grid forward are checked against the same oracle result."""
+    key = (B, T, H, m, seed)
+    if key in _c2_oracle:
+        return _c2_oracle[key]
+    torch.manual_seed(seed)
+    C, P, N = 64 * m, H * H, B * 2 * T
+    qkv0 = bfr(torch.randn(N, 3 * C, H, H))            # reference channel order (m c s)
+    go0 = bfr(torch.randn(N, C, H, H))
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    sc = (torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)
+    qr_in = qkv0.clone().requires_grad_(True)
+    q, k, v = O._split_qkv(qr_in, m)
+    q, k, v = (z.reshape(B, 2 * T, m, P, 64).permute(0, 2, 1, 3, 4) for z in (q, k, v))
+    q, k = O.rope_apply(q, k, inv, sc, True)
+    q, k, v = (z.reshape(B, m, -1, 64) for z in (q, k, v))
+    allowed = torch.from_numpy(O.train_allowed_tokens(T, P))
+    go = go0.reshape(B, 2 * T, m, 64, P).permute(0, 2, 1, 4, 3).reshape(B, m, -1, 64)
+    o = torch.empty(B, m, 2 * T * P, 64)
+    for b in range(B):
+        for h in range(m):
+            oh = torch.nn.functional.scaled_dot_product_attention(q[b:b + 1, h:h + 1], k[b:b + 1, h:h + 1], v[b:b + 1, h:h + 1],
+                                                                  attn_mask=allowed)
+            (oh * go[b:b + 1, h:h + 1]).sum().backward(retain_graph=True)
+            o[b, h] = oh.detach()[0, 0]
+    o = o.reshape(B, m, 2 * T, P, 64).permute(0, 2, 1, 4, 3).reshape(N, C, H, H)
+    _c2_oracle[key] = (qkv0, go0, inv, sc, o, qr_in.grad.clone())
+    return _c2_oracle[key]
+
+
+@pytest.mark.parametrize("persistent", [1, 0])
+def test_video_attention_bench_shape_vs_dense_oracle(persistent, monkeypatch):
+    """the shape bench.py runs -- BASELINE configs[1]: B = 2, T = 64, P = 64, 4 heads, L = 8192 tokens,
+    8 (sequence, head) pairs x 64 query blocks on the longest-first schedule, dK/dV in 4 query chunks (ops defaults, exactly
+    what _AttentionFn uses in the step) -- forward AND backward against the dense masked-softmax oracle, through the
+    persistent wave-specialised forward (attn_fwd_ws_kernel) and through the grid kernel.
+    Tolerance (bf16 operands, fp32 accumulation vs the fp32 oracle): rel L2 <= 1e-2 out, <= 2.5e-2 dqkv."""
+    from autoregressive_diffusion_amd import ops
+    monkeypatch.setattr(ops, "ATTN_PERSISTENT", persistent)
+    assert ops.ATTN_DKV_CHUNKS == 4 and ops.ATTN_DKV_MIN_L == 2048          # the bench's own setting: 8192 // 2048 = 4 chunks
+    B, T, H, m = 2, 64, 8, 4
+    C, P, N = 64 * m, H * H, B * 2 * T
+    qkv0, go0, inv, sc, o, dqkv_ref = _c2_attention_oracle(B, T, H, m, 21)
+    perm = qkv0.reshape(N, m * 64, 3, H, H).permute(0, 2, 1, 3, 4).reshape(N, 3 * C, H, H)
+    x = nhwc(perm).reshape(N, P, 3 * C).requires_grad_(True)
+    out = ops.attention_train(x, "video", B, T, m, (inv.to(DEV), sc.to(DEV)))
+    out.backward(nhwc(go0).reshape(N, P, C))
+    dqkv = x.grad.reshape(N, H, H, 3, m * 64).permute(0, 4, 3, 1, 2).reshape(N, 3 * C, H, H).float().cpu()
+    ho = nchw(out.reshape(N, H, H, C))
+    e = (rel(ho, o), rel(dqkv, dqkv_ref))
+    # per-frame errors too: a wrong softmax weight inside the allowed set of a few rows would hide in the global norm
+    fo = ((ho - o).reshape(N, -1).norm(dim=1) / o.reshape(N, -1).norm(dim=1)).max().item()
+    fg = ((dqkv - dqkv_ref).reshape(N, -1).norm(dim=1) / (dqkv_ref.reshape(N, -1).norm(dim=1) + 1e-12)).max().item()
+    print("video_attention C2 shape", (B, T, H, m), "persistent" if persistent else "grid", "rel out/dqkv", e,
+          "worst frame out/dqkv", (fo, fg))
+    assert e[0] < 1e-2 and e[1] < 2.5e-2
+    assert fo < 2e-2 and fg < 5e-2
+
+
+def test_decode_attention_at_rollout_depth_vs_oracle():
+    """BASELINE configs[4] (256-frame rollout: generation_code.py:83-95, attention_modules.py:51-57,69-70): one new frame
+    against a KV ring that already holds 8 context + 255 generated = 263 frames (16.8 K keys, gym shape: P = 64, 4 heads),
+    i.e. the attention of generated frame 256, compared with the oracle's dense SDPA over the same cache -- including the
+    re-rotation of ALL keys with T = 264 (fp16-rounded tables, RoPe.py:21-32,55-57) and the ring growing past a capacity."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(31)
+    B, H, m, n_old = 1, 8, 4, 263
+    C, P = 64 * m, H * H
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    sc = (torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)
+    # the cache holds normalised, un-rotated k and v: unit-RMS vectors per (token, head), bf16-rounded
+    kc = bfr(O.normalize(torch.randn(B, m, n_old, P, 64), dim=-1))
+    vc = bfr(O.normalize(torch.randn(B, m, n_old, P, 64), dim=-1))
+    ring = ops.KVRing(B, P, C, 264, DEV)                   # exactly full after this frame; the NEXT frame must re-home it
+    to_ring = lambda z: z.permute(0, 2, 3, 1, 4).reshape(B, n_old * P, C).to(DEV, torch.bfloat16)
+    ring.K[:, :n_old * P], ring.V[:, :n_old * P], ring.n = to_ring(kc), to_ring(vc), n_old
+    cache = ring.views()
+    outs = []
+    rk, rv = kc, vc
+    for step in range(2):                                  # frame 256 (fills the ring), frame 257 (grows it)
+        a = bfr(torch.randn(B, 3 * C, H, H))
+        perm = a.reshape(B, m * 64, 3, H, H).permute(0, 2, 1, 3, 4).reshape(B, 3 * C, H, H)
+        out, cache = ops.attention_eval(nhwc(perm).reshape(B, P, 3 * C), B, m, (inv.to(DEV), sc.to(DEV)), cache, True, P)
+        q, k, v = O._split_qkv(a, m)
+        q, k, v = (z.reshape(B, 1, m, P, 64).permute(0, 2, 1, 3, 4) for z in (q, k, v))
+        rk, rv = torch.cat([rk, k], 2), torch.cat([rv, v], 2)
+        qq, kk = O.rope_apply(q, rk, inv, sc, False)
+        o = torch.nn.functional.scaled_dot_product_attention(qq.reshape(B, m, -1, 64), kk.reshape(B, m, -1, 64),
+                                                             rv.reshape(B, m, -1, 64))
+        o = o.reshape(B, m, 1, P, 64).permute(0, 2, 1, 4, 3).reshape(B, C, H, H)
+        outs.append(rel(nchw(out.reshape(B, H, H, C)), o))
+        assert cache[0].shape[1] == (n_old + 1 + step) * P
+    print("decode attention at 264 / 265 cached frames: rel", outs)
+    assert max(outs) < 1e-2
+    assert cache[0]._oniris_ring is not ring and cache[0]._oniris_ring.cap >= 265        # re-homed, old frames copied
+    assert rel(cache[0][:, :n_old * P].reshape(B, n_old, P, m, 64).permute(0, 3, 1, 2, 4), kc) == 0.0
+
+
 def test_fused_qkv_norm_rope_matches_three_launch_path(monkeypatch):
     """oniris_qkv_norm_rope[_bwd] (normalisation + both rotations in one pass, one bf16 rounding) against oniris_qkv_norm +
     2 x oniris_rope (+ their adjoints): same attention output and qkv gradient up to the skipped intermediate rounding."""
