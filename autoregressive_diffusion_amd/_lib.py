@@ -90,6 +90,8 @@ _SIGS = {
                                  c_int, c_int, c_float, c_void_p]),
     "oniris_dart_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                      c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "oniris_loss_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                 c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "oniris_conv_fwd": (c_int, [C.POINTER(ConvArgs), c_void_p]),
     "oniris_conv_wgrad": (c_int, [C.POINTER(WgradArgs), c_void_p]),
     "oniris_conv_wgrad_group": (c_int, [C.POINTER(WgradArgs), c_int, c_void_p]),

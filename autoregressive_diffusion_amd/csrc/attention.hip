@@ -1036,6 +1036,11 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
     ONIRIS_CHECK_ARG(d.a.sched_wgs > 0 && d.a.sched_slots > 0, "attn_fwd: empty schedule");
     ONIRIS_CHECK_ARG(d.a.mask_mode != 0, "attn_fwd: the scheduled kernel serves the table-driven masks");
     ONIRIS_CHECK_ARG(d.a.kv_num && d.a.kv_idx && d.a.tab_cols <= 64, "attn_fwd: the scheduled kernel needs a table with <= 64 blocks per row");
+    // the kernel's assumptions (only the LAST listed block of a table row is partially masked; 128-row query blocks):
+    // true for the DART training table (Lq == Lk == 2*T*P) and for the causal prefill table (Lq == Lk), nothing else
+    ONIRIS_CHECK_ARG(d.a.Lq % 128 == 0 && d.a.Lq == d.a.Lk,
+                     "attn_fwd: the scheduled kernel needs Lq == Lk, a multiple of 128 (got %d, %d): launch without a schedule",
+                     d.a.Lq, d.a.Lk);
     if (d.a.mask_mode == 1) oniris_launch(attn_fwd_ws_kernel<1>, dim3(d.a.sched_wgs), dim3(512), stream, d);
     else oniris_launch(attn_fwd_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), stream, d);
     ONIRIS_LAUNCH_CHECK();

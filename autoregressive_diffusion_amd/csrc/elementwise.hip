@@ -426,6 +426,64 @@ extern "C" int oniris_dart_loss_bwd(const void* F, const float* images, const fl
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// Tail of EDM2Loss.__call__ (edm2/loss.py:32-46) + MultiNoiseLoss.add_data (edm2/loss_weight.py:30-39) in one launch, no host
+// round trip: per (sequence, frame) of the noised half
+//   l    = mse * (sigma^2 + sd^2) / (sigma * sd)^2                                   (loss.py:34-38)
+//   m    = 10 ^ (c0/2 + sum_n c[2n-1] cos(n log10 sigma) + c[2n] sin(n log10 sigma))  (loss_weight.py:104-111,126-131)
+//   out[0] = mean(l / m), out[1] = mean(l) (the un-weighted loss the loops log), dcoef = d out[0] / d mse = w / (m * B*T)
+// and (sigma, l, t) appended to the 10 000-entry history the Fourier fit reads (rings + a device-side write counter:
+// entry number `count + i` lives in slot (count + i) % cap, so the last `cap` entries are always present).
+__global__ __launch_bounds__(256) void loss_tail_kernel(const float* __restrict__ mse, const float* __restrict__ sigma,
+                                                        const float* __restrict__ coef, float* __restrict__ out,
+                                                        float* __restrict__ dcoef, float* __restrict__ ring_sigma,
+                                                        float* __restrict__ ring_loss, int* __restrict__ ring_pos,
+                                                        long long* __restrict__ count, int cap, int n, int T,
+                                                        int sig_pitch, int sig_off, int nterms, float sd) {
+  __shared__ float red[16];
+  const long long base = count ? *count : 0;
+  float a0 = 0.f, a1 = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int b = i / T, t = i - b * T;
+    const float sg = sigma[(size_t)b * sig_pitch + sig_off + t];
+    const float w = (sg * sg + sd * sd) / ((sg * sd) * (sg * sd));
+    const float l = mse[i] * w;
+    const float xl = log10f(sg);
+    float e = 0.5f * coef[0];
+    for (int k = 1; k < nterms; ++k) e += coef[2 * k - 1] * cosf(k * xl) + coef[2 * k] * sinf(k * xl);
+    const float inv_m = exp10f(-e);
+    a0 += l * inv_m;
+    a1 += l;
+    dcoef[i] = w * inv_m / (float)n;
+    if (ring_sigma && i >= n - cap) {
+      const int j = (int)((base + i) % cap);
+      ring_sigma[j] = sg;
+      ring_loss[j] = l;
+      ring_pos[j] = t;
+    }
+  }
+  a0 = block_sum(a0, red);
+  a1 = block_sum(a1, red);
+  if (threadIdx.x == 0) {
+    out[0] = a0 / (float)n;
+    out[1] = a1 / (float)n;
+    if (count && ring_sigma) *count = base + n;
+  }
+}
+
+extern "C" int oniris_loss_tail(const float* mse, const float* sigma, const float* coef, float* out, float* dcoef,
+                                float* ring_sigma, float* ring_loss, int* ring_pos, long long* count, int cap, int B, int T,
+                                int sig_pitch, int sig_off, int nterms, float sigma_data, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(mse && sigma && coef && out && dcoef && B > 0 && T > 0 && sig_pitch >= sig_off + T && sig_off >= 0 &&
+                   nterms >= 1 && sigma_data > 0.f, "loss_tail: bad arguments");
+  ONIRIS_CHECK_ARG(!ring_sigma || (ring_loss && ring_pos && count && cap > 0), "loss_tail: incomplete history ring");
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(256), 0, stream, mse, sigma, coef, out, dcoef, ring_sigma, ring_loss,
+                     ring_pos, count, cap, B * T, T, sig_pitch, sig_off, nterms, sigma_data);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Precond.forward's output side in eval (networks_edm2.py:293-297): D = c_skip * x + c_out * out_gain * F, with F the raw
 // channels-last bf16 UNet output [N][HW][8] and x, D fp32 [N][C][HW] (one block column per frame)
 __global__ __launch_bounds__(256) void precond_out_kernel(const bf16* __restrict__ F, const float* __restrict__ x,

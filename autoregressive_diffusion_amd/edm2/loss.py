@@ -16,8 +16,9 @@ class EDM2Loss:
         self.context_noise_reduction = context_noise_reduction
 
     def __call__(self, net, images, conditioning=None, sigma=None, just_2d=False, noise=None, sync=True):
-        """`noise` (optional): the standard-normal draw to use (fixtures); `sync=False` skips the host round trips
-        (returns the un-weighted loss as a device tensor and does not log to net.noise_weight)."""
+        """`noise` (optional): the standard-normal draw to use (fixtures); `sync=False` skips the host round trip of the
+        reference's `.cpu().item()` (:41) and returns the un-weighted loss as a device tensor.  Either way (sigma, loss) is
+        logged to net.noise_weight (:43) -- on the device for HIP tensors."""
         B, T = images.shape[:2]
         assert net.training, "The model should be in training mode"
         S = 1 if just_2d else 2
@@ -31,23 +32,28 @@ class EDM2Loss:
         if noise is None:
             noise = torch.randn((B, S * T) + tuple(images.shape[2:]), dtype=images.dtype, device=images.device)
         if FUSED and self._fusable(net, images, noise, sigma):
-            # same math in three HIP passes (input packing, per-frame loss, its gradient) instead of ~25 fp32
-            # elementwise launches over (B, 2T, C, H, W): the noised input and D_x are never materialised
+            # same math in HIP passes (input packing, per-frame loss, its gradient, the loss tail) instead of ~45 fp32
+            # elementwise launches over (B, 2T, C, H, W) / (B, T): the noised input and D_x are never materialised
             sgm = sigma.float().contiguous()
             xcl = ops.dart_input(images, noise, sgm, S, net.sigma_data)
             c_noise = sgm.log() / 4                                             # Precond.forward (networks_edm2.py:290)
             Fcl, _ = net.unet.forward(xcl, c_noise, conditioning, None, False, just_2d, _cl_io=(B, S * T))
-            losses = ops.dart_loss(Fcl, net.unet.out_gain, images, noise, sgm, S, net.sigma_data)
-        else:
-            cat_images = images if just_2d else torch.cat((images, images), dim=1)
-            out, _ = net(cat_images + sigma[:, :, None, None, None] * noise, sigma, conditioning, just_2d=just_2d)
-            losses = ((out[:, -T:] - images) ** 2).mean(dim=(-1, -2, -3))
+            mse = ops.dart_loss(Fcl, net.unet.out_gain, images, noise, sgm, S, net.sigma_data)
+            # lambda(sigma) weighting, / fitted mean loss, both means and net.noise_weight.add_data (:37-46) in one launch:
+            # the (sigma, loss, position) history is appended on the device, whether or not the caller syncs
+            nw = net.noise_weight
+            loss, unweighted = ops.loss_tail(mse, sgm, nw.fourier_approximator.coefficients, nw.device_history(images.device),
+                                             self.sigma_data)
+            return loss, (unweighted.cpu().item() if sync else unweighted)
+        cat_images = images if just_2d else torch.cat((images, images), dim=1)
+        out, _ = net(cat_images + sigma[:, :, None, None, None] * noise, sigma, conditioning, just_2d=just_2d)
+        losses = ((out[:, -T:] - images) ** 2).mean(dim=(-1, -2, -3))
         sg = sigma[:, -T:]
         losses = losses * (sg ** 2 + self.sigma_data ** 2) / (sg * self.sigma_data) ** 2
         unweighted = losses.mean().detach()
+        net.noise_weight.add_data(sg, losses)                    # (device-side append for HIP tensors: no host round trip)
         if sync:
             unweighted = unweighted.cpu().item()
-            net.noise_weight.add_data(sg, losses)
         mean_loss = net.noise_weight.calculate_mean_loss(sg)
         return (losses / mean_loss).mean(), unweighted
 

@@ -44,30 +44,78 @@ class FourierSeriesFit(nn.Module):
 
 
 class MultiNoiseLoss(nn.Module):
+    """History of the last `history_size` (sigma, loss, frame position) triples + the Fourier fit of log10 loss over
+    log10 sigma (reference loss_weight.py:9-84).  On a HIP device the history is three preallocated rings and an entry
+    counter IN DEVICE MEMORY, appended to by the loss kernel itself (ops.loss_tail -> oniris_loss_tail) with no host round
+    trip; `.sigmas / .losses / .positions` (what the fit and the reference's dashboard read) copy them out in
+    chronological order -- the only synchronisation, once per fit (every 500 * accumulation steps, gym_train.py:115-116).
+    CPU tensors (tests without a GPU) keep the reference's concatenate-and-truncate lists."""
+
     def __init__(self, vertical_scaling=0, x_min=0., width=0., vertical_offset=0., min_loss=0.005,
                  std_dev_multiplier=0.7, std_dev_shift=2):
         super().__init__()
-        self.sigmas = torch.tensor([], dtype=torch.float32)
-        self.losses = torch.tensor([], dtype=torch.float32)
-        self.positions = torch.tensor([], dtype=torch.int64)
+        self._host = (torch.tensor([], dtype=torch.float32), torch.tensor([], dtype=torch.float32),
+                      torch.tensor([], dtype=torch.int64))
+        self._ring = None                      # (ring_sigma, ring_loss, ring_pos, count) on the training device
         self.history_size = 10000
         self.fourier_approximator = FourierSeriesFit(-torch.pi, torch.pi, num_terms=4)
         self.min_loss = min_loss
+
+    def device_history(self, device):
+        """The rings the loss kernel appends to (created on first use; rank 0 only, like add_data: loss_weight.py:33-34)."""
+        if _dist_on() and dist.get_rank() != 0:
+            return None
+        r = self._ring
+        if r is None or r[0].device != device or r[0].numel() != self.history_size:
+            h = self.history_size
+            r = self._ring = (torch.zeros(h, dtype=torch.float32, device=device), torch.zeros(h, dtype=torch.float32, device=device),
+                              torch.zeros(h, dtype=torch.int32, device=device), torch.zeros(1, dtype=torch.int64, device=device))
+        return r
+
+    def _chronological(self):
+        hs, hl, hp = self._host
+        if self._ring is None:
+            return hs, hl, hp
+        rs, rl, rp, cnt = self._ring
+        n, cap = int(cnt.item()), rs.numel()
+        if n <= cap:
+            order = torch.arange(n)
+        else:
+            order = (torch.arange(cap) + n) % cap
+        order = order.to(rs.device)
+        ds, dl, dp = (z.index_select(0, order).cpu() for z in (rs, rl, rp))
+        h = self.history_size
+        return (torch.cat((hs, ds))[-h:], torch.cat((hl, dl))[-h:], torch.cat((hp, dp.to(torch.int64)))[-h:])
+
+    sigmas = property(lambda self: self._chronological()[0])
+    losses = property(lambda self: self._chronological()[1])
+    positions = property(lambda self: self._chronological()[2])
 
     @torch.no_grad()
     def add_data(self, sigmas, losses):
         if _dist_on() and dist.get_rank() != 0:
             return
         positions = torch.arange(sigmas.numel()) % sigmas.shape[1]
+        if sigmas.is_cuda:                     # same append as the loss kernel's, through torch ops (eager-path callers)
+            rs, rl, rp, cnt = self.device_history(sigmas.device)
+            n, cap = sigmas.numel(), rs.numel()
+            idx = (cnt + torch.arange(n, device=sigmas.device)) % cap
+            rs.index_copy_(0, idx, sigmas.flatten().detach().float())
+            rl.index_copy_(0, idx, losses.flatten().detach().float())
+            rp.index_copy_(0, idx, positions.to(sigmas.device, torch.int32))
+            cnt += n
+            return
         h = self.history_size
-        self.sigmas = torch.cat((self.sigmas, sigmas.flatten().detach().float().cpu()))[-h:]
-        self.losses = torch.cat((self.losses, losses.flatten().detach().float().cpu()))[-h:]
-        self.positions = torch.cat((self.positions, positions))[-h:]
+        hs, hl, hp = self._host
+        self._host = (torch.cat((hs, sigmas.flatten().detach().float().cpu()))[-h:],
+                      torch.cat((hl, losses.flatten().detach().float().cpu()))[-h:], torch.cat((hp, positions))[-h:])
 
     @torch.no_grad()
     def calculate_mean_loss(self, sigma):
         return self.fourier_approximator(sigma)
 
     def fit_loss_curve(self, sigmas=None, losses=None):
-        self.fourier_approximator.fit_data(self.sigmas if sigmas is None else sigmas,
-                                           self.losses if losses is None else losses)
+        if sigmas is None or losses is None:
+            hs, hl, _ = self._chronological()
+            sigmas, losses = (hs if sigmas is None else sigmas), (hl if losses is None else losses)
+        self.fourier_approximator.fit_data(sigmas, losses)

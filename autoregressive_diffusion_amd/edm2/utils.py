@@ -99,6 +99,19 @@ class BetterModule(nn.Module):
         return model
 
     @property
+    def _ddp_params_and_buffers_to_ignore(self):
+        """torch.nn.parallel.DistributedDataParallel reads exactly this attribute of the module it is handed (its
+        constructor; nothing else does) -- the one place where wrapping can be noticed.  torch's reducer learns about a
+        gradient from the parameter's AccumulateGrad node; the conv / attention weight gradients of this net are written
+        into `.grad` through raw pointers by ONE kernel after the backward pass (weights.hip: weight_bwd_kernel), so torch
+        DDP would wait for them forever or, worse, exchange stale buffers.  Refuse loudly (cs_train.py:53-54 becomes
+        `OnirisDDP(unet)`: same `.module`, `no_sync()`, broadcast at construction)."""
+        raise RuntimeError(
+            "torch.nn.parallel.DistributedDataParallel cannot reduce the gradients of this network: its weight gradients "
+            "are written by a HIP kernel at the end of backward, not by autograd.  Use "
+            "autoregressive_diffusion_amd.parallel.OnirisDDP(unet) instead (same .module / no_sync() / forward).")
+
+    @property
     def device(self):
         return next(self.parameters()).device
 

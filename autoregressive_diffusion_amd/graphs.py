@@ -21,9 +21,19 @@ class GraphedStep:
         # flat: the FlatParams of the net -- which weights the captured backward produced gradients for is host-side
         # bookkeeping (FlatAdamW skips parameters without gradient like torch.optim); a replay runs no Python, so the
         # record of the captured backward is re-applied after every replay
+        from .parallel import FlatParams
         if flat is None and self.params:
-            from .parallel import FlatParams
             flat = FlatParams.owner_of(self.params[0])
+        if flat is None:
+            # GraphedStep(fn) with neither params= nor flat=: without the FlatParams the replays cannot re-apply the
+            # gradient bookkeeping and FlatAdamW would silently freeze every kernel-owned weight after the capture step.
+            # One live FlatParams: it is the one; several: the caller has to say which.
+            live = FlatParams.live()
+            if len(live) == 1:
+                flat = live[0]
+            elif len(live) > 1:
+                raise ValueError("GraphedStep: several FlatParams are alive -- pass flat= (or params=) so that the replays "
+                                 "can restore which parameters received a gradient")
         self.flat, self._touched = flat, ([], [])
         self.graph, self.out, self.calls = None, None, 0
         # ONE side stream for the warm-up and the capture of EVERY GraphedStep: autograd pins each parameter's

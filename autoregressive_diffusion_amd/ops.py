@@ -320,7 +320,6 @@ class WeightBank:
     def prepare(self, training):
         """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
         self._ensure()
-        self._fresh = True                             # backward() of the same step need not re-validate the table
         if training or torch.is_grad_enabled():        # (a no_grad evaluation -- the rollout -- never takes from the arena)
             self.zero_arena.reset(self.items[0][0].param.device)   # the previous step's backward is done with its accumulators
         global _weights_epoch
@@ -339,9 +338,10 @@ class WeightBank:
 
     def backward(self):
         """Packed fp32 weight gradients (from the wgrad kernels) -> parameter .grad (accumulated); one launch."""
-        if not getattr(self, "_fresh", False):
-            self._ensure()
-        self._fresh = False
+        # re-validated on every call (~150 us of host time): between forward and backward the gradients may have been
+        # released -- `loss = model(x); opt.zero_grad(); loss.backward()` with torch's set_to_none=True -- and the table
+        # would still hold the freed .grad pointers (the kernel would write into recycled allocator memory)
+        self._ensure()
         join_side_stream()                             # every wgrad kernel (possibly on the side stream) is ordered before
         check(lib.oniris_weight_bwd(_p(self._dev_table), len(self.items), self.total_rows, _stream()), "weight_bwd")
         self.nsplit_all.zero_()        # the slabs are consumed: a second backward() must not add them again
@@ -977,7 +977,7 @@ def embed_train(c_noise, labels, fourier, pw_noise, pw_label, label_dim, t=1 / 3
     if labels is not None and pw_label is not None:
         LP = roundup(label_dim, 8)
         oh = torch.empty((N, 1, 1, LP), dtype=BF16, device=dev)
-        labels = labels.reshape(-1).contiguous()
+        labels = labels.reshape(-1).to(torch.int64).contiguous()      # (the kernel reads `const long long*`)
     freqs, phases = fourier.freqs, fourier.phases
     if freqs.dtype != torch.float32:
         freqs, phases = freqs.float(), phases.float()
@@ -1187,7 +1187,7 @@ class _AttentionFn(torch.autograd.Function):
         ks = 2 if (mask_mode != 0 and L >= 2048) else 1
         name = f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>"
         sched = None
-        if mask_mode == 2 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64:
+        if mask_mode == 2 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64 and L % 128 == 0 and Bq * heads < 32768:
             # persistent kernel: query blocks of 128 rows, cost = key blocks of its table row + 1 (fixed per-item work)
             sched = _train_sched(T, P, Bq * heads, dev, "fwd")
             a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
@@ -1405,6 +1405,45 @@ class _DartLoss(torch.autograd.Function):
 
 def dart_loss(F, out_gain, images, noise, sigma, S, sigma_data):
     return _DartLoss.apply(F, out_gain, images, noise, sigma, S, sigma_data)
+
+
+class _LossTail(torch.autograd.Function):
+    """(loss, un-weighted loss) = tail of EDM2Loss (oniris_loss_tail): lambda(sigma) weighting, division by the fitted mean
+    loss, both means, and the (sigma, loss, position) history append -- one launch, nothing read back by the host."""
+
+    @staticmethod
+    def forward(ctx, mse, sigma, coef, history, sigma_data, T_off):
+        _need_gpu(mse, sigma, coef)
+        B, T = mse.shape
+        assert mse.dtype == torch.float32 and mse.is_contiguous() and sigma.dtype == torch.float32 and sigma.stride(1) == 1
+        out = torch.empty(2, dtype=torch.float32, device=mse.device)
+        dcoef = torch.empty((B, T), dtype=torch.float32, device=mse.device)
+        rs = rl = rp = cnt = None
+        cap = 0
+        if history is not None:
+            rs, rl, rp, cnt = history
+            cap = rs.numel()
+        c = coef.detach().reshape(-1)
+        if c.dtype != torch.float32 or not c.is_contiguous():
+            c = c.float().contiguous()
+        check(lib.oniris_loss_tail(_p(mse), _p(sigma), _p(c), _p(out), _p(dcoef), _p(rs), _p(rl), _p(rp), _p(cnt), cap, B, T,
+                                   sigma.stride(0), T_off, (c.numel() + 1) // 2, float(sigma_data), _stream()), "loss_tail")
+        ctx.save_for_backward(dcoef)
+        loss, unweighted = out[0], out[1]
+        ctx.mark_non_differentiable(unweighted)
+        return loss, unweighted
+
+    @staticmethod
+    def backward(ctx, g, _g_unweighted):
+        (dcoef,) = ctx.saved_tensors
+        return dcoef * g, None, None, None, None, None
+
+
+def loss_tail(mse, sigma, coef, history, sigma_data):
+    """mse (B, T) fp32 per-frame MSE of the noised half; sigma (B, S*T) fp32 (the LAST T columns are read);
+    coef: the Fourier coefficients of the fitted mean loss; history: (ring_sigma, ring_loss, ring_pos, count) device
+    tensors of MultiNoiseLoss or None.  Returns (loss, un-weighted loss) as 0-d device tensors."""
+    return _LossTail.apply(mse, sigma, coef, history, float(sigma_data), sigma.shape[1] - mse.shape[1])
 
 
 SQNORM_WS = 1024          # ONIRIS_SQNORM_WS in include/oniris.h

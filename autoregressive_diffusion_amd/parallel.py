@@ -34,10 +34,16 @@ class FlatParams:
 
     _registry = {}                 # id(parameter) -> weakref to the FlatParams that re-homed it (graphs.GraphedStep)
 
+    _instances = None              # WeakSet of the live FlatParams
+
     @classmethod
     def owner_of(cls, param):
         ref = cls._registry.get(id(param))
         return ref() if ref is not None else None
+
+    @classmethod
+    def live(cls):
+        return list(cls._instances) if cls._instances is not None else []
 
     def __init__(self, module, lazy_small=False):
         """lazy_small: gradients of the parameters autograd itself accumulates (everything except the conv weights,
@@ -86,8 +92,18 @@ class FlatParams:
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
         import weakref
         me = weakref.ref(self)
-        for p in self.params:
-            FlatParams._registry[id(p)] = me
+        ids = [id(p) for p in self.params]
+        for i in ids:
+            FlatParams._registry[i] = me
+        if FlatParams._instances is None:
+            FlatParams._instances = weakref.WeakSet()
+        FlatParams._instances.add(self)
+
+        def _forget(reg=FlatParams._registry, ids=ids, me=me):      # the registry is keyed by id(): drop the entries with
+            for i in ids:                                           # their owner, or a recycled id would find a dead /
+                if reg.get(i) is me:                                # foreign FlatParams
+                    del reg[i]
+        weakref.finalize(self, _forget)
         self._lazy = []
         self._owner = {}                   # kernel-owned weight -> its NormalizedWeight module (.pw.touched: a wgrad ran)
         self._got = set()                  # autograd-owned (lazy) parameters that received a gradient since take_active()
@@ -206,6 +222,12 @@ class OnirisDDP(nn.Module):
         self._queued = False
         self._works = []
         self._tail_sent = False
+        # FlatAdamW skips parameters that received no gradient, decided from rank-LOCAL bookkeeping (take_active), while the
+        # exchange averages the whole flat gradient: ranks that ran different step kinds (just_2d on one rank only,
+        # conditioning on some) would silently diverge.  The reference loops use i % 4 on every rank; this guard turns
+        # a violation into an error: the bitmaps are compared on the first steps and every `active_check_every`-th.
+        self.active_check_every, self._opt_steps = 100, 0
+        self.flat._active_check = self._check_active
         if self.flat.stage_at is not None:               # early exchange of the tail (see FlatParams / _stage)
             module.__dict__["_oniris_stage_at"] = self.flat.stage_at
             module.__dict__["_oniris_stage_cb"] = self._stage
@@ -301,6 +323,20 @@ class OnirisDDP(nn.Module):
         if not self._active():
             return
         self._exchange(0, self.flat.tail_start if sent else self.flat.numel)
+
+    def _check_active(self, active):
+        self._opt_steps += 1
+        if not self._active() or (self._opt_steps > 2 and self._opt_steps % self.active_check_every):
+            return
+        import zlib
+        h = zlib.crc32(bytes(bytearray(int(bool(a)) for a in active)))
+        t = torch.tensor([h, -h], dtype=torch.int64, device=self.flat.grad.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.process_group)
+        hi, lo = int(t[0]), -int(t[1])
+        if hi != lo:
+            raise RuntimeError("OnirisDDP: the ranks disagree about which parameters received a gradient in this step "
+                               "(different step kinds per rank?  e.g. just_2d or conditioning on some ranks only): the "
+                               "optimizer would update them on some ranks and skip them on others")
 
     def wait(self):
         """Block the current stream until the gradient exchange is done (call before the optimizer step)."""
@@ -452,6 +488,9 @@ class FlatAdamW:
         consecutive parameters with equal (has gradient, step count)."""
         f = self.flat
         active = f.take_active()
+        chk = getattr(f, "_active_check", None)        # (set by OnirisDDP: all ranks must skip the same parameters)
+        if chk is not None:
+            chk(active)
         ema = list(ema or ())
         if len(self.param_steps) != len(f.params):
             self.param_steps = [self.steps] * len(f.params)

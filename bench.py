@@ -10,6 +10,7 @@ all-reduce (N > 1), fused AdamW, with the reference's 3:1 mix of 3-D and 2-D ste
 value = latent frames / s over the whole job = N * B * T * K / wall time of the K timed steps (max over ranks).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -59,26 +60,51 @@ MFMA_BF16_PEAK = 2.5e15          # dense bf16, /opt/skills/guides/MI355X_MICROAR
 # algorithmic forward FLOPs per sample of the 3-D step at T=64: 1.82 TFLOP; x3 fwd+bwd
 
 
-def cpu_baseline(frames):
-    """The CPU oracle (fp32 PyTorch restatement, pinned to the reference by tests/golden) on a bounded sample."""
+C1_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=16, channel_mult=[1, 2, 4, 8], num_blocks=1,
+              video_attn_resolutions=[8], frame_attn_resolutions=[16])      # BASELINE configs[0] / SURVEY 8d C1, 8.36 M
+
+
+def _cpu_step_time(cfg, B, frames, warm):
+    """Seconds of ONE 3-D training step (EDM2Loss forward + backward) of the CPU oracle, after `warm` untimed steps."""
     import torch
     import paramgen
     from oracle import oniris_oracle as O
-    cfg = {k: v for k, v in GYM_CFG.items() if v is not None}
+    cfg = {k: v for k, v in cfg.items() if v is not None}
     torch.manual_seed(0)
     p = paramgen.precond_params(cfg, 0)
     p = {k: v.clone().requires_grad_(v.is_floating_point() and "rope" not in k and "fourier" not in k) for k, v in p.items()}
-    images = torch.randn(1, frames, 8, 64, 64)
-    labels = torch.randint(0, 4, (1, frames))
-    sigma = (torch.randn(1, 2 * frames) * 1.0 + 1.2).exp()
-    eps = torch.randn(1, 2 * frames, 8, 64, 64)
-    t0 = time.time()
-    loss, _, _ = O.edm2_loss(p, cfg, images, sigma, eps, labels, sigma_data=1.0)
-    loss.backward()
-    dt = time.time() - t0
-    return dict(value=frames / dt, unit="latent-frames/s", cores=torch.get_num_threads(), kind="port",
-                sample=f"oracle (fp32 PyTorch CPU restatement), gym UNet 46.2M, B=1, T={frames}, one 3-D "
-                       f"forward+backward step, {dt:.1f} s")
+    res = cfg["img_resolution"]
+    images = torch.randn(B, frames, 8, res, res)
+    labels = torch.randint(0, 4, (B, frames))
+    sigma = (torch.randn(B, 2 * frames) * 1.0 + 1.2).exp()
+    eps = torch.randn(B, 2 * frames, 8, res, res)
+    dt = None
+    for it in range(warm + 1):
+        for v in p.values():
+            v.grad = None
+        t0 = time.time()
+        loss, _, _ = O.edm2_loss(p, cfg, images, sigma, eps, labels, sigma_data=1.0)
+        loss.backward()
+        dt = time.time() - t0
+    return dt
+
+
+def cpu_baseline(frames):
+    """The CPU oracle (fp32 PyTorch restatement, pinned to the reference by tests/golden) on the host cores, on the
+    configurations BASELINE.md section 3 states, each timed on its second step (one warm-up):
+      value: the bench workload's own net (gym UNet 46.2 M), B = 1, T = `frames` -- 16 by default (a bounded sample, ~30 s of
+             CPU work), 64 = BASELINE configs[1] at B = 1 (`--cpu-frames 64`, about two minutes);
+      c1:    BASELINE configs[0], the reference's CPU-runnable plumbing case (tiny UNet 8.36 M, B = 2, T = 8), always."""
+    import torch
+    cores = torch.get_num_threads()
+    dt1 = _cpu_step_time(C1_CFG, 2, 8, 1)
+    dt = _cpu_step_time(GYM_CFG, 1, frames, 1)
+    return dict(value=frames / dt, unit="latent-frames/s", cores=cores, kind="port",
+                sample=f"oracle (fp32 PyTorch CPU restatement), gym UNet 46.2M, B=1, T={frames}, one 3-D forward+backward "
+                       f"step after one warm-up step, {dt:.1f} s",
+                c1=dict(value=16 / dt1, unit="latent-frames/s", cores=cores,
+                        sample=f"configs[0]: tiny UNet 8.36M, B=2, T=8, one 3-D forward+backward step after one warm-up step, "
+                               f"{dt1:.2f} s"))
 
 
 def rollout(args):
@@ -177,6 +203,10 @@ def main():
                     help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
     ap.add_argument("--gen-frames", type=int, default=8)
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--accum", type=int, default=1,
+                    help="gradient accumulation as in the reference loops (gym_train.py:96-112, cs_train.py:105-127): the optimizer "
+                         "(+ clip, EMA, learning-rate schedule) runs every K-th micro-step, the K-1 others run their backward "
+                         "under no_sync() (no gradient exchange).  An extra measurement, NOT the headline (K = 1)")
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 64 if args.net == "gym" else 32
@@ -280,10 +310,17 @@ def main():
 
     _only = os.environ.get("ONIRIS_ONLY_MODE")
 
+    accum = max(1, args.accum)
+    from edm2.loss import learning_rate_schedule
+    ref_lr, sched_steps = 1e-2, 100000 / 50                      # gym_train.py:69,110-112 (total_number_of_steps / 50)
+    micro = [0]                                                  # micro-steps taken (the reference's loop index i)
+
     def step(i, profile=False):
         just_2d = (i % 4 == 0)                                   # gym_train.py:96
         if _only:                                                # profiling aid: ONIRIS_ONLY_MODE=2d|3d (not the metric)
             just_2d = _only == "2d"
+        if accum > 1:
+            return accum_step(just_2d)
         if use_graph and not profile:
             loss = graphed[just_2d]()
             if world > 1:
@@ -294,6 +331,27 @@ def main():
             model.wait()
         nimg[0] += world * B
         opt.step(max_norm=max_norm, ema=ema.weights(nimg[0], world * B))      # t_next = images seen so far (gym_train.py:108)
+        return loss
+
+    def accum_step(just_2d):
+        """One micro-step of the reference loops with accumulation_steps = K (cs_train.py:105-127): backward under
+        no_sync() unless i % K == 0; on those i (except i = 0) optimizer.step, zero_grad, EMA update and the learning-rate
+        schedule written into param_groups."""
+        i = micro[0]
+        micro[0] += 1
+        sync_now = i % accum == 0
+        with (contextlib.nullcontext() if sync_now else model.no_sync()):
+            loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
+            loss.backward()
+        nimg[0] += world * B
+        if sync_now:
+            if world > 1 or force_dist:
+                model.wait()
+            if i != 0:
+                opt.step(max_norm=max_norm, ema=ema.weights(nimg[0], accum * world * B))
+                opt.zero_grad()
+                for g_ in opt.param_groups:
+                    g_["lr"] = learning_rate_schedule(i, ref_lr, sched_steps, sched_steps)
         return loss
 
     def fence():
@@ -388,6 +446,7 @@ def main():
                                       f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
                                       f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
                           "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
+                          **({"accum_NOT_THE_HEADLINE": accum, "lr": opt.param_groups[0]["lr"]} if accum > 1 else {}),
                           **({"shared_gpu_gloo_NOT_A_MEASUREMENT": True} if share else {}),
                           **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
                           **{k: round(v, 2) for k, v in per_mode.items()}},

@@ -98,6 +98,16 @@ int oniris_dart_loss_bwd(const void* F, const float* images, const float* noise,
                          const float* out_gain, const float* dlosses, void* dF, float* dgain_part, int B, int S, int T,
                          int C, int H, int W, float sigma_data, oniris_stream_t stream);
 
+/* Tail of EDM2Loss.__call__ + MultiNoiseLoss.add_data without a host round trip (replaces reference edm2/loss.py:32-46
+ * and edm2/loss_weight.py:30-39,104-111,126-131):  per (b, t) of the noised half, sigma read at sigma[b*sig_pitch + sig_off + t]:
+ *   l = mse[b][t] * (sigma^2 + sd^2) / (sigma*sd)^2;   m = 10^(Fourier series of log10 sigma, coef [2*nterms-1]);
+ *   out[0] = mean(l / m) (the training loss), out[1] = mean(l) (the un-weighted loss), dcoef[b][t] = d out[0] / d mse[b][t];
+ *   (sigma, l, t) is appended to the history rings ring_sigma / ring_loss / ring_pos [cap] behind the device-side entry
+ *   counter *count (entry e lives in slot e % cap); ring_sigma == NULL: no logging (ranks other than 0, loss_weight.py:33). */
+int oniris_loss_tail(const float* mse, const float* sigma, const float* coef, float* out, float* dcoef, float* ring_sigma,
+                     float* ring_loss, int* ring_pos, long long* count, int cap, int B, int T, int sig_pitch, int sig_off,
+                     int nterms, float sigma_data, oniris_stream_t stream);
+
 /* Eval-side counterparts (edm2/sampler.py: 31 evaluations per generated frame, every launch counts):
  * oniris_dart_input with noise == NULL packs c_in * x (Precond.forward's input side, networks_edm2.py:287-291);
  * oniris_precond_out: D [N][C][H][W] fp32 = c_skip * x + c_out * out_gain * F  (F = raw channels-last UNet output

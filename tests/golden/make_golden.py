@@ -431,7 +431,49 @@ def g11():
     save("g11_phema", stds=stds, t_next=tn, t_delta=td, exps=exps, betas=betas)
 
 
+# ------------------------------------------------------------------ G12 checkpoint in the reference's own file format
+CKPT_CFG = dict(img_resolution=16, img_channels=4, label_dim=4, model_channels=8, channel_mult=[1, 2], num_blocks=1,
+                video_attn_resolutions=[8], frame_attn_resolutions=[16])     # 8 / 16 channels: no attention heads, ~80 K parameters
+
+
+def g12():
+    """`g12_ckpt_ref.pt`: a {"state_dict", "kwargs"} file WRITTEN BY THE REFERENCE's BetterModule.save_to_state_dict
+    (edm2/utils.py:15-34) for a tiny UNet, + `g12_ckpt.npz`: an input and the reference's eval / 2-D-training outputs of the
+    model the reference rebuilds from that file with UNet.from_pretrained (:36-64).  save_to_state_dict imports boto3
+    unconditionally (:16, only used for s3:// paths): an empty module of that name is registered for the call."""
+    import types
+    sys.modules.setdefault("boto3", types.ModuleType("boto3"))
+    torch.manual_seed(1200)
+    unet = UNet(**CKPT_CFG)
+    with torch.no_grad():                                   # the zero-initialised gains would hide most of the net
+        unet.out_gain.fill_(0.8)
+        for m in unet.modules():
+            if hasattr(m, "emb_gain"):
+                m.emb_gain.fill_(0.3)
+            if isinstance(m, Gating):
+                m.offset.copy_(torch.randn(2) * 0.3)
+                m.max_gating.fill_(1.0)
+    path = os.path.join(HERE, "g12_ckpt_ref.pt")
+    unet.save_to_state_dict(path)
+    print(f"g12_ckpt_ref.pt: {os.path.getsize(path) / 1024:.0f} KiB, kwargs = {unet.kwargs}")
+    again = UNet.from_pretrained(path).eval()
+    g = torch.Generator().manual_seed(1201)
+    B, t = 2, 4
+    x = torch.randn(B, t, 4, 16, 16, generator=g)
+    c_noise = torch.randn(B, t, generator=g) * 0.5
+    lab = torch.randint(0, 4, (B, t), generator=g)
+    with torch.no_grad():
+        y_eval, cache = again(x, c_noise, lab, update_cache=True)
+        x1 = torch.randn(B, 1, 4, 16, 16, generator=g)
+        y_next, _ = again(x1, c_noise[:, :1], lab[:, :1], cache=cache)
+    again.train()
+    with torch.no_grad():
+        y_2d, _ = again(x, c_noise, lab, just_2d=True)      # (training mode: forced weight normalisation, conv.py:16-18)
+    save("g12_ckpt", x=x, c_noise=c_noise, labels=lab, y_eval=y_eval, x1=x1, y_next=y_next, y_2d=y_2d,
+         n_params=np.int64(unet.n_params), keys=np.array(sorted(unet.state_dict().keys())))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

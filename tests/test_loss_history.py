@@ -1,0 +1,102 @@
+"""sigma-loss history of MultiNoiseLoss (reference edm2/loss_weight.py:30-48,122-162): last 10 000
+(sigma, loss, position) triples, read by the Fourier fit.  CPU: the host lists; GPU: the device rings the loss kernel
+appends to (oniris_loss_tail) against the reference's concatenate-and-truncate bookkeeping, incl. wrap-around."""
+import math
+import pytest
+import torch
+
+
+def _reference_history(chunks, h):
+    """edm2/loss_weight.py:35-39 restated: cat, keep the last h."""
+    s, l, p = torch.tensor([]), torch.tensor([]), torch.tensor([], dtype=torch.int64)
+    for sg, ls in chunks:
+        pos = torch.arange(sg.numel()) % sg.shape[1]
+        s, l, p = torch.cat((s, sg.flatten()))[-h:], torch.cat((l, ls.flatten()))[-h:], torch.cat((p, pos))[-h:]
+    return s, l, p
+
+
+def test_host_history_keeps_the_last_entries_in_order():
+    from edm2.loss_weight import MultiNoiseLoss
+    m = MultiNoiseLoss()
+    m.history_size = 50
+    g = torch.Generator().manual_seed(0)
+    chunks = [(torch.rand(3, 7, generator=g) + 0.1, torch.rand(3, 7, generator=g)) for _ in range(5)]
+    for sg, ls in chunks:
+        m.add_data(sg, ls)
+    s, l, p = _reference_history(chunks, 50)
+    assert torch.equal(m.sigmas, s) and torch.equal(m.losses, l) and torch.equal(m.positions, p)
+    assert list(m.state_dict().keys()) == ["fourier_approximator.coefficients"]        # the history is not checkpointed
+
+
+def test_fit_reads_the_history_and_changes_the_mean_loss():
+    from edm2.loss_weight import MultiNoiseLoss
+    m = MultiNoiseLoss()
+    g = torch.Generator().manual_seed(1)
+    sg = (torch.randn(40, 16, generator=g) * 1.0 + 0.5).exp()
+    m.add_data(sg, 0.3 / sg + 0.05)                        # a smooth loss-vs-sigma curve
+    assert torch.allclose(m.calculate_mean_loss(sg), torch.ones_like(sg))              # zero coefficients: 10^0
+    m.fit_loss_curve()
+    fit = m.calculate_mean_loss(sg)
+    keep = (sg.log10().abs() <= math.pi)
+    assert ((fit - (0.3 / sg + 0.05)).abs() / (0.3 / sg + 0.05))[keep].median() < 0.1
+
+
+@pytest.mark.gpu
+def test_loss_tail_kernel_matches_the_torch_formulation_and_logs_on_device():
+    from autoregressive_diffusion_amd import ops
+    from edm2.loss_weight import MultiNoiseLoss
+    dev = "cuda"
+    torch.manual_seed(2)
+    nw = MultiNoiseLoss().to(dev)
+    nw.history_size = 300                                   # 4 x 128 entries: the rings wrap
+    nw.fourier_approximator.coefficients.data.copy_(torch.randn(7, 1) * 0.3)
+    B, T, sd = 2, 64, 1.0
+    chunks = []
+    for step in range(4):
+        S = 1 if step == 2 else 2                           # (a 2-D step: sigma has T columns, not 2T)
+        mse = (torch.rand(B, T, device=dev) + 0.1).requires_grad_(True)
+        sigma = (torch.randn(B, S * T, device=dev) * 1.0 + 1.2).exp()
+        loss, unw = ops.loss_tail(mse, sigma, nw.fourier_approximator.coefficients, nw.device_history(torch.device(dev, 0)), sd)
+        loss.backward()
+        m2 = mse.detach().clone().requires_grad_(True)
+        sg = sigma[:, -T:]
+        l = m2 * (sg ** 2 + sd ** 2) / (sg * sd) ** 2
+        ref = (l / nw.calculate_mean_loss(sg)).mean()
+        ref.backward()
+        assert abs(loss.item() - ref.item()) <= 2e-5 * abs(ref.item())
+        assert abs(unw.item() - l.mean().item()) <= 2e-5 * abs(l.mean().item())
+        assert torch.allclose(mse.grad, m2.grad, rtol=2e-4, atol=1e-9)
+        chunks.append((sg.cpu(), l.detach().cpu()))
+    s, l, p = _reference_history(chunks, 300)
+    assert torch.equal(nw.sigmas, s) and torch.equal(nw.positions, p)
+    assert torch.allclose(nw.losses, l, rtol=1e-5)
+    # torch-op append (the eager loss path's add_data on HIP tensors) continues the same rings
+    nw.add_data(chunks[0][0].to(dev), chunks[0][1].to(dev))
+    s2, l2, p2 = _reference_history(chunks + [chunks[0]], 300)
+    assert torch.equal(nw.sigmas, s2) and torch.allclose(nw.losses, l2, rtol=1e-5) and torch.equal(nw.positions, p2)
+
+
+@pytest.mark.gpu
+def test_no_sync_training_step_still_logs_sigma_and_loss():
+    """VERDICT r02 missing #2: the benched step (sync=False) used to skip noise_weight.add_data (reference loss.py:43)."""
+    import paramgen
+    from edm2.networks_edm2 import UNet, Precond
+    from edm2.loss import EDM2Loss
+    cfg = dict(img_resolution=32, img_channels=4, label_dim=4, model_channels=16, channel_mult=[1, 4, 4],
+               num_blocks=1, video_attn_resolutions=[8], frame_attn_resolutions=[16])
+    net = Precond(UNet(**cfg), sigma_data=1.0)
+    net.load_state_dict({k: v.clone() for k, v in paramgen.prenormalise(paramgen.precond_params(cfg, 5)).items()})
+    net = net.to("cuda").train()
+    loss_fn = EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5)
+    images = torch.randn(2, 4, 4, 32, 32, device="cuda")
+    lab = torch.randint(0, 4, (2, 4), device="cuda")
+    seen = []
+    for i in range(3):
+        loss, unw = loss_fn(net, images, lab, just_2d=(i == 1), sync=False)
+        assert torch.is_tensor(unw) and unw.is_cuda               # no host round trip in the call
+        loss.backward()
+        seen.append(float(unw))
+    assert net.noise_weight.sigmas.numel() == 3 * 8 and net.noise_weight.positions.tolist() == [0, 1, 2, 3] * 6
+    per_step = net.noise_weight.losses.reshape(3, 8).mean(1)
+    assert torch.allclose(per_step, torch.tensor(seen), rtol=1e-5)
+    net.noise_weight.fit_loss_curve()                              # (reads the device rings; must not raise)

@@ -724,3 +724,65 @@ def test_optimizer_skips_parameters_without_gradient(graph):
     assert float(flat.slice_of(opt.v, ctx_params[0]).abs().max()) > 0.0
     sd = opt.state_dict()["state"]
     assert len(sd) == sum(1 for s_ in opt.param_steps if s_ > 0) < len(flat.params)
+
+
+def test_graphed_step_without_params_finds_its_flat_params():
+    """GraphedStep(fn) with neither params= nor flat= (the pre-existing call form) must still restore the
+    host-side "received a gradient" bookkeeping after a replay -- otherwise FlatAdamW freezes every kernel-owned conv
+    weight and every directly packed gate from the first replay on.  FlatParams(lazy_small=False)."""
+    from edm2.loss import EDM2Loss
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW
+    from autoregressive_diffusion_amd.graphs import GraphedStep
+    g = torch.Generator().manual_seed(80)
+    images = torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (1, 4), generator=g).to(DEV)
+    net = build_precond(SMALL_CFG, 58, 1.0).train()
+    flat = FlatParams(net.unet, lazy_small=False)
+    opt = FlatAdamW(flat, lr=1e-3)
+    loss_fn = EDM2Loss(sigma_data=1.0)
+
+    def fwd_bwd():
+        opt.zero_grad()
+        loss, _ = loss_fn(net, images, labels, sync=False)
+        loss.backward()
+        return loss
+    step = GraphedStep(fwd_bwd, warmup=1)
+    assert step.flat is flat
+    own = net.unet.enc["32x32_conv"].last_frame_conv.weight.weight
+    gate = net.unet.enc["32x32_conv"].gating.mult
+    pos = {id(p): i for i, p in enumerate(flat.params)}
+    for n in range(1, 5):                              # eager warm-up, capture (+ first replay), two more replays
+        step()
+        opt.step()
+        torch.cuda.synchronize()
+        assert opt.param_steps[pos[id(own)]] == n and opt.param_steps[pos[id(gate)]] == n, n
+    assert step.graph is not None
+
+
+def test_zero_grad_set_to_none_between_forward_and_backward():
+    """`loss = model(x); opt.zero_grad(); loss.backward()` with torch's default set_to_none=True releases the
+    .grad tensors the weight-gradient table was built on; the backward must re-validate it and deliver fresh gradients."""
+    from edm2.loss import EDM2Loss
+    g = torch.Generator().manual_seed(81)
+    images = torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (1, 4), generator=g).to(DEV)
+    sigma = (torch.randn(1, 8, generator=g) + 0.4).exp().to(DEV)
+    eps = torch.randn(1, 8, 4, 32, 32, generator=g).to(DEV)
+    net = build_precond(SMALL_CFG, 59, 1.0).train()
+    topt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    loss_fn = EDM2Loss(sigma_data=1.0)
+    loss, _ = loss_fn(net, images, labels, sigma=sigma, noise=eps)
+    loss.backward()                                     # reference gradients (first step: .grad created by the table)
+    want = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    topt.zero_grad()                                    # set_to_none=True: every .grad is gone
+    loss, _ = loss_fn(net, images, labels, sigma=sigma, noise=eps)
+    topt.zero_grad()                                    # ... also between forward and backward
+    junk = [torch.full_like(p, 7.0) for p in net.parameters()]        # recycle the allocator blocks the old grads lived in
+    loss.backward()
+    torch.cuda.synchronize()
+    assert all(float(j.min()) == 7.0 and float(j.max()) == 7.0 for j in junk), "the backward wrote into freed memory"
+    got = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    k = "unet.enc.32x32_conv.last_frame_conv.weight.weight"
+    assert k in got and set(want) == set(got)
+    # (the first step's forced weight normalisation moved the weights by < 1e-4, so the gradients agree closely)
+    assert rel(got[k], want[k]) < 2e-2 and rel(got["unet.dec.8x8_in0.conv_res1.weight.weight"], want["unet.dec.8x8_in0.conv_res1.weight.weight"]) < 2e-2
