@@ -24,17 +24,10 @@ class GraphedStep:
         from .parallel import FlatParams
         if flat is None and self.params:
             flat = FlatParams.owner_of(self.params[0])
-        if flat is None:
-            # GraphedStep(fn) with neither params= nor flat=: without the FlatParams the replays cannot re-apply the
-            # gradient bookkeeping and FlatAdamW would silently freeze every kernel-owned weight after the capture step.
-            # One live FlatParams: it is the one; several: the caller has to say which.
-            live = FlatParams.live()
-            if len(live) == 1:
-                flat = live[0]
-            elif len(live) > 1:
-                raise ValueError("GraphedStep: several FlatParams are alive -- pass flat= (or params=) so that the replays "
-                                 "can restore which parameters received a gradient")
-        self.flat, self._touched = flat, ([], [])
+        # GraphedStep(fn) with neither params= nor flat=: without a FlatParams the replays could not re-apply the gradient
+        # bookkeeping and FlatAdamW would silently freeze every kernel-owned weight after the capture step.  The owner is
+        # then found at capture time: whichever live FlatParams the captured backward marked (snapshot_touched non-empty).
+        self.flat, self._touched = flat, []
         self.graph, self.out, self.calls = None, None, 0
         # ONE side stream for the warm-up and the capture of EVERY GraphedStep: autograd pins each parameter's
         # AccumulateGrad node to the stream it was first used on; a node living on another stream would run outside
@@ -56,8 +49,8 @@ class GraphedStep:
             cur.wait_stream(self.stream)
             for p, g in self._grads:
                 p.grad = g
-            if self.flat is not None:
-                self.flat.restore_touched(self._touched)
+            for f, snap in self._touched:
+                f.restore_touched(snap)
             return self.out
         self.calls += 1
         if self.calls <= self.warmup:              # eager warm-up: builds tables, sets kernel attributes, fills caches
@@ -72,6 +65,9 @@ class GraphedStep:
             out = self.fn()
         self.graph, self.out = g, out
         self._grads = [(p, p.grad) for p in self.params if p.grad is not None]
-        if self.flat is not None:
-            self._touched = self.flat.snapshot_touched()
+        from .parallel import FlatParams
+        cands = [self.flat] if self.flat is not None else FlatParams.live()
+        self._touched = [(f, snap) for f, snap in ((f, f.snapshot_touched()) for f in cands) if snap[0] or snap[1]]
+        if self.flat is None and len(self._touched) == 1:
+            self.flat = self._touched[0][0]
         return self.__call__()
