@@ -23,7 +23,7 @@ build/misc.cpp.o: $(CSRC)/misc.cpp $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 
 $(OUT): $(OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $@ $(OBJS)
 
 # diagnostic build: the attention kernels with in-kernel cycle stamps (scratch/attn_stamp.py loads it through
 # ONIRIS_LIB_NAME); never used by the product path
@@ -35,7 +35,7 @@ build/conv_fwd_s2ctx_stamp.o: $(CSRC)/conv_fwd_s2ctx.hip $(HDRS)
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -DCONV_STAMP -c $< -o $@
 stamp: build/attention_stamp.o build/conv_fwd_s2ctx_stamp.o $(OBJS)
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(STAMP_OUT) build/attention_stamp.o build/conv_fwd_s2ctx_stamp.o $(filter-out build/attention.hip.o build/conv_fwd_s2ctx.hip.o,$(OBJS)) -L/opt/rocm/lib -lrccl -Wl,-rpath,/opt/rocm/lib
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o $(STAMP_OUT) build/attention_stamp.o build/conv_fwd_s2ctx_stamp.o $(filter-out build/attention.hip.o build/conv_fwd_s2ctx.hip.o,$(OBJS))
 
 clean:
 	rm -rf build $(OUT)

@@ -21,7 +21,7 @@ c_void_p, c_int, c_float, c_int32, c_int64, c_size_t = C.c_void_p, C.c_int, C.c_
 
 
 class WeightDesc(C.Structure):
-    _fields_ = [("w", c_void_p), ("grad", c_void_p), ("wf", c_void_p), ("wb", c_void_p), ("dwp", c_void_p),
+    _fields_ = [("w", c_void_p), ("grad", c_void_p), ("wf", c_void_p), ("wb", c_void_p), ("dwp", c_void_p), ("dws", c_void_p),
                 ("cout", c_int32), ("cin", c_int32), ("taps", c_int32), ("kt", c_int32),
                 ("CoutP", c_int32), ("CinP", c_int32), ("CoutPb", c_int32), ("CinPb", c_int32),
                 ("row_start", c_int32), ("perm3", c_int32), ("gain", c_float), ("nsplit_cap", c_int32),
@@ -131,10 +131,6 @@ _SIGS = {
     "oniris_attn_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_attn_bwd_dq": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "oniris_attn_bwd_dkv": (c_int, [C.POINTER(AttnArgs), c_void_p]),
-    "oniris_comm_unique_id": (c_int, [c_void_p]),
-    "oniris_comm_init": (c_int, [C.POINTER(c_void_p), c_int, c_int, c_void_p]),
-    "oniris_comm_allreduce_sum_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
-    "oniris_comm_destroy": (c_int, [c_void_p]),
 }
 EXPORTED = sorted(_SIGS)
 

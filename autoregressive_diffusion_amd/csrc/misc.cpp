@@ -1,11 +1,10 @@
-// Host-only pieces of liboniris_hip.so: error string, ABI version, mask tables, RCCL helpers.
+// Host-only pieces of liboniris_hip.so: error string, ABI version, mask tables, attention schedule.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
 #include <vector>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include "common.h"
 #include "../../include/oniris.h"
 
@@ -133,36 +132,6 @@ extern "C" int oniris_attn_schedule(int n_pairs, int n_blocks, const int32_t* we
   for (int w = 0; w < n_wg; ++w)
     for (int k = 0; k < n_slots; ++k) sched[(size_t)w * n_slots + k] = k < (int)lists[w].size() ? lists[w][k] : -1;
   return need;
-}
-
-// ---- RCCL helpers
-extern "C" int oniris_comm_unique_id(void* id128) {
-  ONIRIS_CHECK_ARG(id128, "comm_unique_id: null");
-  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
-  ncclUniqueId id;
-  if (ncclGetUniqueId(&id) != ncclSuccess) { oniris_set_error("ncclGetUniqueId failed"); return ONIRIS_ELAUNCH; }
-  memcpy(id128, &id, 128);
-  return ONIRIS_OK;
-}
-extern "C" int oniris_comm_init(void** comm, int rank, int world, const void* id128) {
-  ONIRIS_CHECK_ARG(comm && id128 && world > 0 && rank >= 0 && rank < world, "comm_init: bad arguments");
-  ncclUniqueId id;
-  memcpy(&id, id128, 128);
-  ncclComm_t c;
-  ncclResult_t r = ncclCommInitRank(&c, world, id, rank);
-  if (r != ncclSuccess) { oniris_set_error("ncclCommInitRank: %s", ncclGetErrorString(r)); return ONIRIS_ELAUNCH; }
-  *comm = (void*)c;
-  return ONIRIS_OK;
-}
-extern "C" int oniris_comm_allreduce_sum_f32(void* comm, float* buf, size_t count, oniris_stream_t stream) {
-  ONIRIS_CHECK_ARG(comm && buf, "comm_allreduce: null");
-  ncclResult_t r = ncclAllReduce(buf, buf, count, ncclFloat, ncclSum, (ncclComm_t)comm, (hipStream_t)stream);
-  if (r != ncclSuccess) { oniris_set_error("ncclAllReduce: %s", ncclGetErrorString(r)); return ONIRIS_ELAUNCH; }
-  return ONIRIS_OK;
-}
-extern "C" int oniris_comm_destroy(void* comm) {
-  if (comm) ncclCommDestroy((ncclComm_t)comm);
-  return ONIRIS_OK;
 }
 
 // sizes of the argument structs, so a binding (ctypes, cgo, JNI ...) can verify its mirror of include/oniris.h

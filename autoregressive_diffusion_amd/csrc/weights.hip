@@ -111,57 +111,61 @@ __global__ __launch_bounds__(256) void weight_wb_kernel(const OnirisWeightDesc* 
   }
 }
 
-// grad(w_hat) of   W = gain/sqrt(f) * w_hat / (eps + |w_hat|/sqrt(f))   given dW (packed fp32, from wgrad)
+// grad(w_hat) of   W = gain/sqrt(f) * w_hat / (eps + |w_hat|/sqrt(f))   given dW (packed bf16 split-K slabs, from wgrad)
 __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc* descs, int ndesc) {
   __shared__ float red[16];
   const int row = blockIdx.x;
   const OnirisWeightDesc* d = find_desc(descs, ndesc, row);
-  if (d->dwp == nullptr || d->grad == nullptr) return;
+  if (d->dwp == nullptr || d->dws == nullptr || d->grad == nullptr) return;
   const int co = row - d->row_start;
   const int taps = d->taps, cin = d->cin;
   const int fan = cin * taps;
   const float* w = d->w + (size_t)co * fan;
   float* g = d->grad + (size_t)co * fan;
   const int cop = perm_row(d, co);
-  float* dwp = d->dwp;
+  const bf16* dwp = (const bf16*)d->dwp;
+  float* dws = d->dws;
   const float rs = rsqrtf((float)fan);
 
   const int nsp = d->nsplit ? *d->nsplit : 1;
   if (nsp <= 0) return;                                         // no wgrad ran for this weight in this step
   const size_t slab = (size_t)taps * d->CoutP * d->CinP;
-  // pass 1 (packed order: ci contiguous -> coalesced slab reads): G = sum over the split-K slabs, kept in slab 0
+  // pass 1 (packed order: ci contiguous -> coalesced slab reads): G = fp32 sum over the bf16 split-K slabs, kept in dws
   float dot = 0.f, nn = 0.f;
-  if ((cin & 3) == 0) {
-    // 16 bytes per lane and up to 8 independent slab reads in flight: with 4-byte loads and 4 chains the kernel ran at
-    // ~2.2 TB/s (a thread had 16 bytes in flight; the slabs are 1.7 GB per step)
-    const int c4 = cin >> 2, items = taps * c4;
+  if ((cin & 7) == 0) {
+    // 16 bytes (8 slab values) per lane and up to 8 independent slab reads in flight (a thread with 4-byte loads and 4
+    // chains had 16 bytes in flight and the kernel ran at ~2.2 TB/s)
+    const int c8 = cin >> 3, items = taps * c8;
     for (int it = threadIdx.x; it < items; it += 256) {
-      const int tap = it / c4, ci = (it - tap * c4) * 4;
+      const int tap = it / c8, ci = (it - tap * c8) * 8;
       const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
-      float4 G[8];
+      float G[4][8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) G[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) G[u][j] = 0.f;
       int s_ = 0;
       for (; s_ + 7 < nsp; s_ += 8) {
+        bf16x8 t[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const float4 t = *(const float4*)(dwp + (size_t)(s_ + u) * slab + pi);
-          G[u].x += t.x; G[u].y += t.y; G[u].z += t.z; G[u].w += t.w;
-        }
+        for (int u = 0; u < 8; ++u) t[u] = *(const bf16x8*)(dwp + (size_t)(s_ + u) * slab + pi);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) G[u & 3][j] += bf2f(t[u][j]);
       }
       for (; s_ < nsp; ++s_) {
-        const float4 t = *(const float4*)(dwp + (size_t)s_ * slab + pi);
-        G[0].x += t.x; G[0].y += t.y; G[0].z += t.z; G[0].w += t.w;
-      }
-      float4 Gs;
-      Gs.x = ((G[0].x + G[1].x) + (G[2].x + G[3].x)) + ((G[4].x + G[5].x) + (G[6].x + G[7].x));
-      Gs.y = ((G[0].y + G[1].y) + (G[2].y + G[3].y)) + ((G[4].y + G[5].y) + (G[6].y + G[7].y));
-      Gs.z = ((G[0].z + G[1].z) + (G[2].z + G[3].z)) + ((G[4].z + G[5].z) + (G[6].z + G[7].z));
-      Gs.w = ((G[0].w + G[1].w) + (G[2].w + G[3].w)) + ((G[4].w + G[5].w) + (G[6].w + G[7].w));
-      if (nsp > 1) *(float4*)(dwp + pi) = Gs;
-      const float gv[4] = {Gs.x, Gs.y, Gs.z, Gs.w};
+        const bf16x8 t = *(const bf16x8*)(dwp + (size_t)s_ * slab + pi);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < 8; ++j) G[s_ & 3][j] += bf2f(t[j]);
+      }
+      float gv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gv[j] = (G[0][j] + G[1][j]) + (G[2][j] + G[3][j]);
+      *(float4*)(dws + pi) = make_float4(gv[0], gv[1], gv[2], gv[3]);
+      *(float4*)(dws + pi + 4) = make_float4(gv[4], gv[5], gv[6], gv[7]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
         const float v = w[(ci + j) * taps + tap];
         dot += gv[j] * v; nn += v * v;
       }
@@ -173,16 +177,16 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
     float G0 = 0.f, G1 = 0.f, G2 = 0.f, G3 = 0.f;            // 4 independent load chains (HBM latency)
     int s_ = 0;
     for (; s_ + 3 < nsp; s_ += 4) {
-      G0 += dwp[(size_t)s_ * slab + pi];       G1 += dwp[(size_t)(s_ + 1) * slab + pi];
-      G2 += dwp[(size_t)(s_ + 2) * slab + pi]; G3 += dwp[(size_t)(s_ + 3) * slab + pi];
+      G0 += bf2f(dwp[(size_t)s_ * slab + pi]);       G1 += bf2f(dwp[(size_t)(s_ + 1) * slab + pi]);
+      G2 += bf2f(dwp[(size_t)(s_ + 2) * slab + pi]); G3 += bf2f(dwp[(size_t)(s_ + 3) * slab + pi]);
     }
-    for (; s_ < nsp; ++s_) G0 += dwp[(size_t)s_ * slab + pi];
+    for (; s_ < nsp; ++s_) G0 += bf2f(dwp[(size_t)s_ * slab + pi]);
     const float G = (G0 + G1) + (G2 + G3);
-    if (nsp > 1) dwp[pi] = G;
+    dws[pi] = G;
     const float v = w[ci * taps + tap];
     dot += G * v; nn += v * v;
   }
-  dot = block_sum(dot, red);          // (block_sum's barriers also order the slab-0 writes before pass 2)
+  dot = block_sum(dot, red);          // (block_sum's barriers also order the dws writes before pass 2)
   nn = block_sum(nn, red);
   const float n = sqrtf(nn);
   const float s = W_EPS + n * rs;
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
     const int tap = q / cin, ci = q - tap * cin;
     const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
     const int e = ci * taps + tap;
-    g[e] += k1 * dwp[pi] - k2 * w[e];
+    g[e] += k1 * dws[pi] - k2 * w[e];
   }
 }
 

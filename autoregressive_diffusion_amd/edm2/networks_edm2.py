@@ -206,8 +206,7 @@ class UNet(BetterModule):
                 gains = eb[1][:] = [b.emb_gain for b in blocks]
             cs = dict(zip(map(id, blocks), ops.emb_scales(emb, self.__dict__["_oniris_groups"][0], gains)))
             skips = []
-            stage_cb = self.__dict__.get("_oniris_stage_cb")
-            stage_at = self.__dict__.get("_oniris_stage_at") if stage_cb is not None else None
+            stage_hooks = self.__dict__.get("_oniris_stage_hooks") or {}    # OnirisDDP: {("enc" | "dec", name): tensor hook}
             for name, block in self.enc.items():
                 if isinstance(block, Block):
                     xcl, cache["enc", name] = block._cl(xcl, emb, B, c_noise, cache.get(("enc", name)), update_cache, just_2d,
@@ -215,8 +214,9 @@ class UNet(BetterModule):
                 else:
                     xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
                 skips.append(xcl)
-                if name == stage_at and xcl.requires_grad:            # everything downstream of here is final when
-                    xcl.register_hook(stage_cb)                       # this gradient arrives (OnirisDDP stage 1)
+                cb = stage_hooks.get(("enc", name))
+                if cb is not None and xcl.requires_grad:              # everything downstream of here is final when
+                    xcl.register_hook(cb)                             # this gradient arrives (an OnirisDDP stage)
             for name, block in self.dec.items():
                 skip, cat_w = None, None
                 if "block" in name:                                   # mp_cat(x, skip, t) fused into the block's act kernel
@@ -226,6 +226,9 @@ class UNet(BetterModule):
                     cat_w = (Cn / math.sqrt(Na) * (1 - t), Cn / math.sqrt(Nb) * t)
                 xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d,
                                                     skip=skip, cat_w=cat_w, c=cs[id(block)])
+                cb = stage_hooks.get(("dec", name))
+                if cb is not None and xcl.requires_grad:
+                    xcl.register_hook(cb)
             xcl, cache["out_conv"] = self.out_conv._cl(xcl, B, c_noise, cache.get("out_conv"), update_cache, just_2d)
             if _cl_io is not None:
                 return xcl, cache
@@ -254,33 +257,48 @@ class UNet(BetterModule):
             cls[id(p)] = 2
         return cls
 
-    def _oniris_overlap_plan(self, head_frac=0.12):
-        """(name of an encoder block, [parameters]) for OnirisDDP's early gradient exchange: the kernel-owned weights
-        (their .grad is written by weight_bwd, not by autograd) of every block AFTER the named one are final as soon
-        as the backward pass has produced the gradient of that block's output -- the backward of the remaining,
-        activation-heavy encoder levels then overlaps their all-reduce.  The boundary is the last encoder block up to
-        which at most `head_frac` of the kernel-owned parameters live.  Everything autograd accumulates itself (gates,
-        emb_gain: evaluated once for all blocks at the top of forward; the grouped emb_linear weights) stays in the
-        final exchange."""
+    def _oniris_overlap_stages(self, max_stages=6, head_frac=0.06):
+        """[((side, block name), [parameters])] for OnirisDDP's early gradient exchanges, in the order the stages become
+        final during backward.  The kernel-owned weights (their .grad is written by weight_bwd, not by autograd) of every
+        block AFTER a given one (forward order) are final as soon as the backward pass has produced the gradient of that
+        block's output -- a tensor hook there starts their exchange beside the backward kernels still to come.  Backward
+        walks out_conv, the decoder from its last block to its first, then the encoder from its last block to its first;
+        the walk is cut into at most `max_stages` stages of about equal parameter count (the deep decoder / encoder levels
+        hold the parameters, the outer levels the time), stopping where at most `head_frac` of them are left: those, and
+        everything autograd accumulates itself (gates, emb_gain: evaluated once for all blocks at the top of forward; the
+        grouped emb_linear weights), go out in the final exchange."""
         from .conv import NormalizedWeight
 
         def owned(mod, skip=()):
-            return [m.weight for m in mod.modules() if isinstance(m, NormalizedWeight) and id(m.weight) not in skip]
+            return [m.weight for m in mod.modules() if isinstance(m, NormalizedWeight) and id(m.weight) not in skip
+                    and m.weight.requires_grad]
         late = {id(b.emb_linear.weight.weight) for b in self._emb_blocks()}
-        names = list(self.enc.keys())
-        per = [owned(self.enc[n], late) for n in names]
-        tail_dec = [w for b in self.dec.values() for w in owned(b, late)] + owned(self.out_conv, late)
-        total = sum(w.numel() for ws in per for w in ws) + sum(w.numel() for w in tail_dec)
-        cum, at = 0, None
-        for i, ws in enumerate(per):
-            cum += sum(w.numel() for w in ws)
-            if cum > head_frac * total:
-                break
-            at = i
-        if at is None:
-            return None
-        early = [w for ws in per[at + 1:] for w in ws] + tail_dec
-        return names[at], [w for w in early if w.requires_grad]
+        # blocks in BACKWARD order with the activation whose gradient marks "everything up to here is done": the output of
+        # the block that precedes them in forward order
+        fwd = [(("enc", n), b) for n, b in self.enc.items()] + [(("dec", n), b) for n, b in self.dec.items()]
+        order = [(fwd[-1][0], owned(self.out_conv, late))]                # out_conv is final once dec[-1]'s output has its gradient
+        for i in range(len(fwd) - 1, 0, -1):
+            order.append((fwd[i - 1][0], owned(fwd[i][1], late)))         # block i is final once block i-1's output has its gradient
+        total = sum(w.numel() for _, ws in order for w in ws) + sum(w.numel() for w in owned(fwd[0][1], late))
+        if total == 0:
+            return []
+        per_stage = total * (1.0 - head_frac) / max_stages
+        stages, cur, acc, done = [], [], 0, 0
+        for key, ws in order:
+            cur += ws
+            acc += sum(w.numel() for w in ws)
+            if acc >= per_stage and cur:
+                stages.append((key, cur))
+                done += acc
+                cur, acc = [], 0
+                if len(stages) == max_stages or done >= total * (1.0 - head_frac):
+                    break
+        return stages
+
+    def _oniris_overlap_plan(self, head_frac=0.12):
+        """One-stage form (round 2): (encoder block name, [parameters behind it])."""
+        st = self._oniris_overlap_stages(max_stages=1, head_frac=head_frac)
+        return (st[0][0], st[0][1]) if st else None
 
     def prewarm_eval(self, cache):
         """Build, OUTSIDE any hipGraph capture, the small per-frame-count device tables the next cached one-frame

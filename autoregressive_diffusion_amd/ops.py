@@ -134,7 +134,7 @@ def attn_schedule(weights, n_pairs, device, n_wg=None):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched")
+                 "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched")
 
 
 def _nsplit_cap(cin, cout, taps):
@@ -211,7 +211,7 @@ class WeightBank:
         w.CoutP, w.CinP = roundup(w.cout, 32), roundup(w.cin, 64)
         w.CoutPb, w.CinPb = roundup(w.cin, 32), roundup(w.cout, 64)
         w.perm3, w.gain = bool(perm3), float(gain)
-        w.wf = w.wb = w.dwp = w.nsplit = None
+        w.wf = w.wb = w.dwp = w.dws = w.nsplit = None
         w.group, w.goff, w.members = None, 0, None
         w.touched = False              # a weight-gradient launch targeted this weight since the last optimizer step
         # split-K slabs of the weight-gradient kernel: same bound as launch_wgrad() in csrc/conv_wgrad.hip
@@ -239,7 +239,7 @@ class WeightBank:
         g.cin, g.taps, g.kt = members[0].cin, 1, 1
         g.CinP, g.CoutPb = roundup(g.cin, 64), roundup(g.cin, 32)
         g.perm3, g.gain, g.param, g.bank = False, 1.0, members[0].param, self
-        g.wf = g.wb = g.dwp = g.nsplit = None
+        g.wf = g.wb = g.dwp = g.dws = g.nsplit = None
         g.touched = False
         g.nsplit_cap = _nsplit_cap(g.cin, g.cout, 1)
         self.groups.append(g)
@@ -265,12 +265,14 @@ class WeightBank:
             if g.wf is None or g.wf.device != device:
                 g.wf = torch.zeros(g.cout * g.CinP, dtype=BF16, device=device)
                 g.wb = torch.zeros(g.CoutPb * g.cout, dtype=BF16, device=device)
-                g.dwp = torch.empty(g.nsplit_cap * g.cout * g.CinP, dtype=torch.float32, device=device)
+                g.dwp = torch.empty(g.nsplit_cap * g.cout * g.CinP, dtype=BF16, device=device)
+                g.dws = torch.empty(g.cout * g.CinP, dtype=torch.float32, device=device)
             for m in g.members:
                 m.nsplit, m.nsplit_cap = g.nsplit, g.nsplit_cap
                 m.wf = g.wf[m.goff * g.CinP:]
                 m.wb = g.wb[m.goff:]
                 m.dwp = g.dwp[m.goff * g.CinP:]
+                m.dws = g.dws[m.goff * g.CinP:]
         for i, (w, need_dgrad) in enumerate(self.items):
             p = w.param
             if p.dtype != torch.float32 or not p.is_contiguous():
@@ -279,7 +281,10 @@ class WeightBank:
             if not grouped and (w.wf is None or w.wf.device != p.device):
                 w.wf = torch.zeros(w.taps * w.CoutP * w.CinP, dtype=BF16, device=device)
                 w.wb = torch.zeros(w.taps * w.CoutPb * w.CinPb, dtype=BF16, device=device) if need_dgrad else None
-                w.dwp = torch.empty(w.nsplit_cap * w.taps * w.CoutP * w.CinP, dtype=torch.float32, device=device)
+                # split-K slabs of the weight-gradient kernels: bf16 (the fp32 partial sum of a workgroup column is rounded
+                # once; ~2 GB per step in fp32 for the gym net, written by the wgrad kernels and read back by weight_bwd)
+                w.dwp = torch.empty(w.nsplit_cap * w.taps * w.CoutP * w.CinP, dtype=BF16, device=device)
+                w.dws = torch.empty(w.taps * w.CoutP * w.CinP, dtype=torch.float32, device=device)
             if p.requires_grad and p.grad is None:
                 p.grad = torch.zeros_like(p)
             d = descs[i]
@@ -288,6 +293,7 @@ class WeightBank:
             d.wf = w.wf.data_ptr()
             d.wb = w.wb.data_ptr() if w.wb is not None else None
             d.dwp = w.dwp.data_ptr()
+            d.dws = w.dws.data_ptr()
             d.cout, d.cin, d.taps, d.kt = w.cout, w.cin, w.taps, w.kt
             d.CoutP, d.CinP, d.CoutPb, d.CinPb = w.CoutP, w.CinP, w.CoutPb, w.CinPb
             if grouped:                                         # slice of the group's matrices (see add_group)

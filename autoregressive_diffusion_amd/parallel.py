@@ -33,6 +33,7 @@ class FlatParams:
     """Re-homes every trainable parameter of `module` (and its .grad) as a view into one flat fp32 buffer."""
 
     _registry = {}                 # id(parameter) -> weakref to the FlatParams that re-homed it (graphs.GraphedStep)
+    SEG_ALIGN = 3360               # = 2^5 * 3 * 5 * 7 elements: a segment splits evenly, in 16-byte units, over 1..8 ranks
 
     _instances = None              # WeakSet of the live FlatParams
 
@@ -57,31 +58,50 @@ class FlatParams:
         self.module = module
         self.names = {id(p): n for n, p in named}          # state_dict keys of the re-homed parameters
         self.orig_params = list(self.params)                # module.parameters() order (the order a torch optimizer sees)
-        # parameters whose gradient is final early in backward (module._oniris_overlap_plan) go, contiguous, to the
-        # END of the buffers: OnirisDDP exchanges [tail_start, numel) while the rest of backward is still running
-        plan = module._oniris_overlap_plan() if hasattr(module, "_oniris_overlap_plan") else None
+        # parameters whose gradient is final early in backward go, stage by stage, contiguous, BEHIND the rest of the
+        # buffers: OnirisDDP exchanges a stage's [lo, hi) while the rest of backward is still running.  The module names
+        # the stages in the order they become final: _oniris_overlap_stages() -> [(hook key, [parameters])], or the
+        # one-stage form _oniris_overlap_plan() -> (hook key, [parameters]).
+        if hasattr(module, "_oniris_overlap_stages"):
+            plan = [(k, list(ps)) for k, ps in (module._oniris_overlap_stages() or []) if ps]
+        elif hasattr(module, "_oniris_overlap_plan"):
+            one = module._oniris_overlap_plan()
+            plan = [(one[0], list(one[1]))] if one is not None and one[1] else []
+        else:
+            plan = []
         # parameters that receive a gradient on the same steps sit next to each other (module hint: 0 = every step,
         # 1 = 3-D steps only, 2 = never), so that FlatAdamW -- which, like torch.optim, skips parameters without a
         # gradient -- covers the buffer with a handful of contiguous launches.  Correctness never depends on the hint.
         cls = module._oniris_param_classes() if hasattr(module, "_oniris_param_classes") else {}
         by_class = lambda ps: sorted(ps, key=lambda p: cls.get(id(p), 0))          # (stable)
-        self.stage_at, ntail = None, 0
-        if plan is not None and plan[1]:
-            tail = {id(p) for p in plan[1]}
-            head = by_class([p for p in self.params if id(p) not in tail])
-            self.params = head + by_class([p for p in self.params if id(p) in tail])
-            self.stage_at, ntail = plan[0], len(self.params) - len(head)
-        else:
-            self.params = by_class(self.params)
+        mine = {id(p) for p in self.params}
+        staged, segs = set(), []
+        for key, ps in plan:
+            ps = [p for p in ps if id(p) in mine and id(p) not in staged]
+            staged.update(id(p) for p in ps)
+            if ps:
+                segs.append((key, by_class(ps)))
+        head = by_class([p for p in self.params if id(p) not in staged])
+        self.params = head + [p for _, ps in segs for p in ps]
         dev, dt = self.params[0].device, self.params[0].dtype
         assert all(p.dtype == dt and p.device == dev for p in self.params)
-        sizes = [p.numel() for p in self.params]
-        self.offsets, off = [], 0
-        for n in sizes:
+        # every segment (head, stages) starts on a multiple of SEG_ALIGN elements: divisible by every world size up to 8
+        # with 16-byte aligned shares -- the mesh exchange (OnirisDDP exchange="mesh") deals a segment out in equal chunks
+        self.offsets, off, seg_lo = [], 0, [0]
+        first_of_seg = {id(ps[0]) for _, ps in segs}
+        for p in self.params:
+            if id(p) in first_of_seg:
+                off = (off + self.SEG_ALIGN - 1) // self.SEG_ALIGN * self.SEG_ALIGN
+                seg_lo.append(off)
             self.offsets.append(off)
-            off += (n + 3) // 4 * 4                      # 16-byte aligned slices
+            off += (p.numel() + 3) // 4 * 4                      # 16-byte aligned slices
+        off = (off + self.SEG_ALIGN - 1) // self.SEG_ALIGN * self.SEG_ALIGN
         self.numel = off
-        self.tail_start = self.offsets[len(self.params) - ntail] if ntail else off
+        seg_hi = seg_lo[1:] + [off]
+        self.head = (0, seg_lo[1] if segs else off)               # [lo, hi) of everything that is exchanged at the end
+        self.stages = [(key, lo, hi) for (key, _), lo, hi in zip(segs, seg_lo[1:], seg_hi[1:])]      # firing order
+        self.stage_at = self.stages[0][0] if self.stages else None
+        self.tail_start = self.stages[0][1] if self.stages else off
         self.flat = torch.zeros(off, dtype=dt, device=dev)
         self.grad = torch.zeros(off, dtype=dt, device=dev)
         with torch.no_grad():
@@ -209,34 +229,70 @@ class FlatParams:
 
 
 class OnirisDDP(nn.Module):
-    """Data-parallel wrapper: forward delegates to `module`; at the END of every backward pass (unless inside
-    `no_sync()`) the flat gradient buffer is averaged over the process group in `bucket_mb`-sized all-reduces."""
+    """Data-parallel wrapper: forward delegates to `module`; during / at the end of every backward pass (unless inside
+    `no_sync()`) the flat gradient buffer is averaged over the process group.
 
-    def __init__(self, module, process_group=None, bucket_mb=256, flat=None):
+    Overlap.  The module names STAGES (FlatParams.stages): groups of parameters whose gradients are final when the
+    backward pass reaches a given activation (UNet: the decoder and deep-encoder levels, which hold the parameters, are
+    done long before the activation-heavy outer levels).  A tensor hook per stage turns the pending weight-gradient slabs
+    into parameter gradients and starts that stage's exchange on RCCL's stream, beside the remaining backward kernels;
+    the rest (`FlatParams.head`) follows at the end of backward.
+
+    exchange = "allreduce": one (bucketed) all-reduce per stage -- RCCL's ring / tree over xGMI.
+    exchange = "mesh":      reduce-scatter as ONE all-to-all per stage (every rank sends chunk r of the segment straight to
+                            rank r: on the xGMI full mesh each of the 7 links carries 1/8 of the bytes, instead of a ring
+                            pushing 7/8 of them through every link), a local sum, the optimizer on the OWNED chunks only
+                            (1/world of the AdamW / EMA work and traffic per GPU), then one all-gather of the updated
+                            parameters (FlatAdamW.step calls back: `after_step`).  SURVEY section 5: 1.24 GB of Counter-Strike
+                            gradients = 14.2 ms as a ring all-reduce vs ~2 x 1 ms.
+    grad_dtype = torch.bfloat16: the gradients travel as bf16 (half the bytes; fp32 master gradients are kept, the
+                            average is rounded once per element)."""
+
+    def __init__(self, module, process_group=None, bucket_mb=256, flat=None, exchange=None, grad_dtype=None,
+                 force_collectives=False):
+        """force_collectives: issue the collectives in a one-rank group too (tests / profiling of the exchange path)."""
         super().__init__()
+        import os
         self.module = module
+        self.force_collectives = bool(force_collectives)
         self.process_group = process_group
         self.flat = flat if flat is not None else FlatParams(module)
         self.bucket_elems = max(1, int(bucket_mb * (1 << 20) // 4))
+        self.exchange = exchange or os.environ.get("ONIRIS_DDP_EXCHANGE", "allreduce")
+        assert self.exchange in ("allreduce", "mesh"), self.exchange
+        if grad_dtype is None and os.environ.get("ONIRIS_DDP_BF16"):
+            grad_dtype = torch.bfloat16
+        self.grad_dtype = grad_dtype
         self._sync_enabled = True
         self._queued = False
-        self._works = []
-        self._tail_sent = False
+        self._works = []                   # [(work, finish callable | None)]
+        self._sent = [False] * len(self.flat.stages)
+        self._g16 = None                   # bf16 transport buffer (grad_dtype)
+        self._recv = {}                    # mesh: receive buffers per segment
         # FlatAdamW skips parameters that received no gradient, decided from rank-LOCAL bookkeeping (take_active), while the
         # exchange averages the whole flat gradient: ranks that ran different step kinds (just_2d on one rank only,
         # conditioning on some) would silently diverge.  The reference loops use i % 4 on every rank; this guard turns
         # a violation into an error: the bitmaps are compared on the first steps and every `active_check_every`-th.
         self.active_check_every, self._opt_steps = 100, 0
         self.flat._active_check = self._check_active
-        if self.flat.stage_at is not None:               # early exchange of the tail (see FlatParams / _stage)
-            module.__dict__["_oniris_stage_at"] = self.flat.stage_at
-            module.__dict__["_oniris_stage_cb"] = self._stage
+        if self.flat.stages:                             # early exchanges (see FlatParams / _stage)
+            hooks = {key: self._make_stage(i) for i, (key, _, _) in enumerate(self.flat.stages)}
+            module.__dict__["_oniris_stage_hooks"] = hooks
+            module.__dict__["_oniris_stage_at"] = self.flat.stages[0][0]       # (one-stage form, toy modules)
+            module.__dict__["_oniris_stage_cb"] = hooks[self.flat.stages[0][0]]
         # every rank starts from rank 0's parameters AND buffers (what torch DDP does at construction: MPFourier's
         # random freqs / phases are buffers, utils.py:63-64 -- ranks built from different RNG states would otherwise
         # keep different noise / time embeddings under shared weights)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self.flat.flat, src=0, group=self.process_group)
             self._broadcast_buffers()
+        if self.exchange == "mesh" and self._active():
+            world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+            segs = [self.flat.head] + [(lo, hi) for _, lo, hi in self.flat.stages]
+            self.flat._owned_ranges = [(lo + rank * ((hi - lo) // world), lo + (rank + 1) * ((hi - lo) // world))
+                                       for lo, hi in segs if hi > lo]
+            self.flat._after_step = self._allgather_params
+            self.flat._norm_reduce = self._sum_over_ranks
 
     def _broadcast_buffers(self):
         """Rank 0's module buffers to every rank: one coalesced broadcast per dtype, copied back in place."""
@@ -280,18 +336,27 @@ class OnirisDDP(nn.Module):
             return False
         return dist.get_world_size(self.process_group) > 1 or getattr(self, "force_collectives", False)
 
-    def _stage(self, grad):
-        """Tensor hook on the output of encoder block `flat.stage_at` (fires in the middle of backward): the weights
-        of every later block have all their wgrad slabs, so turn them into parameter gradients now (weight_bwd skips
-        weights with no pending slab) and start their all-reduce; RCCL runs it on its own stream, beside the backward
-        kernels of the remaining encoder levels."""
-        if self._sync_enabled and self._active() and not self._tail_sent:
-            bank = self.module.__dict__.get("_oniris_bank")
-            if bank is not None:
-                bank.backward()
-            self._exchange(self.flat.tail_start, self.flat.numel)
-            self._tail_sent = True
-        return None
+    def _make_stage(self, i):
+        def hook(grad):
+            """Tensor hook on the activation that ends stage i (fires in the middle of backward): the weights of every
+            block behind it have all their wgrad slabs, so turn them into parameter gradients now (weight_bwd skips
+            weights with no pending slab) and start their exchange; RCCL runs it on its own stream, beside the backward
+            kernels that are still to come.  Stages that did not fire by themselves (their activation needed no
+            gradient) go out with the next one."""
+            if self._sync_enabled and self._active() and not self._sent[i]:
+                bank = self.module.__dict__.get("_oniris_bank")
+                if bank is not None:
+                    bank.backward()
+                for j in range(i + 1):
+                    if not self._sent[j]:
+                        _, lo, hi = self.flat.stages[j]
+                        self._exchange(lo, hi)
+                        self._sent[j] = True
+            return None
+        return hook
+
+    def _stage(self, grad):                              # (one-stage form kept for callers of the round-2 API)
+        return self.module.__dict__["_oniris_stage_cb"](grad)
 
     def _end_of_backward(self):
         self._queued = False
@@ -300,17 +365,56 @@ class OnirisDDP(nn.Module):
         self.allreduce_grads()                           # (finalises weight gradients + gathers the small ones first)
 
     def _exchange(self, lo, hi):
+        if hi <= lo:
+            return
         g = self.flat.grad
         world = dist.get_world_size(self.process_group)
-        avg = g.is_cuda and dist.get_backend(self.process_group) == "nccl"   # RCCL averages in the collective; gloo has no AVG
-        if not avg:
-            g[lo:hi].mul_(1.0 / world)
-        op = dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM
-        self._works += [dist.all_reduce(g[s:min(hi, s + self.bucket_elems)], op=op, group=self.process_group,
-                                        async_op=True) for s in range(lo, hi, self.bucket_elems)]
+        nccl = g.is_cuda and dist.get_backend(self.process_group) == "nccl"    # RCCL averages in the collective; gloo has no AVG
+        if self.exchange == "mesh":
+            return self._exchange_mesh(lo, hi, world)
+        buf = g
+        if self.grad_dtype is not None:                  # bf16 transport: one cast pass each way, half the bytes on the links
+            if self._g16 is None:
+                self._g16 = torch.empty(self.flat.numel, dtype=self.grad_dtype, device=g.device)
+            buf = self._g16
+            buf[lo:hi].copy_(g[lo:hi])
+        if not nccl:
+            buf[lo:hi].mul_(1.0 / world)
+        op = dist.ReduceOp.AVG if nccl else dist.ReduceOp.SUM
+        for s in range(lo, hi, self.bucket_elems):
+            e = min(hi, s + self.bucket_elems)
+            w = dist.all_reduce(buf[s:e], op=op, group=self.process_group, async_op=True)
+            fin = (lambda s=s, e=e: g[s:e].copy_(self._g16[s:e])) if buf is not g else None
+            self._works.append((w, fin))
+
+    def _exchange_mesh(self, lo, hi, world):
+        """Reduce-scatter of segment [lo, hi) as ONE all-to-all (chunk r goes straight to rank r) + a local sum; the
+        averaged chunk this rank owns lands in its place of the flat gradient buffer (the other chunks keep this rank's
+        local, un-reduced values: nothing reads them -- the optimizer runs on the owned ranges only)."""
+        g = self.flat.grad
+        rank = dist.get_rank(self.process_group)
+        n = hi - lo
+        assert n % world == 0, "segments are SEG_ALIGN-aligned: divisible by every world size up to 8"
+        chunk = n // world
+        dt = self.grad_dtype or g.dtype
+        key = (lo, hi, dt)
+        if key not in self._recv:
+            self._recv[key] = (torch.empty(n, dtype=dt, device=g.device), torch.empty(n, dtype=dt, device=g.device) if dt != g.dtype else None)
+        recv, send16 = self._recv[key]
+        send = g[lo:hi]
+        if send16 is not None:
+            send16.copy_(send)
+            send = send16
+        w = dist.all_to_all_single(recv, send, group=self.process_group, async_op=True)
+
+        def fin(recv=recv, lo=lo, chunk=chunk, world=world, rank=rank):
+            own = g[lo + rank * chunk: lo + (rank + 1) * chunk]
+            torch.sum(recv.view(world, chunk).float() if recv.dtype != g.dtype else recv.view(world, chunk), dim=0, out=own)
+            own.mul_(1.0 / world)
+        self._works.append((w, fin))
 
     def allreduce_grads(self):
-        """Exchange whatever `_stage` has not sent yet (everything, when no stage fired in this backward).
+        """Exchange whatever the stage hooks have not sent yet (everything, when none fired in this backward).
         Also the entry point after a backward that ran under `no_sync()` (bench.py --graph replays forward+backward
         from a hipGraph and exchanges eagerly): the weight gradients are finalised and the autograd-owned small
         gradients (gates, emb_gain, out_gain, grouped emb weights) are gathered into the flat buffer FIRST, so that
@@ -319,10 +423,13 @@ class OnirisDDP(nn.Module):
         if bank is not None:
             bank._finish()                               # no-op unless a backward left it pending
         self.flat.gather()
-        sent, self._tail_sent = self._tail_sent, False
+        sent, self._sent = self._sent, [False] * len(self.flat.stages)
         if not self._active():
             return
-        self._exchange(0, self.flat.tail_start if sent else self.flat.numel)
+        for (_, lo, hi), done in zip(self.flat.stages, sent):
+            if not done:
+                self._exchange(lo, hi)
+        self._exchange(*self.flat.head)
 
     def _check_active(self, active):
         self._opt_steps += 1
@@ -338,10 +445,30 @@ class OnirisDDP(nn.Module):
                                "(different step kinds per rank?  e.g. just_2d or conditioning on some ranks only): the "
                                "optimizer would update them on some ranks and skip them on others")
 
+    def _sum_over_ranks(self, t):
+        """mesh mode: FlatAdamW's sum of squares covers the owned chunks only -- add the other ranks' (in place)."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.process_group)
+        return t
+
+    def _allgather_params(self):
+        """mesh mode, called by FlatAdamW.step after the update of the owned chunks: every rank receives the other ranks'
+        updated chunks of every segment (one all-gather per segment, straight over the mesh links)."""
+        world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        p = self.flat.flat
+        for lo, hi in [self.flat.head] + [(a, b) for _, a, b in self.flat.stages]:
+            if hi <= lo:
+                continue
+            chunk = (hi - lo) // world
+            mine = p[lo + rank * chunk: lo + (rank + 1) * chunk].clone()       # (input must not alias the output)
+            dist.all_gather_into_tensor(p[lo:hi], mine, group=self.process_group)
+
     def wait(self):
         """Block the current stream until the gradient exchange is done (call before the optimizer step)."""
-        for w in self._works:
+        for w, fin in self._works:
             w.wait()
+            if fin is not None:
+                with torch.no_grad():
+                    fin()
         self._works = []
 
     @contextlib.contextmanager
@@ -505,32 +632,56 @@ class FlatAdamW:
             else:
                 runs.append([o, hi, st])
         self.steps = max(self.param_steps)
+        owned = getattr(f, "_owned_ranges", None)      # OnirisDDP(exchange="mesh"): this rank updates its chunks only
+        if owned is not None:
+            cut = []
+            for lo, hi, st in runs:
+                for a, b in owned:
+                    x, y = max(lo, a), min(hi, b)
+                    if x < y:
+                        cut.append([x, y, st])
+            runs = cut
+        norm_reduce = getattr(f, "_norm_reduce", None)
         if f.flat.is_cuda:
             from . import ops
             if max_norm is not None:
                 if self._norm_buf is None:
                     self._norm_buf = torch.zeros(1 + ops.SQNORM_WS, dtype=torch.float32, device=f.flat.device)
-                ops.sqnorm_(f.grad, self._norm_buf)    # over the whole buffer (parameters without gradient hold zeros)
+                if owned is None:
+                    ops.sqnorm_(f.grad, self._norm_buf)    # over the whole buffer (parameters without gradient hold zeros)
+                else:                                      # sum of squares of the owned (reduced) chunks, then over the ranks
+                    tot = torch.zeros(1, dtype=torch.float32, device=f.flat.device)
+                    for a, b in owned:
+                        ops.sqnorm_(f.grad[a:b], self._norm_buf)
+                        tot += self._norm_buf[:1]
+                    self._norm_buf[:1].copy_(norm_reduce(tot))
             for lo, hi, st in runs:
                 if st == 0 and not ema:
                     continue
                 ops.adamw_(f.flat[lo:hi], f.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
                            self.betas[1], self.eps, self.weight_decay, st, grad_scale, max_norm, self._norm_buf,
                            [(e[lo:hi], w) for e, w in ema], norm_ready=True)
-            return
-        b1, b2 = self.betas
-        coef = 1.0
-        if max_norm is not None:
-            coef = min(1.0, max_norm / (float((f.grad * grad_scale).norm()) + 1e-6))
-        for lo, hi, st in runs:
-            if st:
-                g = f.grad[lo:hi] * (grad_scale * coef)
-                self.m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
-                self.v[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
-                mh, vh = self.m[lo:hi] / (1 - b1 ** st), self.v[lo:hi] / (1 - b2 ** st)
-                f.flat[lo:hi].mul_(1 - self.lr * self.weight_decay).sub_(self.lr * mh / (vh.sqrt() + self.eps))
-            for e, w in ema:
-                e[lo:hi].lerp_(f.flat[lo:hi], w)
+        else:
+            b1, b2 = self.betas
+            coef = 1.0
+            if max_norm is not None:
+                if owned is None:
+                    sq = (f.grad * grad_scale).pow(2).sum().reshape(1)
+                else:
+                    sq = norm_reduce(sum((f.grad[a:b] * grad_scale).pow(2).sum() for a, b in owned).reshape(1))
+                coef = min(1.0, max_norm / (float(sq.sqrt()) + 1e-6))
+            for lo, hi, st in runs:
+                if st:
+                    g = f.grad[lo:hi] * (grad_scale * coef)
+                    self.m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
+                    self.v[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
+                    mh, vh = self.m[lo:hi] / (1 - b1 ** st), self.v[lo:hi] / (1 - b2 ** st)
+                    f.flat[lo:hi].mul_(1 - self.lr * self.weight_decay).sub_(self.lr * mh / (vh.sqrt() + self.eps))
+                for e, w in ema:
+                    e[lo:hi].lerp_(f.flat[lo:hi], w)
+        after = getattr(f, "_after_step", None)
+        if after is not None:
+            after()
 
     def zero_grad(self):
         self.flat.zero_grad()

@@ -258,9 +258,8 @@ def main():
             torch.nn.init.constant_(m.emb_gain, 0.3)
     torch.nn.init.constant_(unet.out_gain, 1.0)
     flat = FlatParams(unet, lazy_small=True)
-    model = OnirisDDP(unet, flat=flat) if (world > 1 or force_dist) else unet
-    if force_dist:
-        model.force_collectives = True
+    # exchange form / transport: ONIRIS_DDP_EXCHANGE=allreduce|mesh, ONIRIS_DDP_BF16=1 (parallel.OnirisDDP; default: fp32 all-reduce per stage)
+    model = OnirisDDP(unet, flat=flat, force_collectives=force_dist) if (world > 1 or force_dist) else unet
     net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
     opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
     # optimizer side as in the reference loops: clip_grad_norm_(0.1) (gym_train.py:105 only) + AdamW +
@@ -441,6 +440,8 @@ def main():
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "rccl_world": rccl_world, "devices": sorted(set(devices)),
                "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
+               "ddp": ({"exchange": model.exchange, "grad_dtype": str(model.grad_dtype or "fp32"), "stages": len(flat.stages)}
+                       if (world > 1 or force_dist) else None),
                "config": {"workload": (f"Counter-Strike latents {T}-frame seq, EDM2 UNet 310.0M (cs_train.py:35-45), " if cs else
                                        f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), ") +
                                       f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "

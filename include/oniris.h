@@ -60,8 +60,10 @@ typedef struct OnirisWeightDesc {
   float* grad;     /* fp32 gradient, same shape; oniris_weight_bwd ACCUMULATES into it                           */
   void* wf;        /* bf16 packed forward weight  [taps][CoutP][CinP]   (ci contiguous)                          */
   void* wb;        /* bf16 packed dgrad weight    [taps][CoutPb][CinPb] = flipped/transposed copy (may be NULL)  */
-  float* dwp;      /* fp32 split-K slabs [nsplit_cap][taps][CoutP][CinP]: oniris_conv_wgrad workgroup column s   *
-                    * overwrites slab s with plain stores; oniris_weight_bwd sums the first *nsplit slabs        */
+  void* dwp;       /* bf16 split-K slabs [nsplit_cap][taps][CoutP][CinP]: oniris_conv_wgrad workgroup column s   *
+                    * overwrites slab s with plain stores (its fp32 partial sum rounded once); oniris_weight_bwd  *
+                    * adds the first *nsplit slabs in fp32                                                         */
+  float* dws;      /* fp32 [taps][CoutP][CinP]: the sum of the slabs (scratch of oniris_weight_bwd)               */
   int32_t cout, cin, taps, kt;     /* taps = kt*kh*kw (1, 9 or 18); kt = temporal taps (1 or 2)                  */
   int32_t CoutP, CinP;             /* CoutP = roundup(cout,32), CinP = roundup(cin,64)                           */
   int32_t CoutPb, CinPb;           /* CoutPb = roundup(cin,32), CinPb = roundup(cout,64)                         */
@@ -225,7 +227,7 @@ int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t str
 typedef struct OnirisWgradArgs {
   const void* x;          /* bf16 input frames   [B*xb_stride][H][W][Cin]                                         */
   const void* dy;         /* bf16 output grads   [B*T][H][W][Cout]                                                */
-  float* dwp;             /* fp32 slabs [nsplit_cap][taps_total][CoutP][CinP]                                      */
+  void* dwp;              /* bf16 slabs [nsplit_cap][taps_total][CoutP][CinP]                                      */
   const float* scale;     /* [B*T] or NULL                                                                        */
   int32_t B, T, H, W, Cin, CinP, Cout, CoutP, taps;
   int32_t xb_stride, x_T, coff;   /* xframe(b,t) = x[b*xb_stride + t + coff] if 0 <= t+coff < x_T else fill       */
@@ -372,13 +374,10 @@ int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* 
 int oniris_attn_bwd_dq(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
 int oniris_attn_bwd_dkv(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
 
-/* ---------------------------------------------------------------------------------------------------------------
- * RCCL helpers (cs_train.py:53-54,108-114,168): thin wrappers so a non-torch host can drive the same
- * gradient all-reduce; the Python host uses torch.distributed ("nccl" == RCCL) over the same library.           */
-int oniris_comm_unique_id(void* id128 /* [host] 128 bytes */);
-int oniris_comm_init(void** comm, int rank, int world, const void* id128 /* [host] */);
-int oniris_comm_allreduce_sum_f32(void* comm, float* buf, size_t count, oniris_stream_t stream);
-int oniris_comm_destroy(void* comm);
+/* The gradient exchange of the data-parallel loop (cs_train.py:53-54,108-114,168) is issued by the host through
+ * torch.distributed ("nccl" == RCCL on ROCm) on the flat gradient buffer: autoregressive_diffusion_amd/parallel.py.
+ * This library exports no collective wrappers (the four pass-through oniris_comm_* entry points of ABI <= 7 carried no
+ * logic and are gone in ABI 8).                                                                                    */
 
 #ifdef __cplusplus
 }

@@ -62,7 +62,7 @@ def _worker(rank, world, port, q, staged=False):
         out, _ = ddp(data[2 * rank]); out.pow(2).mean().backward()
     out, _ = ddp(data[2 * rank + 1]); out.pow(2).mean().backward()
     if staged:                                  # the stage hook ran in both backwards, exchanged only in the synced one
-        assert StagedNet.stage_calls == 2 and not ddp._tail_sent and len(ddp._works) > 2
+        assert StagedNet.stage_calls == 2 and not any(ddp._sent) and len(ddp._works) > 2
     ddp.wait()
     grad = ddp.flat.grad.clone()
     opt.step()
@@ -353,3 +353,84 @@ def test_ranks_that_skip_different_parameters_are_detected():
     skipped a parameter another rank updated would silently diverge; OnirisDDP compares the bitmaps and raises."""
     for rank, outcome in _run2(_active_mismatch_worker):
         assert outcome == ["ok", "raised"], (rank, outcome)
+
+
+class MultiStageNet(nn.Module):
+    """Three layers; the module offers TWO early stages (c's parameters are final when the gradient of h2 exists, b's when
+    that of h1 does) through the hook dictionary OnirisDDP installs (UNet._oniris_overlap_stages / _oniris_stage_hooks)."""
+    fired = []
+
+    def __init__(self):
+        super().__init__()
+        self.a, self.b, self.c = nn.Linear(6, 16), nn.Linear(16, 16), nn.Linear(16, 3)
+        self.unused = nn.Linear(4, 4)
+
+    def _oniris_overlap_stages(self):
+        return [("h2", list(self.c.parameters())), ("h1", list(self.b.parameters()))]
+
+    def forward(self, x):
+        hooks = self.__dict__.get("_oniris_stage_hooks") or {}
+        h1 = torch.tanh(self.a(x))
+        h2 = torch.tanh(self.b(h1))
+        for key, h in (("h1", h1), ("h2", h2)):
+            cb = hooks.get(key)
+            if cb is not None and h.requires_grad:
+                h.register_hook(lambda g, key=key, cb=cb: (MultiStageNet.fired.append(key), cb(g))[1])
+        return self.c(h2), None
+
+
+def _modes_worker(rank, world, port, q, exchange, bf16, clip):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autoregressive_diffusion_amd.parallel import OnirisDDP, FlatAdamW, FlatParams, FlatEMA
+    torch.manual_seed(200 + rank)
+    net = MultiStageNet()
+    flat = FlatParams(net)          # (autograd-owned gradients must sit in the flat buffer when a stage fires: not lazy)
+    ddp = OnirisDDP(net, flat=flat, bucket_mb=1e-4, exchange=exchange, grad_dtype=torch.bfloat16 if bf16 else None)
+    assert [k for k, _, _ in flat.stages] == ["h2", "h1"] and flat.head[1] == flat.stages[0][1]
+    assert all(lo % FlatParams.SEG_ALIGN == 0 and hi % FlatParams.SEG_ALIGN == 0 for _, lo, hi in flat.stages)
+    opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.01)
+    ema = FlatEMA(flat, stds=(0.05,))
+    g = torch.Generator().manual_seed(9)
+    data = torch.randn(3, 2, 5, 6, generator=g)          # [step][rank][batch][features]
+    for step in range(3):
+        opt.zero_grad()
+        MultiStageNet.fired.clear()
+        out, _ = ddp(data[step, rank]); out.pow(2).mean().backward()
+        assert MultiStageNet.fired == ["h2", "h1"] and not any(ddp._sent)
+        ddp.wait()
+        opt.step(max_norm=clip, ema=ema.weights(8 * (step + 1), 8))
+    q.put((rank, {k: v.detach().numpy().copy() for k, v in net.state_dict().items()},
+           flat.flat.numpy().copy(), [tuple(r) for r in getattr(flat, "_owned_ranges", [])]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,bf16,clip", [("allreduce", False, None), ("allreduce", True, None), ("mesh", False, None),
+                                                ("mesh", True, None), ("mesh", False, 0.05), ("allreduce", False, 0.05)])
+def test_ddp_stages_and_exchange_modes(exchange, bf16, clip):
+    """Multi-stage overlap with every exchange form: ring/tree all-reduce per stage, bf16 transport, and the mesh form
+    (all-to-all reduce-scatter, optimizer on the owned chunks, parameter all-gather) -- ranks stay bit-equal, and equal a
+    single process that averages the two ranks' gradients (torch.optim.AdamW + clip_grad_norm_)."""
+    res = _run2(_modes_worker, exchange, bf16, clip)
+    (_, sd0, p0, own0), (_, sd1, p1, own1) = res
+    assert (p0 == p1).all(), "ranks diverged"
+    if exchange == "mesh":
+        assert own0 and own1 and own0 != own1 and all(a[1] == b[0] for a, b in zip(own0, own1))    # rank 0's chunk, then rank 1's
+    torch.manual_seed(200)
+    ref = MultiStageNet()
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.01)
+    g = torch.Generator().manual_seed(9)
+    data = torch.randn(3, 2, 5, 6, generator=g)
+    for step in range(3):
+        topt.zero_grad()
+        for r in range(2):
+            out, _ = ref(data[step, r]); (out.pow(2).mean() / 2).backward()
+        for p in ref.unused.parameters():              # (a permanent zero .grad view counts as "has a gradient")
+            p.grad = torch.zeros_like(p)
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(list(ref.parameters()), clip)
+        topt.step()
+    tol = 2e-3 if bf16 else 2e-6
+    for k, v in ref.state_dict().items():
+        assert torch.allclose(torch.from_numpy(sd0[k]), v, atol=tol), (k, (torch.from_numpy(sd0[k]) - v).abs().max())

@@ -521,25 +521,33 @@ def _ddp_worker(q):
         labels = torch.randint(0, 4, (1, 4), generator=g).to(dev)
         sigma = (torch.randn(1, 8, generator=g) + 0.4).exp().to(dev)
         eps = torch.randn(1, 8, 8, 64, 64, generator=g).to(dev)
-        grads = {}
-        for mode in ("plain", "ddp"):
+        grads, params, info = {}, {}, {}
+        from autoregressive_diffusion_amd.parallel import FlatAdamW
+        for mode in ("plain", "ddp", "ddp-bf16", "mesh", "mesh-bf16"):
             net = M.build_precond(M.C1_CFG, 43, 1.0).train()
             flat = FlatParams(net.unet, lazy_small=True)
-            staged = flat.stage_at is not None and 0 < flat.tail_start < flat.numel
-            if mode == "ddp":
-                ddp = OnirisDDP(net.unet, flat=flat)
-                ddp.force_collectives = True
+            staged = len(flat.stages)
+            if mode != "plain":
+                ddp = OnirisDDP(net.unet, flat=flat, exchange="mesh" if mode.startswith("mesh") else "allreduce",
+                                grad_dtype=torch.bfloat16 if mode.endswith("bf16") else None, force_collectives=True)
+                assert (getattr(flat, "_owned_ranges", None) is not None) == (ddp.exchange == "mesh")
                 net.unet = ddp
+            opt = FlatAdamW(flat, lr=1e-3)
             loss, _ = EDM2Loss(sigma_data=1.0)(net, images, labels, sigma=sigma, noise=eps, sync=False)
             loss.backward()
-            if mode == "ddp":
-                sent_early = len(ddp._works)
+            if mode != "plain":
+                info[mode] = (len(ddp._works), list(ddp._sent))
                 ddp.wait()
             flat.gather()
             torch.cuda.synchronize()
             grads[mode] = flat.grad.clone()
-        d = (grads["plain"] - grads["ddp"]).abs().max().item()
-        q.put(("ok", staged, sent_early, d, grads["plain"].abs().max().item()))
+            opt.step(max_norm=0.1)
+            torch.cuda.synchronize()
+            params[mode] = flat.flat.clone()
+        gmax, pmax = grads["plain"].abs().max().item(), params["plain"].abs().max().item()
+        dg = {m: (grads["plain"] - grads[m]).abs().max().item() for m in grads if m != "plain"}
+        dp = {m: (params["plain"] - params[m]).abs().max().item() for m in params if m != "plain"}
+        q.put(("ok", staged, info, dg, dp, gmax, pmax))
         dist.destroy_process_group()
     except Exception as e:      # noqa: BLE001
         import traceback
@@ -547,9 +555,10 @@ def _ddp_worker(q):
 
 
 def test_ddp_staged_exchange_single_rank():
-    """OnirisDDP on the real UNet (one RCCL rank): the tensor hook fires mid-backward, weight_bwd runs twice (pending
-    slabs only), the tail of the flat gradient buffer is exchanged early and the head at the end -- and the resulting
-    gradients equal those of the plain backward."""
+    """OnirisDDP on the real UNet (one RCCL rank): the stage hooks fire mid-backward, weight_bwd runs once per stage (pending
+    slabs only), every stage's segment of the flat gradient buffer is exchanged early and the head at the end -- and the
+    resulting gradients and the parameters after one clipped AdamW step equal those of the plain backward, for the all-reduce
+    and the mesh (all-to-all + owned-chunk optimizer + all-gather) forms, with fp32 and bf16 transport."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -558,10 +567,16 @@ def test_ddp_staged_exchange_single_rank():
     res = q.get(timeout=300)
     p.join(timeout=60)
     assert res[0] == "ok", res[1]
-    _, staged, sent, d, gmax = res
-    print("ddp single rank: staged", staged, "all-reduces", sent, "max |grad diff|", d, "of", gmax)
-    assert staged and sent >= 2
-    assert d <= 1e-3 * gmax
+    _, staged, info, dg, dp, gmax, pmax = res
+    print("ddp single rank: stages", staged, "collectives issued during backward / stage flags at its end", info,
+          "max |grad diff|", dg, "of", gmax, "max |param diff after AdamW|", dp, "of", pmax)
+    assert staged >= 2
+    for mode, (nworks, sent) in info.items():
+        assert nworks >= staged + 1 and not any(sent), (mode, nworks, sent)      # every stage + the head went out
+    for mode in dg:
+        tol = 1e-2 if mode.endswith("bf16") else 1e-3                        # bf16 transport: one rounding of the average
+        assert dg[mode] <= tol * gmax, (mode, dg[mode], gmax)
+        assert dp[mode] <= (3e-3 if mode.endswith("bf16") else 1e-5) * pmax + 2.1e-3 * mode.endswith("bf16"), (mode, dp[mode], pmax)
 
 
 def test_hipgraph_step_matches_eager():

@@ -66,12 +66,13 @@ def test_weight_prep_and_bwd(shape):
     refb = w_eff.detach().reshape(cout, cin, pw.kt, per).flip(-1).reshape(cout, cin, taps).permute(2, 1, 0)
     assert rel(wb, refb) < 5e-3, "packed dgrad weight (flipped, transposed)"
     # backward: random packed gradient
-    G = torch.randn(cout, cin, taps)
-    dwp = torch.zeros(taps, pw.CoutP, pw.CinP)          # two split-K slabs: 0.25*G + 0.75*G
+    G = bfr(torch.randn(cout, cin, taps))               # (the split-K slabs are bf16: power-of-two multiples are exact)
+    dwp = torch.zeros(taps, pw.CoutP, pw.CinP)          # two split-K slabs: 0.5*G + 1.5*G = 2*G
     dwp[:, :cout, :cin] = G.permute(2, 0, 1)
-    assert pw.nsplit_cap >= 2
-    pw.dwp[:dwp.numel()].copy_(0.25 * dwp.reshape(-1))
-    pw.dwp[dwp.numel():2 * dwp.numel()].copy_(0.75 * dwp.reshape(-1))
+    assert pw.nsplit_cap >= 2 and pw.dwp.dtype == torch.bfloat16
+    pw.dwp[:dwp.numel()].copy_(0.5 * dwp.reshape(-1))
+    pw.dwp[dwp.numel():2 * dwp.numel()].copy_(bfr(1.5 * dwp.reshape(-1)))
+    G = (0.5 * G + bfr(1.5 * G))
     pw.nsplit.fill_(2)
     p.grad.zero_()
     bank.backward()
