@@ -63,11 +63,14 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x
   *(bf16x8*)(a + pix * C + cg * 8) = av;
 }
 
-// g = dxo + da * silu'(xo)/0.596 ; NORM: g <- (g - xo * sum(g*xo) * k) / s ; dx = w1*g[:C1], dskip = w2*g[C1:]
+// g = dxo + da * silu'(xo)/0.596 ; NORM: g <- (g - xo * sum(g*xo) * k) / s ; dx = w1*g[:C1] (+ dadd), dskip = w2*g[C1:]
+// dadd: a second gradient of x that is already complete (the decoder's gradient of an encoder output that is also a skip
+// connection): added here instead of by a separate pass over the three tensors
 template <bool NORM>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ da, const bf16* __restrict__ dxo,
                                                       const bf16* __restrict__ xo, const float* __restrict__ sden,
-                                                      bf16* __restrict__ dx, bf16* __restrict__ dskip, long long npix,
+                                                      bf16* __restrict__ dx, bf16* __restrict__ dskip,
+                                                      const bf16* __restrict__ dadd, long long npix,
                                                       int C1, int C2, float w1, float w2) {
   const int C = C1 + C2, G = C >> 3;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -105,8 +108,14 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ d
   const int c = cg * 8;
   bf16x8 o;
   if (c < C1) {
+    if (dadd) {
+      const bf16x8 d3 = *(const bf16x8*)(dadd + pix * C1 + c);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w1);
+      for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w1 + bf2f(d3[i]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w1);
+    }
     *(bf16x8*)(dx + pix * C1 + c) = o;
   } else {
 #pragma unroll
@@ -131,7 +140,8 @@ extern "C" int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a
 }
 
 extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
-                              int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream_) {
+                              const void* dadd, int64_t npix, int C1, int C2, float w1, float w2, int norm,
+                              oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int C = C1 + C2;
   ONIRIS_CHECK_ARG(da && xo && dx && npix > 0 && C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || dskip),
@@ -139,8 +149,8 @@ extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, c
   ONIRIS_CHECK_ARG(!norm || ((C / 8) <= 64 && ((C / 8) & (C / 8 - 1)) == 0 && sden), "act_bwd: pixel norm needs C/8 = 2^k <= 64");
   const long long nthr = npix * (C / 8);
   const dim3 grid((unsigned)((nthr + 255) / 256));
-  if (norm) hipLaunchKernelGGL(act_bwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (long long)npix, C1, C2, w1, w2);
-  else hipLaunchKernelGGL(act_bwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (long long)npix, C1, C2, w1, w2);
+  if (norm) hipLaunchKernelGGL(act_bwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2);
+  else hipLaunchKernelGGL(act_bwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -253,8 +263,8 @@ extern "C" int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void
 // ---------------------------------------------------------------------------------------------------------------
 // resample: mode 0: out[n][y][x] = mean of the 2x2 input block (H,W = INPUT size);  mode 1: nearest x2 (H,W = INPUT size)
 // `scale` multiplies the result (adjoints: down^T = 0.25 * up, up^T = 4 * down -> pass scale accordingly)
-__global__ void resample_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, long long nout8, int H, int W, int C,
-                                int mode, float scale) {
+__global__ void resample_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, const bf16* __restrict__ add,
+                                long long nout8, int H, int W, int C, int mode, float scale) {
   const int G = C >> 3;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nout8; i += (long long)gridDim.x * blockDim.x) {
     const int cg = (int)(i % G);
@@ -284,6 +294,11 @@ __global__ void resample_kernel(const bf16* __restrict__ in, bf16* __restrict__ 
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = bf2f(a[k]) * scale;
     }
+    if (add) {                                        // (see act_bwd_kernel: a second, complete gradient of the same tensor)
+      const bf16x8 d3 = *(const bf16x8*)(add + i * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += bf2f(d3[k]);
+    }
     bf16x8 o;
 #pragma unroll
     for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k]);
@@ -291,7 +306,7 @@ __global__ void resample_kernel(const bf16* __restrict__ in, bf16* __restrict__ 
   }
 }
 
-extern "C" int oniris_resample(const void* in, void* out, int64_t N, int H, int W, int C, int mode, float scale,
+extern "C" int oniris_resample(const void* in, void* out, const void* add, int64_t N, int H, int W, int C, int mode, float scale,
                                oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(in && out && N > 0 && H > 0 && W > 0 && C % 8 == 0 && (mode == 1 || (H % 2 == 0 && W % 2 == 0)),
@@ -300,8 +315,8 @@ extern "C" int oniris_resample(const void* in, void* out, int64_t N, int H, int 
   const long long n8 = npix_out * (C / 8);
   long long nb = (n8 + 255) / 256;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out, n8, H, W, C,
-                     mode, scale);
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out, (const bf16*)add, n8,
+                     H, W, C, mode, scale);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -663,18 +678,21 @@ __global__ void emb_scale_kernel(const bf16* __restrict__ c_all, const float* __
   }
 }
 
-// adjoint: dc_all = dc * gain[seg] (bf16), dgain[k] = sum over n and the columns [start[k], start[k+1]) of dc * c_all;
-// one block per Block k (no atomics: deterministic)
+// adjoint: dc_all = dc * gain[seg] (bf16), dgain_part[k][chunk] = sum over the chunk's rows n and the columns
+// [start[k], start[k+1]) of dc * c_all; grid (Block k, row chunk): the caller adds the EMB_BWD_CHUNKS partial sums per k
+// (no atomics: deterministic).  One block per k walked 65 K elements serially (99 us for 3.8 MB at the gym size).
+#define EMB_BWD_CHUNKS ONIRIS_EMB_BWD_CHUNKS
 __global__ __launch_bounds__(256) void emb_scale_bwd_kernel(const float* __restrict__ dc, const bf16* __restrict__ c_all,
                                                             const float* __restrict__ gain, const int* __restrict__ start,
-                                                            bf16* __restrict__ dc_all, float* __restrict__ dgain, int N, int Ctot) {
+                                                            bf16* __restrict__ dc_all, float* __restrict__ dgain_part, int N, int Ctot) {
   __shared__ float red[4];
-  const int k = blockIdx.x;
+  const int k = blockIdx.x, ch = blockIdx.y;
   const int j0 = start[k], w = start[k + 1] - j0;
+  const int n0 = (int)((long long)N * ch / EMB_BWD_CHUNKS), n1 = (int)((long long)N * (ch + 1) / EMB_BWD_CHUNKS);
   const float g = gain[k];
   float acc = 0.f;
-  for (int i = threadIdx.x; i < N * w; i += 256) {
-    const int n = i / w, j = j0 + (i - n * w);
+  for (int i = threadIdx.x; i < (n1 - n0) * w; i += 256) {
+    const int n = n0 + i / w, j = j0 + i % w;
     const size_t at = (size_t)n * Ctot + j;
     const float d = dc[at];
     acc += d * bf2f(c_all[at]);
@@ -684,7 +702,7 @@ __global__ __launch_bounds__(256) void emb_scale_bwd_kernel(const float* __restr
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) dgain[k] = (red[0] + red[1]) + (red[2] + red[3]);
+  if (threadIdx.x == 0) dgain_part[k * EMB_BWD_CHUNKS + ch] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 extern "C" int oniris_emb_scale(const void* c_all, const float* gain, const int32_t* seg, float* c, int N, int Ctot,
@@ -699,11 +717,11 @@ extern "C" int oniris_emb_scale(const void* c_all, const float* gain, const int3
 }
 
 extern "C" int oniris_emb_scale_bwd(const float* dc, const void* c_all, const float* gain, const int32_t* start, void* dc_all,
-                                    float* dgain, int N, int Ctot, int K, oniris_stream_t stream_) {
+                                    float* dgain_part, int N, int Ctot, int K, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ONIRIS_CHECK_ARG(dc && c_all && gain && start && dc_all && dgain && N > 0 && Ctot > 0 && K > 0, "emb_scale_bwd: bad arguments");
-  hipLaunchKernelGGL(emb_scale_bwd_kernel, dim3(K), dim3(256), 0, stream, dc, (const bf16*)c_all, gain, (const int*)start,
-                     (bf16*)dc_all, dgain, N, Ctot);
+  ONIRIS_CHECK_ARG(dc && c_all && gain && start && dc_all && dgain_part && N > 0 && Ctot > 0 && K > 0, "emb_scale_bwd: bad arguments");
+  hipLaunchKernelGGL(emb_scale_bwd_kernel, dim3(K, EMB_BWD_CHUNKS), dim3(256), 0, stream, dc, (const bf16*)c_all, gain,
+                     (const int*)start, (bf16*)dc_all, dgain_part, N, Ctot);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -37,22 +37,25 @@ class Block(nn.Module):
             self.attn = FrameAttention(out_channels, self.num_heads, attn_balance)
 
     def _cl(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False, skip=None, cat_w=None,
-            c=None):
+            c=None, in_slot=None, skip_slot=None):
         """x (N,H,W,C) bf16, emb (N,1,1,cemb) bf16; skip/cat_w: the decoder's mp_cat operand, fused into the first
         activation kernel.  Elementwise chains of the reference's Block.forward (:62-94) run as fused HIP kernels:
         [mp_cat | pixel norm] + mp_silu -> act;  *c + mp_silu -> conv_res0 epilogue;  mp_sum (+clip) -> conv_res1 /
         attn_proj epilogue."""
         if cache is None:
             cache = {}
-        x = ops.resample(x, self.resample_mode)
+        # in_slot / skip_slot (ops.GradSlot): x / skip is an encoder output with a second consumer; the block's first op
+        # adds the other consumer's gradient inside its own backward kernel, the mp_cat parks the skip gradient for it
+        if self.resample_mode != "keep":
+            x, in_slot = ops.resample(x, self.resample_mode, in_slot), None
         if self.flavor == "enc":
             if self.conv_skip is not None:
-                x = self.conv_skip._cl(x)
-            x, a = ops.act(x, norm=True)                                   # x <- pixel norm(x); a = mp_silu(x)
+                x, in_slot = self.conv_skip._cl(x, in_slot=in_slot), None
+            x, a = ops.act(x, norm=True, in_slot=in_slot)                  # x <- pixel norm(x); a = mp_silu(x)
         elif skip is not None:
-            x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True)      # x <- mp_cat(x, skip); a = mp_silu(x)
+            x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True, in_slot=in_slot, skip_slot=skip_slot)   # x <- mp_cat(x, skip); a = mp_silu(x)
         else:
-            a = ops.act(x)
+            a = ops.act(x, in_slot=in_slot)
         N = x.shape[0]
         if c is None:          # (the UNet hands in all of its blocks' scales from one grouped GEMM: ops.emb_scales)
             c = (self.emb_linear._cl(emb).reshape(N, -1).float() * self.emb_gain + 1)      # (N, Cout) fp32
@@ -206,26 +209,32 @@ class UNet(BetterModule):
                 gains = eb[1][:] = [b.emb_gain for b in blocks]
             cs = dict(zip(map(id, blocks), ops.emb_scales(emb, self.__dict__["_oniris_groups"][0], gains)))
             skips = []
+            # one GradSlot per encoder output (training): it is read by the next block AND by a decoder block (skip)
+            use_slots = torch.is_grad_enabled() and self.training
+            slot = None
             stage_hooks = self.__dict__.get("_oniris_stage_hooks") or {}    # OnirisDDP: {("enc" | "dec", name): tensor hook}
             for name, block in self.enc.items():
                 if isinstance(block, Block):
                     xcl, cache["enc", name] = block._cl(xcl, emb, B, c_noise, cache.get(("enc", name)), update_cache, just_2d,
-                                                        c=cs[id(block)])
+                                                        c=cs[id(block)], in_slot=slot)
                 else:
                     xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
-                skips.append(xcl)
+                slot = ops.GradSlot() if use_slots else None
+                skips.append((xcl, slot))
                 cb = stage_hooks.get(("enc", name))
                 if cb is not None and xcl.requires_grad:              # everything downstream of here is final when
                     xcl.register_hook(cb)                             # this gradient arrives (an OnirisDDP stage)
             for name, block in self.dec.items():
-                skip, cat_w = None, None
+                skip, cat_w, skip_slot = None, None, None
                 if "block" in name:                                   # mp_cat(x, skip, t) fused into the block's act kernel
-                    skip = skips.pop()
+                    skip, skip_slot = skips.pop()
                     Na, Nb, t = xcl.shape[-1], skip.shape[-1], self.concat_balance
                     Cn = math.sqrt((Na + Nb) / ((1 - t) ** 2 + t ** 2))
                     cat_w = (Cn / math.sqrt(Na) * (1 - t), Cn / math.sqrt(Nb) * t)
+                # (the last encoder output enters the decoder as its main input: `slot` is still that tensor's slot)
                 xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d,
-                                                    skip=skip, cat_w=cat_w, c=cs[id(block)])
+                                                    skip=skip, cat_w=cat_w, c=cs[id(block)], in_slot=slot, skip_slot=skip_slot)
+                slot = None
                 cb = stage_hooks.get(("dec", name))
                 if cb is not None and xcl.requires_grad:
                     xcl.register_hook(cb)

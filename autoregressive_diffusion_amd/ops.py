@@ -586,11 +586,12 @@ def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb
 
 class ConvCfg:
     """Static configuration of one conv op (not a tensor: passed through autograd untouched)."""
-    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad")
+    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad", "in_slot")
 
-    def __init__(self, pw2, pw3=None, B=1, T=1, epi="none", ta=0.0, tb=0.0, clip=0.0, need_grad=True):
+    def __init__(self, pw2, pw3=None, B=1, T=1, epi="none", ta=0.0, tb=0.0, clip=0.0, need_grad=True, in_slot=None):
         self.pw2, self.pw3, self.B, self.T = pw2, pw3, B, T
         self.epi, self.ta, self.tb, self.clip, self.need_grad = epi, ta, tb, clip, need_grad
+        self.in_slot = in_slot             # GradSlot of the input (plain convs): a second gradient of x joins in the dgrad epilogue
 
 
 def _rows_f32(t):
@@ -717,8 +718,13 @@ class _ConvOp(torch.autograd.Function):
         else:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
-                _conv_launch(dout, None, pw2.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
-                             pw2.taps)
+                dadd = cfg.in_slot.take() if cfg.in_slot is not None else None       # (see GradSlot)
+                if dadd is not None:             # dx = dadd + dgrad: the mp_sum epilogue with ta = tb = 1, no clip
+                    _conv_launch(dout, None, pw2.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
+                                 pw2.taps, epi=_lib.EPI_MPSUM, res=dadd.contiguous(), ta=1.0, tb=1.0, clip=0.0)
+                else:
+                    _conv_launch(dout, None, pw2.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
+                                 pw2.taps)
             if pw2.param.requires_grad:
                 _wgrad_launch(x, dout, pw2, None, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
         if pw2.param.requires_grad or (gated and pw3.param.requires_grad):
@@ -744,11 +750,11 @@ def gate_coefs(gate):
     return (1 - gate) * den, gate * den
 
 
-def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None):
+def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None):
     """MPConv forward on packed weights.  Optional fused epilogues: res -> clip(ta*res + tb*conv(x));
-    cscale (N,Cout) fp32 -> silu(conv(x)*cscale)/0.596."""
+    cscale (N,Cout) fp32 -> silu(conv(x)*cscale)/0.596.  in_slot: GradSlot of x."""
     epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
-    cfg = ConvCfg(pw, None, epi=epi, ta=ta, tb=tb, clip=clip, need_grad=torch.is_grad_enabled())
+    cfg = ConvCfg(pw, None, epi=epi, ta=ta, tb=tb, clip=clip, need_grad=torch.is_grad_enabled(), in_slot=in_slot)
     return _ConvOp.apply(x, pw.param, None, None, None, cscale, res, cfg)
 
 
@@ -786,11 +792,33 @@ def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, t
 # ------------------------------------------------------------------------------------------------------------------
 # fused magnitude-preserving glue (HBM-bound single-pass kernels, csrc/elementwise.hip)
 
+class GradSlot:
+    """Side channel for the gradient of an encoder output that is ALSO a skip connection (networks_edm2.py:227-230): such a
+    tensor has two consumers, and autograd would add their two gradients with one more pass over three activation-sized
+    tensors (12 per step, the largest 67 MB each).  Instead the decoder-side consumer (the mp_cat inside _ActFn, which runs
+    first in backward: the whole decoder precedes the encoder) parks its gradient here and reports None to autograd; the
+    encoder-side consumer -- the first op of the next block: pixel-norm / resample / 1x1 skip conv -- takes it and adds
+    it inside its own backward kernel (`dadd` of oniris_act_bwd / `add` of oniris_resample / the mp_sum epilogue of the
+    1x1 dgrad).  One slot per skip tensor and per forward pass."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+    def put(self, g):
+        self.g = g if self.g is None else self.g + g
+
+    def take(self):
+        g, self.g = self.g, None
+        return g
+
+
 class _ActFn(torch.autograd.Function):
-    """(xo, a) = act(x[, skip]):  v = cat(w1*x, w2*skip); norm: v /= eps + |v|/sqrt(C); xo = v; a = silu(v)/0.596."""
+    """(xo, a) = act(x[, skip]):  v = cat(w1*x, w2*skip); norm: v /= eps + |v|/sqrt(C); xo = v; a = silu(v)/0.596.
+    in_slot / skip_slot: GradSlots of x / of skip (see GradSlot)."""
 
     @staticmethod
-    def forward(ctx, x, skip, w1, w2, norm, want_xo):
+    def forward(ctx, x, skip, w1, w2, norm, want_xo, in_slot=None, skip_slot=None):
         _need_gpu(x)
         C1 = x.shape[-1]
         C2 = skip.shape[-1] if skip is not None else 0
@@ -804,6 +832,7 @@ class _ActFn(torch.autograd.Function):
         check(lib.oniris_act_fwd(_p(x), _p(skip), _p(xo), _p(a), _p(sden), npix, C1, C2, w1, w2, int(norm), _stream()),
               "act_fwd")
         ctx.meta = (C1, C2, w1, w2, norm, npix, x.shape, skip.shape if skip is not None else None)
+        ctx.slots = (in_slot, skip_slot)
         # without norm/cat xo would just be x itself: reuse the input for the silu' evaluation
         ctx.save_for_backward(xo if xo is not None else x, sden)
         if want_xo or norm:
@@ -824,44 +853,57 @@ class _ActFn(torch.autograd.Function):
         dxo = dxo.contiguous() if dxo is not None else None
         dx = torch.empty(xshape, dtype=BF16, device=xo.device)
         dskip = torch.empty(sshape, dtype=BF16, device=xo.device) if C2 else None
-        check(lib.oniris_act_bwd(_p(da), _p(dxo), _p(xo), _p(sden), _p(dx), _p(dskip), npix, C1, C2, w1, w2, int(norm),
-                                 _stream()), "act_bwd")
-        return dx, dskip, None, None, None, None
+        in_slot, skip_slot = ctx.slots
+        dadd = in_slot.take() if in_slot is not None else None
+        if dadd is not None:
+            dadd = dadd.contiguous()
+            assert dadd.shape == dx.shape
+        check(lib.oniris_act_bwd(_p(da), _p(dxo), _p(xo), _p(sden), _p(dx), _p(dskip), _p(dadd), npix, C1, C2, w1, w2,
+                                 int(norm), _stream()), "act_bwd")
+        if skip_slot is not None and dskip is not None:
+            skip_slot.put(dskip)                      # joins the encoder-side gradient inside that consumer's kernel
+            dskip = None
+        return dx, dskip, None, None, None, None, None, None
 
 
-def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False):
-    return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo))
+def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, skip_slot=None):
+    return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo), in_slot, skip_slot)
 
 
 class _ResampleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mode):
+    def forward(ctx, x, mode, in_slot=None):
         _need_gpu(x)
         N, H, W, C = x.shape
         x = x.contiguous()
         out = torch.empty((N, H // 2, W // 2, C) if mode == 0 else (N, H * 2, W * 2, C), dtype=BF16, device=x.device)
-        check(lib.oniris_resample(_p(x), _p(out), N, H, W, C, mode, 1.0, _stream()), "resample")
-        ctx.mode = mode
+        check(lib.oniris_resample(_p(x), _p(out), None, N, H, W, C, mode, 1.0, _stream()), "resample")
+        ctx.mode, ctx.slot = mode, in_slot
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
         N, H, W, C = g.shape
+        dadd = ctx.slot.take() if ctx.slot is not None else None        # (see GradSlot)
+        if dadd is not None:
+            dadd = dadd.contiguous()
         if ctx.mode == 0:      # adjoint of the 2x2 mean: nearest x2 scaled by 1/4
             dx = torch.empty((N, H * 2, W * 2, C), dtype=BF16, device=g.device)
-            check(lib.oniris_resample(_p(g), _p(dx), N, H, W, C, 1, 0.25, _stream()), "resample")
+            assert dadd is None or dadd.shape == dx.shape
+            check(lib.oniris_resample(_p(g), _p(dx), _p(dadd), N, H, W, C, 1, 0.25, _stream()), "resample")
         else:                  # adjoint of nearest x2: 2x2 sum = 4 * mean
             dx = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=g.device)
-            check(lib.oniris_resample(_p(g), _p(dx), N, H, W, C, 0, 4.0, _stream()), "resample")
-        return dx, None
+            assert dadd is None or dadd.shape == dx.shape
+            check(lib.oniris_resample(_p(g), _p(dx), _p(dadd), N, H, W, C, 0, 4.0, _stream()), "resample")
+        return dx, None, None
 
 
-def resample(x, mode):
+def resample(x, mode, in_slot=None):
     """mode 'keep' | 'down' (2x2 mean) | 'up' (nearest x2)   (utils.py:94-107 with f=[1,1])."""
     if mode == "keep":
         return x
-    return _ResampleFn.apply(x, 0 if mode == "down" else 1)
+    return _ResampleFn.apply(x, 0 if mode == "down" else 1, in_slot)
 
 
 class _SplitCols(torch.autograd.Function):
@@ -920,6 +962,9 @@ def direct_pack(params, holder, name):
 _pack_cache = {}
 
 
+EMB_BWD_CHUNKS = 16       # ONIRIS_EMB_BWD_CHUNKS in include/oniris.h
+
+
 class _EmbScaleFn(torch.autograd.Function):
     """c = 1 + c_all * gain[seg]  (oniris_emb_scale / oniris_emb_scale_bwd).  sink (parallel.ParamPack or None): where the
     gain gradient goes when `gain` has no autograd history."""
@@ -939,9 +984,10 @@ class _EmbScaleFn(torch.autograd.Function):
         N, Ctot = c_all.shape
         dc = dc.contiguous()
         dc_all = torch.empty_like(c_all)
-        dgain = torch.empty_like(gain)
-        check(lib.oniris_emb_scale_bwd(_p(dc), _p(c_all), _p(gain), _p(start), _p(dc_all), _p(dgain), N, Ctot, gain.numel(),
+        part = torch.empty((gain.numel(), EMB_BWD_CHUNKS), dtype=torch.float32, device=gain.device)
+        check(lib.oniris_emb_scale_bwd(_p(dc), _p(c_all), _p(gain), _p(start), _p(dc_all), _p(part), N, Ctot, gain.numel(),
                                        _stream()), "emb_scale_bwd")
+        dgain = part.sum(1).reshape(gain.shape)
         if ctx.sink is not None:
             ctx.sink.deliver(dgain)
             dgain = None

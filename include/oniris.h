@@ -133,7 +133,8 @@ int oniris_gates(const float* c_noise, const float* params, const int32_t* nctx,
  * oniris_gates_bwd: adjoint of oniris_gates, dparams [L][6] from dca, dcb [L][N] (Gating, edm2/conv.py:113-127);
  * oniris_emb_scale: c [N][Ctot] fp32 = 1 + c_all * gain[seg[j]] for every Block at once (networks_edm2.py:78; c_all
  *   [N][Ctot] bf16 = the row-concatenated emb_linear GEMM, seg [Ctot] = Block of column j, gain [K] = the emb_gain's);
- *   oniris_emb_scale_bwd: dc_all bf16 and dgain [K] from dc (start [K+1] = first column of each Block);
+ *   oniris_emb_scale_bwd: dc_all bf16 and dgain_part [K][ONIRIS_EMB_BWD_CHUNKS] from dc (start [K+1] = first column of
+ *   each Block; d gain[k] = the sum of row k of dgain_part, added by the caller: deterministic, no atomics);
  * oniris_embed_pre: the inputs of the embedding linears, four [N][cnoiseP] bf16 = MPFourier(c_noise) (utils.py:139-150),
  *   onehot [N][labelP] bf16 = one_hot(labels) * sqrt(L) (networks_edm2.py:209; NULL = no labels), zero-padded columns;
  * oniris_embed_post: emb = mp_silu(mp_sum(e1, e2, t)) (networks_edm2.py:210-212; e2 NULL: mp_silu(e1)), bf16 [n];
@@ -142,8 +143,9 @@ int oniris_gates_bwd(const float* c_noise, const float* params, const int32_t* n
                      float* dparams, int L, int N, int T, oniris_stream_t stream);
 int oniris_emb_scale(const void* c_all, const float* gain, const int32_t* seg, float* c, int N, int Ctot,
                      oniris_stream_t stream);
+#define ONIRIS_EMB_BWD_CHUNKS 16
 int oniris_emb_scale_bwd(const float* dc, const void* c_all, const float* gain, const int32_t* start, void* dc_all,
-                         float* dgain, int N, int Ctot, int K, oniris_stream_t stream);
+                         float* dgain_part, int N, int Ctot, int K, oniris_stream_t stream);
 int oniris_embed_pre(const float* c_noise, const int64_t* labels, const float* freqs, const float* phases, void* four,
                      void* onehot, int N, int cnoise, int cnoiseP, int label_dim, int labelP, oniris_stream_t stream);
 int oniris_embed_post(const void* e1, const void* e2, void* emb, size_t n, float t, oniris_stream_t stream);
@@ -270,20 +272,22 @@ int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void*
  * (edm2/networks_edm2.py:62-94) and their adjoints.  All tensors bf16 channels-last.
  * oniris_act_fwd: v = concat(w1*x[C1], w2*skip[C2]) (mp_cat, utils.py:128-134; C2 = 0: none); norm != 0: pixel norm
  *   v /= eps + |v|/sqrt(C) (utils.py:83-88), sden[pixel] receives the denominator; xo (optional) = v;
- *   a = silu(v)/0.596 (utils.py:112).   oniris_act_bwd: given da (and optionally dxo) -> dx [C1], dskip [C2].
+ *   a = silu(v)/0.596 (utils.py:112).   oniris_act_bwd: given da (and optionally dxo) -> dx [C1], dskip [C2]; dadd
+ *   (optional, [C1]) is added to dx: a second, already complete gradient of x (an encoder output that is also a skip
+ *   connection, networks_edm2.py:227-230) joins here instead of in a separate pass over three tensors.
  * oniris_emb_silu_bwd: backward of u = silu(y*c[n][co])/0.596: dy, and dc[n][co] = sum_pixels (fp32, overwritten).
  * oniris_mpsum_bwd: backward of out = clip(ta*res + tb*v): dres, dv (clip <= 0: no mask, `out` may be NULL).
- * oniris_resample: mode 0 = 2x2 mean (H,W = input size), mode 1 = nearest x2; result * scale
- *   (utils.py:94-107 with f = [1,1]; adjoints: down^T = up * 0.25, up^T = down * 4).                             */
+ * oniris_resample: mode 0 = 2x2 mean (H,W = input size), mode 1 = nearest x2; result * scale (+ add, optional, shaped
+ *   like out: see dadd above)  (utils.py:94-107 with f = [1,1]; adjoints: down^T = up * 0.25, up^T = down * 4).   */
 int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sden, int64_t npix, int C1, int C2,
                    float w1, float w2, int norm, oniris_stream_t stream);
 int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
-                   int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream);
+                   const void* dadd, int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream);
 int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P, int C,
                         int c_pitch /* floats between rows of c; 0 = C */, oniris_stream_t stream);
 int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv, int64_t numel, float ta, float tb, float clip,
                      oniris_stream_t stream);
-int oniris_resample(const void* in, void* out, int64_t N, int H, int W, int C, int mode, float scale,
+int oniris_resample(const void* in, void* out, const void* add, int64_t N, int H, int W, int C, int mode, float scale,
                     oniris_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
