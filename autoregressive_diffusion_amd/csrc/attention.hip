@@ -714,6 +714,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
 #endif
 }
 
+#include "attention_bwd_ws.h"
+
 // dk|dv = sum over the chunks (in chunk order) of the fp32 partials; 8 elements per thread
 __global__ void attn_dkv_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ dk, bf16* __restrict__ dv,
                                        size_t n8, int nch) {      // (dk partials were summed against q' = c q: * 1/c here)
@@ -1093,6 +1095,19 @@ extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t s
   if (rc) return rc;
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.dout && d.a.lse && d.a.delta && d.a.dk && d.a.dv,
                    "attn_bwd_dkv: null pointer");
+  if (d.a.sched) {                                  // persistent, statically balanced, wave-specialised kernel (attention_bwd_ws.h):
+    // items = 64-key blocks with their whole query list (schedule built over Lk / 64 items per pair); no partial sums
+    ONIRIS_CHECK_ARG(d.a.sched_wgs > 0 && d.a.sched_slots > 0, "attn_bwd_dkv: empty schedule");
+    ONIRIS_CHECK_ARG(d.a.mask_mode != 0, "attn_bwd_dkv: the scheduled kernel serves the table-driven masks");
+    ONIRIS_CHECK_ARG(d.a.q_num && d.a.q_idx && d.a.qtab_cols <= 64,
+                     "attn_bwd_dkv: the scheduled kernel needs the transposed table with <= 64 blocks per row");
+    ONIRIS_CHECK_ARG(d.a.Lq % 128 == 0 && d.a.Lq == d.a.Lk && d.a.Lk / 64 < 65536,
+                     "attn_bwd_dkv: the scheduled kernel needs Lq == Lk, a multiple of 128 (got %d, %d)", d.a.Lq, d.a.Lk);
+    if (d.a.mask_mode == 1) oniris_launch(attn_bwd_dkv_ws_kernel<1>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    else oniris_launch(attn_bwd_dkv_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
   const int nch = d.a.dkv_chunks > 1 ? d.a.dkv_chunks : 1;
   ONIRIS_CHECK_ARG(nch == 1 || d.a.dkv_part, "attn_bwd_dkv: dkv_chunks > 1 needs the dkv_part scratch");
   ONIRIS_CHECK_ARG(nch <= 64, "attn_bwd_dkv: at most 64 chunks");

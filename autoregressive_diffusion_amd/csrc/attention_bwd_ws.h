@@ -1,0 +1,273 @@
+// VideoAttention backward, dK / dV for gfx950: persistent, statically balanced, wave-specialised
+// (included by attention.hip; the scheduled path of oniris_attn_bwd_dkv).
+//
+// The grid kernel (attn_bwd_dkv_kernel) gives a workgroup 128 keys and -- because under the causal DART table the first key
+// blocks are attended by every later query block and the last by one -- splits every key block's query list over
+// `dkv_chunks` workgroups that write fp32 partial sums (134 MB per layer at the gym shape) for a second kernel to add.
+// Here a work ITEM is 64 keys of one (batch, head) pair with its WHOLE query list: the heaviest item (64 clean keys of
+// frame 0: 63 query blocks of 128 rows at T = 64, P = 64) is below the per-CU average of the launch (66 block units),
+// so a longest-first assignment of whole items to one workgroup per CU (oniris_attn_schedule, the forward's scheduler)
+// balances the launch and dK / dV leave the kernel finished, in bf16: no partial sums, no reduction kernel.
+//
+// Launch: one 512-thread workgroup per CU.  Waves 4..7 = LOADERS: they only issue LDS-DMA -- 128-row blocks of Q | dO
+// (16 KB each) + the rows' lse | delta (1 KB) through a four-slot ring, three blocks ahead of the consumers, and the first
+// three blocks of the next item while the compute waves finish the current one.  Waves 0..3 = COMPUTE, wave (kh, qh) =
+// keys [32 kh, 32 kh + 32) of the item (lane = key; K and V fragments stay in registers for the whole item) x query half
+// qh of every 128-row block (two 32-row sub-blocks).  Per sub-block: S = Q.K^T and dP = dO.V^T (8 MFMAs, query on the
+// rows, key on the lanes), P = exp2(S - lse), dS = P (dP - delta) / 8 in registers, then dV^T += dO^T.P and
+// dK^T += Q^T.dS (8 MFMAs) with the transposed operands read from the SAME LDS tiles (ds_read_b64_tr_b16).  The two
+// query halves of a key half add their dK / dV through LDS at the end of the item.
+// q arrives with log2(e)/8 folded in (qkv_norm_rope_kernel): dK is rescaled by 8/log2(e) in the epilogue.
+#pragma once
+
+template <int MODE>
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int TQ = 128 * 128;                    // one tile: 128 rows x 128 B (64 channels of a head)
+  constexpr int SLOT = 2 * TQ + 1024;              // Q | dO | lse[128] | delta[128]
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * SLOT];
+  const OnirisAttnArgs& a = d.a;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C = a.C, Lq = a.Lq, Lk = a.Lk;
+  const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
+  const int nslots = a.sched_slots;
+  const int32_t* sched = a.sched + (size_t)blockIdx.x * nslots;
+  auto item_at = [&](int i) __attribute__((always_inline)) { return i < nslots ? __builtin_amdgcn_readfirstlane(sched[i]) : -1; };
+  const int tmask = (1 << d.tshift) - 1;
+
+  if (wave >= 4) {
+    // ------------------------------------------------------------------------------------------------ loader waves
+    const int lw = wave - 4;
+    const int drow = 8 * lw + (lane >> 3), dpp = lane & 7;        // piece (lw + 4 i): row 32 i + drow, 16-byte part dpp
+    const int tsw_ = (dpp ^ (4 * ((drow >> 1) & 1))) * 16;        // transposing-read swizzle (row fragments take a 4-way conflict)
+    constexpr int OOB = (int)0x80000000;
+    struct Src { i32x4 rs_q, rs_do, rs_l, rs_d; int qvo, nblk, qvl; };
+    auto open_item = [&](int itm) __attribute__((always_inline)) {
+      Src s;
+      const int pair = itm >> 16, kb64 = itm & 0xffff;
+      const int b = pair / a.heads, head = pair - b * a.heads;
+      const int trow = (kb64 >> 1) >> d.tshift;
+      const int nent = __builtin_amdgcn_readfirstlane(a.q_num[trow]);
+      s.nblk = nent << d.tshift;
+      s.qvl = (lane < nent) ? a.q_idx[(size_t)trow * a.qtab_cols + lane] : 0;
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(s.qvl)::"memory");     // (hipcc does not count the asm DMAs: wait by hand)
+      s.rs_q = make_rsrc((const bf16*)a.q + (size_t)b * Lq * C, Lq * C * 2);
+      s.rs_do = make_rsrc((const bf16*)a.dout + (size_t)b * Lq * C, Lq * C * 2);
+      s.rs_l = make_rsrc(a.lse + (size_t)(b * a.heads + head) * Lq, Lq * 4);
+      s.rs_d = make_rsrc(a.delta + (size_t)(b * a.heads + head) * Lq, Lq * 4);
+      s.qvo = (drow * C + head * 64) * 2 + tsw_;
+      return s;
+    };
+    auto issue_block = [&](const Src& s, int j) __attribute__((always_inline)) {       // block j of the list -> slot j % 4
+      const int q0 = (((__builtin_amdgcn_readlane(s.qvl, j >> d.tshift)) << d.tshift) + (j & tmask)) * 128;
+      const unsigned dst = lds0 + (j & 3) * SLOT + lw * 1024;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const bool ok = drow + 32 * i < Lq - q0;
+        const int so = (q0 + 32 * i) * C * 2;
+        dma16(s.rs_q, ok ? s.qvo : OOB, so, dst + i * 4096);
+        dma16(s.rs_do, ok ? s.qvo : OOB, so, dst + i * 4096 + TQ);
+      }
+      if (lw == 0) {                               // lanes 0..31: lse[q0 .. q0+127] (16 B each), lanes 32..63: delta
+        const int l32 = lane & 31;
+        const int vo = (l32 * 4 < Lq - q0) ? l32 * 16 : OOB;
+        const unsigned sdst = lds0 + (j & 3) * SLOT + 2 * TQ;
+        if (lane < 32) dma16(s.rs_l, vo, q0 * 4, sdst);
+        else dma16(s.rs_d, vo, q0 * 4, sdst);
+      }
+    };
+    int item = item_at(0);
+    if (item < 0) return;
+    Src cur = open_item(item);
+#pragma unroll 1
+    for (int j = 0; j < 3 && j < cur.nblk; ++j) issue_block(cur, j);
+#pragma unroll 1
+    for (int it = 0;; ++it) {
+      const int nblk = cur.nblk, nb = nblk > 0 ? nblk : 1;
+      // requests so far, in order: blocks 0 .. min(nblk, 3) - 1.  barrier_j needs blocks <= j + 1 landed; a block is 8 DMA
+      // instructions of a loader wave, 10 of wave 4 (lse / delta)
+#pragma unroll 1
+      for (int j = 0; j < nb; ++j) {
+        if (j + 2 < nblk) {
+          if (lw == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");             // block j + 2 may still be in flight
+          else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                           // barrier_j: block j + 1 landed; block j - 1 released
+        if (j + 3 < nblk) issue_block(cur, j + 3);
+      }
+      const int next = item_at(it + 1);
+      Src nxt = cur;
+      if (next >= 0) nxt = open_item(next);        // (nothing of this item is in flight any more)
+      __syncthreads();                             // E1: the compute waves are done with the ring
+      if (next >= 0) {
+#pragma unroll 1
+        for (int j = 0; j < 3 && j < nxt.nblk; ++j) issue_block(nxt, j);      // slots 0..2; the merge uses slot 3
+      }
+      __syncthreads();                             // E2
+      if (next < 0) break;
+      cur = nxt;
+    }
+    return;
+  }
+
+  // -------------------------------------------------------------------------------------------------- compute waves
+  const int kh = wave & 1, qh = wave >> 1;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+  int item = item_at(0);
+#pragma unroll 1
+  for (int it = 0; item >= 0; ++it) {
+    const int pair = item >> 16, kb64 = item & 0xffff;
+    const int b = pair / a.heads, head = pair - b * a.heads;
+    // per-item copy of the lane id: keeps hipcc from hoisting (and spilling) lane-constant addresses out of the item loop
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int r = le & 31, h = le >> 5;
+    const int kw0 = kb64 * 64 + kh * 32;
+    const int krow = kw0 + r;
+    const int rr0 = r * 128 + ((h ^ (4 * ((r >> 1) & 1))) << 4);
+    const int grp = le >> 4, hh = grp >> 1, q4 = (le & 15) >> 2, pcol = (le & 3) * 4 + 16 * (grp & 1);
+    const int tb0 = (4 * hh + q4) * 128 + pcol * 2, tsw = (q4 >> 1) & 1;
+    auto ttr = [&](const unsigned char* t_, int tokbase, int dt) __attribute__((always_inline)) {
+      const unsigned char* p0 = t_ + tb0 + tokbase * 128 + ((dt ^ tsw) * 64);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 128));
+      s16x8 v;
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+      v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+      return __builtin_bit_cast(bf16x8, v);
+    };
+
+    const bf16* kg = (const bf16*)a.k + (size_t)b * Lk * C + head * 64;
+    const bf16* vg = (const bf16*)a.v + (size_t)b * Lk * C + head * 64;
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 v = u32x4{0u, 0u, 0u, 0u}, w = u32x4{0u, 0u, 0u, 0u};
+      if (krow < Lk) {
+        v = *(const u32x4*)(kg + (size_t)krow * C + ks * 16 + h * 8);
+        w = *(const u32x4*)(vg + (size_t)krow * C + ks * 16 + h * 8);
+      }
+      kf[ks] = __builtin_bit_cast(bf16x8, v);
+      vf[ks] = __builtin_bit_cast(bf16x8, w);
+    }
+    f32x16 dk[2], dv[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
+
+    const int trow = (kb64 >> 1) >> d.tshift;
+    const int nent = __builtin_amdgcn_readfirstlane(a.q_num[trow]);
+    const int nblk = nent << d.tshift, nb = nblk > 0 ? nblk : 1;
+    const int qvl = (lane < nent) ? a.q_idx[(size_t)trow * a.qtab_cols + lane] : 0;
+
+    __syncthreads();                               // barrier_0: blocks 0 and 1 landed
+#pragma unroll 1
+    for (int j = 0; j < nb; ++j) {
+      if (j > 0) __syncthreads();                  // barrier_j: block j + 1 landed, block j - 1 released
+      if (j >= nblk || kw0 >= Lk) continue;
+      const unsigned char* Qt = smem + (j & 3) * SLOT;
+      const unsigned char* dOt = Qt + TQ;
+      const float* lse_lds = (const float*)(Qt + 2 * TQ);
+      const float* del_lds = lse_lds + 128;
+      const int q0 = (((__builtin_amdgcn_readlane(qvl, j >> d.tshift)) << d.tshift) + (j & tmask)) * 128;
+#pragma unroll
+      for (int qs = 0; qs < 2; ++qs) {
+        const int trw = qh * 64 + qs * 32;         // first row of this 32-row sub-block inside the tile
+        const int qq0 = q0 + trw;
+        int cls = classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off);
+        if ((qq0 + 31 >= Lq || kw0 + 31 >= Lk) && cls == 2) cls = 1;
+        if (cls == 0 || qq0 >= Lq) continue;
+        bf16x8 qa[4], da[4], dotf[2][2], qtf[2][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          qa[ks] = *(const bf16x8*)(Qt + ((rr0 ^ (ks * 32)) + trw * 128));
+          da[ks] = *(const bf16x8*)(dOt + ((rr0 ^ (ks * 32)) + trw * 128));
+        }
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dotf[s2][dt] = ttr(dOt, trw + 16 * s2, dt);
+            qtf[s2][dt] = ttr(Qt, trw + 16 * s2, dt);
+          }
+        f32x16 s, dp;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          s = mfma32(qa[ks], kf[ks], s);                   // S[q][key]
+          dp = mfma32(da[ks], vf[ks], dp);                 // dP[q][key]
+        }
+        f32x16 pv;
+        auto dsoft = [&](auto masked_) __attribute__((always_inline)) {
+          constexpr bool MASKED = decltype(masked_)::value;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const int qb4 = trw + 8 * g4 + 4 * h;          // 4 consecutive query rows per accumulator group
+            const float4 ls = *(const float4*)(lse_lds + qb4), de = *(const float4*)(del_lds + qb4);
+            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const int rr = 4 * g4 + k;
+              float p = __builtin_amdgcn_exp2f(s[rr] - lsv[k]);                // (q carries log2(e)/8: qkv_norm_kernel)
+              if constexpr (MASKED) {
+                const int qtok = q0 + qb4 + k;
+                if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
+              }
+              pv[rr] = p;
+              s[rr] = p * (dp[rr] - dev[k]) * 0.125f;          // dS (scaled)
+            }
+          }
+        };
+        if (cls == 2) dsoft(std::false_type{});
+        else dsoft(std::true_type{});
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const bf16x8 pb = pack8(pv, s2);
+          const bf16x8 db = pack8(s, s2);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) {
+            dv[dt] = mfma32(dotf[s2][dt], pb, dv[dt]);     // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+            dk[dt] = mfma32(qtf[s2][dt], db, dk[dt]);      // dK^T[d][key]  += Q^T[d][q] dS[q][key]
+          }
+        }
+      }
+    }
+
+    // ---- epilogue: the two query halves of a key half meet in ring slot 3 (2 x 16 KB), wave (kh, 0) writes dK, dV
+    float* red = (float*)(smem + 3 * SLOT) + kh * 4096 + le;       // [kh][64 registers][64 lanes]
+    __syncthreads();                               // E1: every compute wave is done with the ring
+    if (qh == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        red[i * 64] = dk[0][i]; red[(16 + i) * 64] = dk[1][i];
+        red[(32 + i) * 64] = dv[0][i]; red[(48 + i) * 64] = dv[1][i];
+      }
+    }
+    __syncthreads();                               // E2
+    if (qh == 0 && krow < Lk) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        dk[0][i] += red[i * 64]; dk[1][i] += red[(16 + i) * 64];
+        dv[0][i] += red[(32 + i) * 64]; dv[1][i] += red[(48 + i) * 64];
+      }
+      bf16* dkg = (bf16*)a.dk + ((size_t)b * Lk + krow) * C + head * 64;
+      bf16* dvg = (bf16*)a.dv + ((size_t)b * Lk + krow) * C + head * 64;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 o1, o2;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { o1[k] = f2bf(dk[dt][4 * g + k] * (1.f / SCALE_LOG2)); o2[k] = f2bf(dv[dt][4 * g + k]); }   // dK^T was summed against q' = c q
+          *(bf16x4*)(dkg + dt * 32 + 8 * g + 4 * h) = o1;
+          *(bf16x4*)(dvg + dt * 32 + 8 * g + 4 * h) = o2;
+        }
+    }
+    item = item_at(it + 1);
+  }
+#endif
+}

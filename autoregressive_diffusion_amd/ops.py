@@ -376,6 +376,7 @@ WGRAD_SIDE_STREAM = int(_os.environ.get("ONIRIS_WGRAD_STREAM", "0"))   # opt-in:
 FUSED_ROPE = int(_os.environ.get("ONIRIS_FUSED_ROPE", "1"))        # 0: qkv normalisation and the two rotations as three launches (A/B, tests)
 ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
 ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
+ATTN_DKV_PERSISTENT = int(_os.environ.get("ONIRIS_DKV_PERSISTENT", "1"))   # 0: grid dK/dV kernel + chunk reduction (A/B, tests)
 WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
 BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (see OnirisConvArgs.big_tile)
 
@@ -1186,10 +1187,10 @@ def _train_sched(T, P, n_pairs, dev, which):
     if which == "fwd":
         per = blk // 128
         w = np.repeat(num * per + 1, per)                    # a table row of `blk` tokens = per 128-row query blocks
-    else:
+    else:                                                    # items of 64 keys: 2 per 128-token block, whole query list each
         qn, _ = mask_transpose(num, idx)
         per = blk // 128
-        w = np.repeat(qn * per + 1, per)
+        w = np.repeat(qn * per + 1, 2 * per)
     return attn_schedule(w, n_pairs, dev)
 
 
@@ -1266,13 +1267,22 @@ class _AttentionFn(torch.autograd.Function):
         ks = 2 if (mask_mode != 0 and L >= 2048) else 1
         _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
                   lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
-        # causal tables: split every key block's query list so that no workgroup walks more than ~32 sub-tiles
-        nch = max(1, min(ATTN_DKV_CHUNKS, L // ATTN_DKV_MIN_L)) if mask_mode == 2 else 1
-        if nch > 1:
-            part = torch.empty((2, nch, Bq, L, C), dtype=torch.float32, device=dev)
-            a.dkv_part, a.dkv_chunks = _p(part), nch
-        _profiled(f"attn_bwd_dkv_kernel<MODE={mask_mode}>", 2.0 * fl,
-                  lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))     # (+ the partial-sum reduce)
+        if (mask_mode == 2 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and ctx.tabs[3].shape[1] <= 64 and L % 128 == 0
+                and Bq * heads < 32768):
+            # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
+            # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch)
+            sched = _train_sched(T, P, Bq * heads, dev, "dkv")
+            a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+            _profiled(f"attn_bwd_dkv_ws_kernel<MODE={mask_mode}>", 2.0 * fl,
+                      lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))
+        else:
+            # causal tables: split every key block's query list so that no workgroup walks more than ~32 sub-tiles
+            nch = max(1, min(ATTN_DKV_CHUNKS, L // ATTN_DKV_MIN_L)) if mask_mode == 2 else 1
+            if nch > 1:
+                part = torch.empty((2, nch, Bq, L, C), dtype=torch.float32, device=dev)
+                a.dkv_part, a.dkv_chunks = _p(part), nch
+            _profiled(f"attn_bwd_dkv_kernel<MODE={mask_mode}>", 2.0 * fl,
+                      lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))     # (+ the partial-sum reduce)
         dqkv = torch.empty_like(qkv)
         N = qkv.shape[0]
         if kind == "video" and FUSED_ROPE:
