@@ -128,7 +128,8 @@ _SIGS = {
     "oniris_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                             c_int, c_int, c_int, c_int64, c_void_p]),
     "oniris_attn_fwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
-    "oniris_attn_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "oniris_attn_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                                     c_void_p]),
     "oniris_attn_bwd_dq": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "oniris_attn_bwd_dkv": (c_int, [C.POINTER(AttnArgs), c_void_p]),
 }

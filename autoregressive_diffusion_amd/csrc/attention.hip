@@ -966,7 +966,8 @@ __global__ __launch_bounds__(256) void rope_kernel(const bf16* __restrict__ x, b
 
 // delta[b][h][tok] = sum_c dO * O
 __global__ void attn_delta_kernel(const bf16* __restrict__ dout, const bf16* __restrict__ out, float* __restrict__ delta,
-                                  long long nvec, int L, int C, int heads) {
+                                  const float* __restrict__ lse, float* __restrict__ neg, long long nvec, int L, int C,
+                                  int heads) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long vec = gid >> 3;
   const int part = (int)(gid & 7);
@@ -1195,13 +1196,14 @@ extern "C" int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t
   return ONIRIS_OK;
 }
 
-extern "C" int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* doutt, int B, int heads,
-                                    int L, int C, oniris_stream_t stream_) {
+extern "C" int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* doutt, const float* lse, float* neg,
+                                    int B, int heads, int L, int C, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(dout && out && delta && B > 0 && heads > 0 && L > 0 && C == heads * 64, "attn_bwd_prep: bad arguments");
+  ONIRIS_CHECK_ARG(!neg || lse, "attn_bwd_prep: the negated row constants need lse");
   const long long nvec = (long long)B * L * heads;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
-                     (const bf16*)dout, (const bf16*)out, delta, nvec, L, C, heads);
+                     (const bf16*)dout, (const bf16*)out, delta, lse, neg, nvec, L, C, heads);
   ONIRIS_LAUNCH_CHECK();
   if (doutt) return oniris_rope(dout, nullptr, doutt, nullptr, nullptr, nullptr, 0, B, L, 1, C, 0, 1, 0, stream_);
   return ONIRIS_OK;

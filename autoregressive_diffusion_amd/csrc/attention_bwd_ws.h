@@ -13,11 +13,13 @@
 // (16 KB each) + the rows' lse | delta (1 KB) through a four-slot ring, three blocks ahead of the consumers, and the first
 // three blocks of the next item while the compute waves finish the current one.  Waves 0..3 = COMPUTE, wave (kh, qh) =
 // keys [32 kh, 32 kh + 32) of the item (lane = key; K and V fragments stay in registers for the whole item) x query half
-// qh of every 128-row block (two 32-row sub-blocks).  Per sub-block: S = Q.K^T and dP = dO.V^T (8 MFMAs, query on the
-// rows, key on the lanes), P = exp2(S - lse), dS = P (dP - delta) / 8 in registers, then dV^T += dO^T.P and
-// dK^T += Q^T.dS (8 MFMAs) with the transposed operands read from the SAME LDS tiles (ds_read_b64_tr_b16).  The two
-// query halves of a key half add their dK / dV through LDS at the end of the item.
-// q arrives with log2(e)/8 folded in (qkv_norm_rope_kernel): dK is rescaled by 8/log2(e) in the epilogue.
+// qh of every 128-row block (two 32-row sub-blocks).  Per sub-block: S' = Q.K^T - lse and dP' = dO.V^T - delta (8 MFMAs,
+// query on the rows, key on the lanes; -lse and -delta, written by oniris_attn_bwd_prep, are the chains' initial
+// accumulators), P = exp2(S'), dS = P dP' in registers (2 VALU instructions + 2 converts per element), then
+// dV^T += dO^T.P and dK^T += Q^T.dS (8 MFMAs) with the transposed operands read from the SAME LDS tiles
+// (ds_read_b64_tr_b16).  The two query halves of a key half add their dK / dV through LDS at the end of the item.
+// q arrives with log2(e)/8 folded in (qkv_norm_rope_kernel): dK is rescaled by 1/log2(e) in the epilogue.
+// OnirisAttnArgs.lse / .delta of THIS kernel point at the NEGATED rows (oniris_attn_bwd_prep's `neg` output).
 #pragma once
 
 template <int MODE>
@@ -162,80 +164,108 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     const int nent = __builtin_amdgcn_readfirstlane(a.q_num[trow]);
     const int nblk = nent << d.tshift, nb = nblk > 0 ? nblk : 1;
     const int qvl = (lane < nent) ? a.q_idx[(size_t)trow * a.qtab_cols + lane] : 0;
+    auto q_start = [&](int j) __attribute__((always_inline)) {
+      return (((__builtin_amdgcn_readlane(qvl, j >> d.tshift)) << d.tshift) + (j & tmask)) * 128;
+    };
 
+    // The stream of work is the list's 32-row sub-blocks u = (block j, qs): rows [64 qh + 32 qs, +32) of block j.
+    //   A(u): S' = Q.K^T - lse and dP' = dO.V^T - delta: the row constants (negated by oniris_attn_bwd_prep) are the INITIAL
+    //         accumulators of the two MFMA chains; a partially masked sub-block starts S' at -1e30 where the pair is masked
+    //         (P = exp2(S') = 0 there, and so is dS): the softmax code below is the same for every sub-block;
+    //   B(u): P = exp2(S'), dS = P dP' (the 1/8 of the score scale is applied once, to dK, in the epilogue), packed to bf16;
+    //   C(u): dV^T += dO^T.P, dK^T += Q^T.dS with the transposed fragments of the same tiles.
+    // Two-stage software pipeline: a slot issues A(u+1) | B(u) | C(u) -- the 8 MFMAs of A(u+1) depend on nothing the slot
+    // computes, so the exponentials / products / converts of B(u) ride in their gaps (pinned below).
+    auto stageA = [&](f32x16& s, f32x16& dp, const unsigned char* Qt, int trw, int q0) __attribute__((always_inline)) {
+      const unsigned char* dOt = Qt + TQ;
+      const float* nl = (const float*)(Qt + 2 * TQ) + trw + 4 * h;
+      const float* nd = nl + 128;
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const float4 ls = *(const float4*)(nl + 8 * g4), de = *(const float4*)(nd + 8 * g4);
+        s[4 * g4] = ls.x; s[4 * g4 + 1] = ls.y; s[4 * g4 + 2] = ls.z; s[4 * g4 + 3] = ls.w;
+        dp[4 * g4] = de.x; dp[4 * g4 + 1] = de.y; dp[4 * g4 + 2] = de.z; dp[4 * g4 + 3] = de.w;
+      }
+      const int qq0 = q0 + trw;
+      if (classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off) != 2) {      // (diagonal blocks only)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+          const int qtok = qq0 + 8 * (rr >> 2) + 4 * h + (rr & 3);
+          if (!tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) s[rr] = NEG_BIG;
+        }
+      }
+      bf16x8 qa[4], da[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        qa[ks] = *(const bf16x8*)(Qt + ((rr0 ^ (ks * 32)) + trw * 128));
+        da[ks] = *(const bf16x8*)(dOt + ((rr0 ^ (ks * 32)) + trw * 128));
+      }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        s = mfma32(qa[ks], kf[ks], s);                   // S'[q][key]
+        dp = mfma32(da[ks], vf[ks], dp);                 // dP'[q][key]
+      }
+    };
+    auto stageB = [&](const f32x16& s, const f32x16& dp, bf16x8 (&pb)[2], bf16x8 (&db)[2]) __attribute__((always_inline)) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float p = __builtin_amdgcn_exp2f(s[8 * s2 + e]);             // (q carries log2(e)/8: qkv_norm_rope_kernel)
+          pb[s2][e] = f2bf(p);
+          db[s2][e] = f2bf(p * dp[8 * s2 + e]);
+        }
+    };
+    auto stageC = [&](const unsigned char* Qt, int trw, bf16x8 (&pb)[2], bf16x8 (&db)[2]) __attribute__((always_inline)) {
+      const unsigned char* dOt = Qt + TQ;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        bf16x8 dotf[2], qtf[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) { dotf[dt] = ttr(dOt, trw + 16 * s2, dt); qtf[dt] = ttr(Qt, trw + 16 * s2, dt); }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          dv[dt] = mfma32(dotf[dt], pb[s2], dv[dt]);     // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+          dk[dt] = mfma32(qtf[dt], db[s2], dk[dt]);      // dK^T[d][key]  += Q^T[d][q] dS[q][key]
+        }
+      }
+    };
+    // issue order of a slot: one MFMA of A(u+1), then two exponentials, two products and two converts of B(u) (8 times);
+    // hipcc's own order bunches the transcendental ops, during which an in-order wave cannot feed the matrix pipe
+#define DKV_PIN                                                                          \
+  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                   \
+  }
+
+    const int trw0 = qh * 64, trw1 = qh * 64 + 32;
+    const bool work = kw0 < Lk && nblk > 0;
+    f32x16 sA, dpA, sB, dpB;
+    bf16x8 pb[2], db[2];
     __syncthreads();                               // barrier_0: blocks 0 and 1 landed
+    if (work) stageA(sA, dpA, smem, trw0, q_start(0));
 #pragma unroll 1
     for (int j = 0; j < nb; ++j) {
       if (j > 0) __syncthreads();                  // barrier_j: block j + 1 landed, block j - 1 released
-      if (j >= nblk || kw0 >= Lk) continue;
-      const unsigned char* Qt = smem + (j & 3) * SLOT;
-      const unsigned char* dOt = Qt + TQ;
-      const float* lse_lds = (const float*)(Qt + 2 * TQ);
-      const float* del_lds = lse_lds + 128;
-      const int q0 = (((__builtin_amdgcn_readlane(qvl, j >> d.tshift)) << d.tshift) + (j & tmask)) * 128;
-#pragma unroll
-      for (int qs = 0; qs < 2; ++qs) {
-        const int trw = qh * 64 + qs * 32;         // first row of this 32-row sub-block inside the tile
-        const int qq0 = q0 + trw;
-        int cls = classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off);
-        if ((qq0 + 31 >= Lq || kw0 + 31 >= Lk) && cls == 2) cls = 1;
-        if (cls == 0 || qq0 >= Lq) continue;
-        bf16x8 qa[4], da[4], dotf[2][2], qtf[2][2];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          qa[ks] = *(const bf16x8*)(Qt + ((rr0 ^ (ks * 32)) + trw * 128));
-          da[ks] = *(const bf16x8*)(dOt + ((rr0 ^ (ks * 32)) + trw * 128));
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            dotf[s2][dt] = ttr(dOt, trw + 16 * s2, dt);
-            qtf[s2][dt] = ttr(Qt, trw + 16 * s2, dt);
-          }
-        f32x16 s, dp;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { s[i] = 0.f; dp[i] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          s = mfma32(qa[ks], kf[ks], s);                   // S[q][key]
-          dp = mfma32(da[ks], vf[ks], dp);                 // dP[q][key]
-        }
-        f32x16 pv;
-        auto dsoft = [&](auto masked_) __attribute__((always_inline)) {
-          constexpr bool MASKED = decltype(masked_)::value;
-#pragma unroll
-          for (int g4 = 0; g4 < 4; ++g4) {
-            const int qb4 = trw + 8 * g4 + 4 * h;          // 4 consecutive query rows per accumulator group
-            const float4 ls = *(const float4*)(lse_lds + qb4), de = *(const float4*)(del_lds + qb4);
-            const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dev[4] = {de.x, de.y, de.z, de.w};
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-              const int rr = 4 * g4 + k;
-              float p = __builtin_amdgcn_exp2f(s[rr] - lsv[k]);                // (q carries log2(e)/8: qkv_norm_kernel)
-              if constexpr (MASKED) {
-                const int qtok = q0 + qb4 + k;
-                if (qtok >= Lq || krow >= Lk || !tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) p = 0.f;
-              }
-              pv[rr] = p;
-              s[rr] = p * (dp[rr] - dev[k]) * 0.125f;          // dS (scaled)
-            }
-          }
-        };
-        if (cls == 2) dsoft(std::false_type{});
-        else dsoft(std::true_type{});
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-          const bf16x8 pb = pack8(pv, s2);
-          const bf16x8 db = pack8(s, s2);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            dv[dt] = mfma32(dotf[s2][dt], pb, dv[dt]);     // dV^T[dv][key] += dO^T[dv][q] P[q][key]
-            dk[dt] = mfma32(qtf[s2][dt], db, dk[dt]);      // dK^T[d][key]  += Q^T[d][q] dS[q][key]
-          }
-        }
+      if (!work) continue;
+      const unsigned char* S0 = smem + (j & 3) * SLOT;
+      // slot (j, 0):  A(j, 1) | B(j, 0) | C(j, 0)
+      stageA(sB, dpB, S0, trw1, q_start(j));
+      stageB(sA, dpA, pb, db);
+      DKV_PIN
+      stageC(S0, trw0, pb, db);
+      // slot (j, 1):  A(j + 1, 0) | B(j, 1) | C(j, 1)
+      if (j + 1 < nblk) {
+        stageA(sA, dpA, smem + ((j + 1) & 3) * SLOT, trw0, q_start(j + 1));
+        stageB(sB, dpB, pb, db);
+        DKV_PIN
+      } else {
+        stageB(sB, dpB, pb, db);
       }
+      stageC(S0, trw1, pb, db);
     }
+#undef DKV_PIN
 
     // ---- epilogue: the two query halves of a key half meet in ring slot 3 (2 x 16 KB), wave (kh, 0) writes dK, dV
     float* red = (float*)(smem + 3 * SLOT) + kh * 4096 + le;       // [kh][64 registers][64 lanes]
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
         for (int g = 0; g < 4; ++g) {
           bf16x4 o1, o2;
 #pragma unroll
-          for (int k = 0; k < 4; ++k) { o1[k] = f2bf(dk[dt][4 * g + k] * (1.f / SCALE_LOG2)); o2[k] = f2bf(dv[dt][4 * g + k]); }   // dK^T was summed against q' = c q
+          for (int k = 0; k < 4; ++k) { o1[k] = f2bf(dk[dt][4 * g + k] * (0.125f / SCALE_LOG2)); o2[k] = f2bf(dv[dt][4 * g + k]); }   // dK^T was summed against q' = c q and the unscaled P dP'; 1/8 = the score scale
           *(bf16x4*)(dkg + dt * 32 + 8 * g + 4 * h) = o1;
           *(bf16x4*)(dvg + dt * 32 + 8 * g + 4 * h) = o2;
         }

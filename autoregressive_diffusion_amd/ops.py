@@ -1258,8 +1258,11 @@ class _AttentionFn(torch.autograd.Function):
         dev = qkv.device
         dout = dout.contiguous()
         delta = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
-        check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), None, Bq, heads, L, C, _stream()),
-              "attn_bwd_prep")
+        dkv_ws = (mask_mode == 2 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and ctx.tabs[3].shape[1] <= 64 and L % 128 == 0
+                  and Bq * heads < 32768)
+        neg = torch.empty((2, Bq, heads, L), dtype=torch.float32, device=dev) if dkv_ws else None     # -lse | -delta
+        check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), None, _p(lse) if dkv_ws else None, _p(neg), Bq, heads, L, C,
+                                       _stream()), "attn_bwd_prep")
         dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
         a = _attn_args(qr, kr, v, None, None, None, out, lse, ctx.tabs, Bq, heads, L, L, C, mask_mode, P, T)
         a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
@@ -1267,12 +1270,12 @@ class _AttentionFn(torch.autograd.Function):
         ks = 2 if (mask_mode != 0 and L >= 2048) else 1
         _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
                   lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
-        if (mask_mode == 2 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and ctx.tabs[3].shape[1] <= 64 and L % 128 == 0
-                and Bq * heads < 32768):
+        if dkv_ws:
             # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
-            # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch)
+            # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch); it reads the NEGATED row constants
             sched = _train_sched(T, P, Bq * heads, dev, "dkv")
             a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+            a.lse, a.delta = _p(neg[0]), _p(neg[1])
             _profiled(f"attn_bwd_dkv_ws_kernel<MODE={mask_mode}>", 2.0 * fl,
                       lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))
         else:

@@ -372,9 +372,11 @@ typedef struct OnirisAttnArgs {
 int oniris_attn_schedule(int n_pairs, int n_blocks, const int32_t* weight, int n_wg, int32_t* sched, int n_slots);
 
 int oniris_attn_fwd(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
-/* delta[b][h][q] = sum_c dout*out ; doutt = transposed dout                                                      */
-int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* doutt, int B, int heads, int L, int C,
-                         oniris_stream_t stream);
+/* delta[b][h][q] = sum_c dout*out ; doutt (optional) = transposed dout; neg (optional, needs lse) [2][B][heads][L] =
+ * -lse | -delta: the row constants the scheduled dK/dV kernel starts its S / dP accumulators from (its OnirisAttnArgs.lse
+ * / .delta point at these two planes)                                                                             */
+int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* doutt, const float* lse, float* neg, int B,
+                         int heads, int L, int C, oniris_stream_t stream);
 int oniris_attn_bwd_dq(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
 int oniris_attn_bwd_dkv(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
 
