@@ -982,7 +982,12 @@ __global__ void attn_delta_kernel(const bf16* __restrict__ dout, const bf16* __r
   s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
   if (part == 0) {
     const long long bb = tokg / L, tok = tokg % L;
-    delta[(bb * heads + hd) * L + tok] = s;
+    const long long at = (bb * heads + hd) * L + tok;
+    delta[at] = s;
+    if (neg) {                                     // row constants of the persistent dK/dV kernel: [0] = -lse, [1] = -delta
+      neg[at] = -lse[at];
+      neg[nvec + at] = -s;
+    }
   }
 }
 
