@@ -41,7 +41,11 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     // ------------------------------------------------------------------------------------------------ loader waves
     const int lw = wave - 4;
     const int drow = 8 * lw + (lane >> 3), dpp = lane & 7;        // piece (lw + 4 i): row 32 i + drow, 16-byte part dpp
-    const int tsw_ = (dpp ^ (4 * ((drow >> 1) & 1))) * 16;        // transposing-read swizzle (row fragments take a 4-way conflict)
+    // ONE image for the row reads (ds_read_b128) and the transposing reads (ds_read_b64_tr_b16) of a tile: the 16-byte
+    // chunk c of row R sits at chunk c ^ f(R), f(R) = bit1(R) << 2 | bit3(R) << 1 | bit2(R) -- both kinds of read are
+    // conflict-free (bank model of MI355X_MICROARCH.md, LDS section; the transposing-read swizzle alone left the row reads
+    // 4-way conflicted, and with four compute waves on one LDS that was the kernel's bound)
+    const int tsw_ = (dpp ^ ((((drow >> 1) & 1) << 2) | (((drow >> 3) & 1) << 1) | ((drow >> 2) & 1))) * 16;
     constexpr int OOB = (int)0x80000000;
     struct Src { i32x4 rs_q, rs_do, rs_l, rs_d; int qvo, nblk, qvl; };
     auto open_item = [&](int itm) __attribute__((always_inline)) {
@@ -130,13 +134,17 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     const int r = le & 31, h = le >> 5;
     const int kw0 = kb64 * 64 + kh * 32;
     const int krow = kw0 + r;
-    const int rr0 = r * 128 + ((h ^ (4 * ((r >> 1) & 1))) << 4);
-    const int grp = le >> 4, hh = grp >> 1, q4 = (le & 15) >> 2, pcol = (le & 3) * 4 + 16 * (grp & 1);
-    const int tb0 = (4 * hh + q4) * 128 + pcol * 2, tsw = (q4 >> 1) & 1;
+    const int rr0 = r * 128 + ((h ^ ((((r >> 1) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 2) & 1))) << 4);
+    // transposing reads: lane (grp, q4, p) takes row tokbase + 4 hh + q4 (+ 8 for the second read), logical bytes
+    // 8 p + 32 (grp & 1) + 64 dt of it: chunk c = 2 (grp & 1) + (p >> 1) + 4 dt, stored at c ^ f(row)
+    const int grp = le >> 4, hh = grp >> 1, q4 = (le & 15) >> 2, c0 = 2 * (grp & 1) + ((le & 3) >> 1);
+    const int tbA = (4 * hh + q4) * 128 + ((c0 ^ hh) << 4) + 8 * (le & 1);
+    const int tbB = (4 * hh + q4 + 8) * 128 + ((c0 ^ hh ^ 2) << 4) + 8 * (le & 1);
+    const int tsw = (q4 >> 1) & 1;
     auto ttr = [&](const unsigned char* t_, int tokbase, int dt) __attribute__((always_inline)) {
-      const unsigned char* p0 = t_ + tb0 + tokbase * 128 + ((dt ^ tsw) * 64);
-      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 128));
+      const int o = tokbase * 128 + ((dt ^ tsw) * 64);
+      const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t_ + tbA + o));
+      const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(t_ + tbB + o));
       s16x8 v;
       v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
       v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
