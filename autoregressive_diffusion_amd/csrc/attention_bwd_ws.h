@@ -182,9 +182,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     //         (P = exp2(S') = 0 there, and so is dS): the softmax code below is the same for every sub-block;
     //   B(u): P = exp2(S'), dS = P dP' (the 1/8 of the score scale is applied once, to dK, in the epilogue), packed to bf16;
     //   C(u): dV^T += dO^T.P, dK^T += Q^T.dS with the transposed fragments of the same tiles.
-    // Two-stage software pipeline: a slot issues A(u+1) | B(u) | C(u) -- the 8 MFMAs of A(u+1) depend on nothing the slot
-    // computes, so the exponentials / products / converts of B(u) ride in their gaps (pinned below).
-    auto stageA = [&](f32x16& s, f32x16& dp, const unsigned char* Qt, int trw, int q0) __attribute__((always_inline)) {
+    // MASKED: the sub-block may be partially masked.  Under the DART training table and the causal prefill table that is
+    // the FIRST block of a key block's query list only (the diagonal block: clean queries of the keys' own frames, or -- for
+    // noisy keys -- the only entry); every later block is fully allowed.  The hot loop therefore carries no mask code and
+    // no branch (a branch splits hipcc's scheduling region: the MFMAs of A and the VALU work of B must share one).
+    auto stageA = [&](auto masked_, f32x16& s, f32x16& dp, const unsigned char* Qt, int trw, int q0) __attribute__((always_inline)) {
+      constexpr bool MASKED = decltype(masked_)::value;
       const unsigned char* dOt = Qt + TQ;
       const float* nl = (const float*)(Qt + 2 * TQ) + trw + 4 * h;
       const float* nd = nl + 128;
@@ -194,12 +197,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
         s[4 * g4] = ls.x; s[4 * g4 + 1] = ls.y; s[4 * g4 + 2] = ls.z; s[4 * g4 + 3] = ls.w;
         dp[4 * g4] = de.x; dp[4 * g4 + 1] = de.y; dp[4 * g4 + 2] = de.z; dp[4 * g4 + 3] = de.w;
       }
-      const int qq0 = q0 + trw;
-      if (classify<MODE>(qq0, qq0 + 31, kw0, kw0 + 31, d.pshift, a.T, d.qf_off) != 2) {      // (diagonal blocks only)
+      if constexpr (MASKED) {
+        const int qq0 = q0 + trw;
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) {
           const int qtok = qq0 + 8 * (rr >> 2) + 4 * h + (rr & 3);
-          if (!tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off)) s[rr] = NEG_BIG;
+          s[rr] = tok_allowed<MODE>(qtok, krow, d.pshift, a.T, d.qf_off) ? s[rr] : NEG_BIG;
         }
       }
       bf16x8 qa[4], da[4];
@@ -214,7 +217,16 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
         dp = mfma32(da[ks], vf[ks], dp);                 // dP'[q][key]
       }
     };
-    auto stageB = [&](const f32x16& s, const f32x16& dp, bf16x8 (&pb)[2], bf16x8 (&db)[2]) __attribute__((always_inline)) {
+    // B and C of a sub-block, interleaved by halves: the exponentials / products / converts of key-step half s2 = 1 ride in
+    // the gaps of the four MFMAs of half s2 = 0 (one set of S' / dP' accumulators: a second set, for a deeper pipeline
+    // across sub-blocks, does not fit the 256 registers next to dK, dV, K and V: it spilled)
+    auto stageBC = [&](const f32x16& s, const f32x16& dp, const unsigned char* Qt, int trw) __attribute__((always_inline)) {
+      const unsigned char* dOt = Qt + TQ;
+      bf16x8 pb[2], db[2], dotf[2][2], qtf[2][2];
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) { dotf[s2][dt] = ttr(dOt, trw + 16 * s2, dt); qtf[s2][dt] = ttr(Qt, trw + 16 * s2, dt); }
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -223,57 +235,45 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
           pb[s2][e] = f2bf(p);
           db[s2][e] = f2bf(p * dp[8 * s2 + e]);
         }
-    };
-    auto stageC = [&](const unsigned char* Qt, int trw, bf16x8 (&pb)[2], bf16x8 (&db)[2]) __attribute__((always_inline)) {
-      const unsigned char* dOt = Qt + TQ;
 #pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        bf16x8 dotf[2], qtf[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) { dotf[dt] = ttr(dOt, trw + 16 * s2, dt); qtf[dt] = ttr(Qt, trw + 16 * s2, dt); }
+      for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          dv[dt] = mfma32(dotf[dt], pb[s2], dv[dt]);     // dV^T[dv][key] += dO^T[dv][q] P[q][key]
-          dk[dt] = mfma32(qtf[dt], db[s2], dk[dt]);      // dK^T[d][key]  += Q^T[d][q] dS[q][key]
+          dv[dt] = mfma32(dotf[s2][dt], pb[s2], dv[dt]);     // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+          dk[dt] = mfma32(qtf[s2][dt], db[s2], dk[dt]);      // dK^T[d][key]  += Q^T[d][q] dS[q][key]
         }
+      // pinned order: the 16 transposing reads, the 8 + 8 + 8 VALU instructions of half 0, then each MFMA of half 0 with
+      // two exponentials, two products and two converts of half 1 behind it, then the MFMAs of half 1
+      __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);
+      __builtin_amdgcn_sched_group_barrier(0x400, 8, 0);
+      __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);
+#pragma unroll
+      for (int g_ = 0; g_ < 4; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
       }
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
     };
-    // issue order of a slot: one MFMA of A(u+1), then two exponentials, two products and two converts of B(u) (8 times);
-    // hipcc's own order bunches the transcendental ops, during which an in-order wave cannot feed the matrix pipe
-#define DKV_PIN                                                                          \
-  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                                     \
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
-    __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);                                   \
-    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                   \
-  }
 
     const int trw0 = qh * 64, trw1 = qh * 64 + 32;
     const bool work = kw0 < Lk && nblk > 0;
-    f32x16 sA, dpA, sB, dpB;
-    bf16x8 pb[2], db[2];
-    __syncthreads();                               // barrier_0: blocks 0 and 1 landed
-    if (work) stageA(sA, dpA, smem, trw0, q_start(0));
-#pragma unroll 1
-    for (int j = 0; j < nb; ++j) {
-      if (j > 0) __syncthreads();                  // barrier_j: block j + 1 landed, block j - 1 released
-      if (!work) continue;
+    f32x16 sA, dpA;
+    auto block = [&](auto first_, int j) __attribute__((always_inline)) {
       const unsigned char* S0 = smem + (j & 3) * SLOT;
-      // slot (j, 0):  A(j, 1) | B(j, 0) | C(j, 0)
-      stageA(sB, dpB, S0, trw1, q_start(j));
-      stageB(sA, dpA, pb, db);
-      DKV_PIN
-      stageC(S0, trw0, pb, db);
-      // slot (j, 1):  A(j + 1, 0) | B(j, 1) | C(j, 1)
-      if (j + 1 < nblk) {
-        stageA(sA, dpA, smem + ((j + 1) & 3) * SLOT, trw0, q_start(j + 1));
-        stageB(sB, dpB, pb, db);
-        DKV_PIN
-      } else {
-        stageB(sB, dpB, pb, db);
-      }
-      stageC(S0, trw1, pb, db);
+      const int q0 = q_start(j);
+      stageA(first_, sA, dpA, S0, trw0, q0);
+      stageBC(sA, dpA, S0, trw0);
+      stageA(first_, sA, dpA, S0, trw1, q0);
+      stageBC(sA, dpA, S0, trw1);
+    };
+    __syncthreads();                               // barrier_0: blocks 0 and 1 landed
+    if (work) block(std::true_type{}, 0);
+#pragma unroll 1
+    for (int j = 1; j < nb; ++j) {
+      __syncthreads();                             // barrier_j: block j + 1 landed, block j - 1 released
+      if (work) block(std::false_type{}, j);
     }
-#undef DKV_PIN
 
     // ---- epilogue: the two query halves of a key half meet in ring slot 3 (2 x 16 KB), wave (kh, 0) writes dK, dV
     float* red = (float*)(smem + 3 * SLOT) + kh * 4096 + le;       // [kh][64 registers][64 lanes]
