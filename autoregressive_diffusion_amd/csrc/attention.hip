@@ -329,8 +329,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
 // ================================================================================================================
 // backward: dQ   (the forward's structure: lane = query row, LDS-DMA double-buffered K / V tiles, KS key streams
 // whose partial dQ add up in LDS).  K is read both row-wise (S^T = K.Q^T) and transposed (dQ^T += K^T.dS^T): it is
-// staged once, with the transposing-read swizzle (the row-wise 16-byte reads then take a 4-way bank conflict, which
-// is cheaper than a second copy: LDS is not the limiter here); V is only read row-wise (dP^T = V.dO^T).
+// staged once, in the dual-use image of attention_bwd_ws.h (conflict-free for both kinds of read); V is only read
+// row-wise (dP^T = V.dO^T).
 template <int MODE, int KS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -393,7 +393,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
   for (int i = 0; i < NPC; ++i) {
     const int e = i * NTS + tis, row = e >> 3, pp = e & 7;
     prow[i] = row;
-    kvo[i] = (row * C + head * 64 + (pp ^ (4 * ((row >> 1) & 1))) * 8) * 2;      // K: transposing-read swizzle
+    // K is read row-wise (S^T) AND transposed (dQ^T): one image, chunk c of row R at c ^ f(R), f = bit1 << 2 | bit3 << 1 | bit2,
+    // is conflict-free for both (attention_bwd_ws.h)
+    kvo[i] = (row * C + head * 64 + (pp ^ ((((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 1) | ((row >> 2) & 1))) * 8) * 2;
     vvo[i] = (row * C + head * 64 + (pp ^ ((row >> 1) & 7)) * 8) * 2;            // V: row-read swizzle
   }
   const i32x4 rs_k = make_rsrc((const bf16*)a.k + (size_t)b * Lk * C, Lk * C * 2);
@@ -410,16 +412,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
     }
   };
   // fragment addresses: row reads of K (tr swizzle: piece ^ 4*bit1(row)) and V (piece ^ ((row>>1)&7)); rows kt*32 + r
-  const int kr0 = r * 128 + (((h ^ (4 * ((r >> 1) & 1)))) << 4);          // k-step ks: piece (2ks+h) ^ 4b = ((h ^ 4b) ^ 2ks)
+  const int kr0 = r * 128 + ((h ^ ((((r >> 1) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 2) & 1))) << 4);   // k-step ks: chunk (2ks+h) ^ f(r)
   const int vr0 = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
-  const int grp = lane >> 4, hh = grp >> 1, q4 = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
-  const int tb0 = (4 * hh + q4) * 128 + pcol * 2, tsw = (q4 >> 1) & 1;
+  const int grp = lane >> 4, hh = grp >> 1, q4 = (lane & 15) >> 2, c0 = 2 * (grp & 1) + ((lane & 3) >> 1);
+  const int tbA = (4 * hh + q4) * 128 + ((c0 ^ hh) << 4) + 8 * (lane & 1);
+  const int tbB = (4 * hh + q4 + 8) * 128 + ((c0 ^ hh ^ 2) << 4) + 8 * (lane & 1);
+  const int tsw = (q4 >> 1) & 1;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
   auto ktr = [&](const unsigned char* kt_, int tokbase, int dt) __attribute__((always_inline)) {
-    const unsigned char* p0 = kt_ + tb0 + tokbase * 128 + ((dt ^ tsw) * 64);
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p0 + 8 * 128));
+    const int o = tokbase * 128 + ((dt ^ tsw) * 64);
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(kt_ + tbA + o));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(kt_ + tbB + o));
     s16x8 v;
     v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
     v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
@@ -473,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
             const int key = key0 + kt * 32 + mfma_row(rr, lane);
             if (key >= Lk || !tok_allowed<MODE>(qrow, key, d.pshift, a.T, d.qf_off)) p = 0.f;
           }
-          s[rr] = p * (dp[rr] - delta) * 0.125f;          // dS (scaled)
+          s[rr] = p * (dp[rr] - delta);                   // dS (the 1/8 of the score scale is applied to dQ in the epilogue)
         }
       };
       if (cls == 2) dsoft(std::false_type{});
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnDev d) {
     for (int g = 0; g < 4; ++g) {
       bf16x4 ov;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) ov[k] = f2bf(dq[dt][4 * g + k]);
+      for (int k = 0; k < 4; ++k) ov[k] = f2bf(dq[dt][4 * g + k] * 0.125f);
       *(bf16x4*)(og + dt * 32 + 8 * g + 4 * h) = ov;
     }
 #endif
