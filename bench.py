@@ -400,7 +400,7 @@ def main():
         fence(); t1 = time.perf_counter(); step(i); fence()
         per_mode[name] = (time.perf_counter() - t1) * 1e3
 
-    roof, kernels, roof_attn = None, None, None
+    roof, kernels, roof_attn, roof_attn_bwd = None, None, None, None
     if rank == 0 and not args.no_profile:
         ops.KernelProfile.start()
         for i in range(4):                                        # one full 3:1 cycle (eager), every MFMA conv launch
@@ -423,6 +423,21 @@ def main():
                              flops_per_launch=v["flops"] / v["launches"], achieved=ach / 1e12, peak=MFMA_BF16_PEAK / 1e12,
                              unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK,
                              note="algorithmic FLOPs = unmasked token pairs x 4 x 64 x heads x B (SURVEY 8d)")
+        # ... and its backward: dQ + dK/dV launches of a layer together, priced on the ALGORITHMIC backward FLOPs = 2.5 x the
+        # forward's (five products S, dP, dV, dK, dQ; the two kernels execute seven: each recomputes S and dP)
+        bq = {k: v for k, v in agg.items() if k.startswith("attn_bwd_dq") and "MODE=2" in k}
+        bkv = {k: v for k, v in agg.items() if k.startswith("attn_bwd_dkv") and "MODE=2" in k}
+        roof_attn_bwd = None
+        if attn and bq and bkv:
+            fwd = max(attn.values(), key=lambda v: v["ms"])
+            n = fwd["launches"]
+            ms = sum(v["ms"] for v in bq.values()) + sum(v["ms"] for v in bkv.values())
+            fl = 2.5 * fwd["flops"]
+            ach = fl / (ms * 1e-3)
+            roof_attn_bwd = dict(bound="mfma", kernels=sorted(bq) + sorted(bkv), layers=n, avg_layer_ms=ms / n,
+                                 flops_per_layer=fl / n, achieved=ach / 1e12, peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s",
+                                 frac=ach / MFMA_BF16_PEAK,
+                                 note="dQ + dK/dV launches of one VideoAttention layer; algorithmic FLOPs = 2.5 x forward")
     elif world > 1:
         for i in range(4):
             step(i, profile=True)                                 # keep collectives matched across ranks
@@ -452,7 +467,7 @@ def main():
                           **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
                           **{k: round(v, 2) for k, v in per_mode.items()}},
                "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "roofline_attention": roof_attn,
-               "kernels": kernels}
+               "roofline_attention_bwd": roof_attn_bwd, "kernels": kernels}
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()
