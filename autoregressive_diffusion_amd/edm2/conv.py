@@ -191,18 +191,7 @@ def batched_gates(convs, c_noise, caches, training):
         ca, cb = ops.gates_train(c_noise.float().reshape(-1).contiguous(), P, _nctx_i32(n_ctx, dev) if any(n_ctx) else None, T,
                                  pack, anchor)
         return [(a, b, n + T) for a, b, n in zip(ca.unbind(0), cb.unbind(0), n_ctx)]
-    mult = torch.stack([m.gating.mult for m in convs])            # (L,2)
-    off = torch.stack([m.gating.offset for m in convs])           # (L,2)
-    lo = torch.sigmoid(torch.stack([m.gating.min_gating for m in convs]))[:, None, None]
-    hi = torch.sigmoid(torch.stack([m.gating.max_gating for m in convs]))[:, None, None]
-    base = (torch.arange(B * tt, device=dev) % T).reshape(1, B, tt)
-    if any(n_ctx):
-        base = base + nctx_tensor(n_ctx, dev)
-    pos = base.to(c_noise.dtype).log1p()              # (no host->device copy in training: hipGraph-capturable)
-    sv = c_noise[None] * mult[:, 0, None, None] + off[:, 0, None, None] + pos * mult[:, 1, None, None] + off[:, 1, None, None]
-    g = (lo + (1 - lo) * hi * torch.sigmoid(sv)).reshape(len(convs), -1)
-    ca, cb = ops.gate_coefs(g)
-    return [(a, b, n + T) for a, b, n in zip(ca.unbind(0), cb.unbind(0), n_ctx)]
+    return ops._prelude_ref("batched_gates")(convs, c_noise, caches, training, n_ctx, T, nctx_tensor)
 
 
 class MPCausal3DGatedConv(nn.Module):

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .loss_weight import MultiNoiseLoss
-from .utils import (BetterModule, MPFourier, mp_silu, mp_sum, mp_cat_cl, normalize_cl, resample_cl, to_cl, from_cl, BF16)
+from .utils import BetterModule, MPFourier, to_cl, from_cl, BF16
 from .conv import MPConv, MPCausal3DGatedConv, Gating, weights_ready, batched_gates
 from .attention import FrameAttention, VideoAttention
 
@@ -183,13 +183,7 @@ class UNet(BetterModule):
                                       self.emb_noise.weight.pw, self.emb_label.weight.pw if with_label else None,
                                       self.label_dim)
             else:
-                # embedding (fp32 in torch for the tiny Fourier features, bf16 through the linear kernels)
-                emb = self.emb_noise.forward(self.emb_fourier_sigma(cn))
-                if self.emb_label is not None and conditioning is not None:
-                    oh = F.one_hot(conditioning.reshape(-1), num_classes=self.label_dim).to(cn.dtype) * math.sqrt(self.label_dim)
-                    emb = mp_sum(emb, self.emb_label.forward(oh), t=1 / 3)
-                emb = mp_silu(emb)
-                emb = emb.to(BF16)[:, None, None, :].contiguous()
+                emb = ops._prelude_ref("embedding")(self, cn, conditioning)
             # input: (B,t,C,H,W) -> channels-last with the extra all-ones channel (:221), padded to 16 channels
             N = B * tt
             if _cl_io is None:

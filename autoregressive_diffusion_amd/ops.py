@@ -935,7 +935,15 @@ class _SplitCols(torch.autograd.Function):
         return torch.cat(parts, dim=1), None
 
 
-FUSED_PRELUDE = int(_os.environ.get("ONIRIS_FUSED_PRELUDE", "1"))   # 0: torch-autograd formulation of gates / embedding / emb scales (A/B, tests)
+FUSED_PRELUDE = 1              # tests set 0 AND install `prelude_reference` (tests/torch_prelude.py): the torch-autograd
+prelude_reference = None       # formulation of gates / embedding / emb scales lives with the tests, not in the product
+
+
+def _prelude_ref(name):
+    if prelude_reference is None:
+        raise RuntimeError("the conditioning prelude runs on the fused HIP kernels only (HIP tensors, FUSED_PRELUDE = 1); its "
+                           "torch formulation is test infrastructure: tests/torch_prelude.py")
+    return getattr(prelude_reference, name)
 
 
 def direct_pack(params, holder, name):
@@ -1115,26 +1123,7 @@ def emb_scales(emb, gpw, gains):
             res.append(outs[j])
             j += 2 if roundup(m.cout, 64) != m.cout else 1
         return res
-    sizes, seg = [], []
-    for k, m in enumerate(gpw.members):
-        sizes.append(m.cout)
-        seg += [k] * m.cout
-        pad = roundup(m.cout, 64) - m.cout
-        if pad:
-            sizes.append(pad)
-            seg += [k] * pad
-    cache = _emb_idx_cache.get((id(gpw), str(dev)))
-    if cache is None:
-        cache = torch.tensor(seg, dtype=torch.int64, device=dev)
-        _emb_idx_cache[(id(gpw), str(dev))] = cache
-    g_col = torch.stack(list(gains)).float().index_select(0, cache)                 # (Ctot,)
-    c = torch.addcmul(torch.ones((), dtype=torch.float32, device=dev), c_all.float(), g_col)
-    outs = _SplitCols.apply(c, tuple(sizes))
-    res, j = [], 0
-    for m in gpw.members:
-        res.append(outs[j])
-        j += 2 if roundup(m.cout, 64) != m.cout else 1
-    return res
+    return _prelude_ref("emb_scales")(c_all, gpw, gains, _SplitCols)
 
 
 _emb_idx_cache = {}

@@ -552,8 +552,10 @@ class FlatEMA:
 
 
 class FlatAdamW:
-    """AdamW on the flat buffers, optionally with gradient-norm clipping and the EMA update in the same pass.
-    GPU: fused HIP kernels (oniris_sqnorm + oniris_adamw_clip_ema); CPU tensors (tests): plain torch math."""
+    """AdamW on the flat buffers, optionally with gradient-norm clipping and the EMA update in the same pass: fused HIP
+    kernels (oniris_sqnorm + oniris_adamw_clip_ema).  CPU tensors are refused unless a test installed `cpu_update`."""
+
+    cpu_update = None          # tests only: callable(opt, runs, grad_scale, max_norm, ema, owned, norm_reduce)
 
     def __init__(self, flat, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.flat = flat
@@ -662,23 +664,13 @@ class FlatAdamW:
                            self.betas[1], self.eps, self.weight_decay, st, grad_scale, max_norm, self._norm_buf,
                            [(e[lo:hi], w) for e, w in ema], norm_ready=True)
         else:
-            b1, b2 = self.betas
-            coef = 1.0
-            if max_norm is not None:
-                if owned is None:
-                    sq = (f.grad * grad_scale).pow(2).sum().reshape(1)
-                else:
-                    sq = norm_reduce(sum((f.grad[a:b] * grad_scale).pow(2).sum() for a, b in owned).reshape(1))
-                coef = min(1.0, max_norm / (float(sq.sqrt()) + 1e-6))
-            for lo, hi, st in runs:
-                if st:
-                    g = f.grad[lo:hi] * (grad_scale * coef)
-                    self.m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
-                    self.v[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
-                    mh, vh = self.m[lo:hi] / (1 - b1 ** st), self.v[lo:hi] / (1 - b2 ** st)
-                    f.flat[lo:hi].mul_(1 - self.lr * self.weight_decay).sub_(self.lr * mh / (vh.sqrt() + self.eps))
-                for e, w in ema:
-                    e[lo:hi].lerp_(f.flat[lo:hi], w)
+            # No CPU arithmetic in the product path: the host-side LOGIC of this class (runs, per-parameter step counters,
+            # owned ranges, state_dict layout) is exercised by the CPU tests with a reference update they install themselves
+            # (tests/cpu_reference_optimizer.py); without it CPU tensors are refused.
+            if FlatAdamW.cpu_update is None:
+                raise RuntimeError("FlatAdamW needs HIP tensors (no CPU fallback in the product path; the CPU tests "
+                                   "install tests/cpu_reference_optimizer.py)")
+            FlatAdamW.cpu_update(self, runs, grad_scale, max_norm, ema, owned, norm_reduce)
         after = getattr(f, "_after_step", None)
         if after is not None:
             after()

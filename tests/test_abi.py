@@ -120,3 +120,21 @@ def test_attention_flop_count_is_the_unmasked_pair_count():
     for T, P, want in [(64, 64, 4128), (32, 16, 944), (64, 16, 3936), (8, 64, 68), (4, 256, 20), (3, 128, 12), (16, 32, 248)]:
         assert ops.train_frame_pairs(T, P) == want == int(O.train_allowed_tokens(T, P).sum()) // (P * P)
     assert ops._attn_flops("video", 2, 64, 4, 8192, 64) == 4.0 * 64 * 4 * 2 * 4128 * 64 * 64
+
+
+def test_optimizer_and_prelude_have_no_cpu_arithmetic_in_the_product():
+    """the plain-torch AdamW for CPU tensors and the torch formulation of the conditioning prelude
+    used to ship inside the package; they live under tests/ now (cpu_reference_optimizer.py, torch_prelude.py) and the
+    product refuses without them.  Checked in a fresh interpreter (this process may have them installed)."""
+    import subprocess, sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch\n"
+        "from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW\n"
+        "from autoregressive_diffusion_amd import ops\n"
+        "net = torch.nn.Linear(3, 2); flat = FlatParams(net); opt = FlatAdamW(flat)\n"
+        "net(torch.randn(4, 3)).sum().backward()\n"
+        "try:\n    opt.step(); print('STEPPED')\nexcept RuntimeError as e:\n    print('REFUSED', 'no CPU fallback' in str(e))\n"
+        "try:\n    ops._prelude_ref('batched_gates'); print('HAS_REF')\nexcept RuntimeError as e:\n    print('NOREF')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "REFUSED True" in out.stdout and "NOREF" in out.stdout, out.stdout + out.stderr

@@ -7,6 +7,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 from torch import nn
 
+import cpu_reference_optimizer      # the product's FlatAdamW has no CPU arithmetic: the tests bring their own (also in the
+cpu_reference_optimizer.install()   # spawned workers, which import this module)
+
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p

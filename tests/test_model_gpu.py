@@ -245,6 +245,8 @@ def test_fused_prelude_matches_torch_formulation(mode, monkeypatch):
     sigma = (torch.randn(B, n, generator=g) + 0.4).exp().to(DEV)
     eps = torch.randn(B, n, 8, 64, 64, generator=g).to(DEV)
     res = {}
+    import torch_prelude
+    monkeypatch.setattr(ops, "prelude_reference", torch_prelude)
     for fused in (1, 0):
         monkeypatch.setattr(ops, "FUSED_PRELUDE", fused)
         net = build_precond(C1_CFG, 33, 1.0).train()

@@ -7,6 +7,9 @@ import pytest
 import torch
 from torch import nn
 
+import cpu_reference_optimizer      # (the product's FlatAdamW has no CPU arithmetic: the CPU tests install their own)
+cpu_reference_optimizer.install()
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
