@@ -369,7 +369,7 @@ def test_cs_shaped_unet_vs_oracle(tag, cfg, Tn, labelled):
     print(tag, "loss", loss.item(), ref.item(), "median weight-grad rel L2", float(np.median(list(errs.values()))),
           "worst", worst, errs[worst])
     assert abs(loss.item() - ref.item()) / abs(ref.item()) < 2e-2
-    assert np.median(list(errs.values())) < 2e-2 and errs[worst] < 8e-2
+    assert np.median(list(errs.values())) < 2e-2 and errs[worst] < 4e-2        # (measured: median 1.1-1.5e-2, worst <= 2.3e-2, flat in T: profiles/r03_err_vs_T.txt)
     if not labelled:
         assert prm["unet.emb_label.weight.weight"].grad is None or float(prm["unet.emb_label.weight.weight"].grad.abs().max()) == 0
 
