@@ -134,7 +134,7 @@ def attn_schedule(weights, n_pairs, device, n_wg=None):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched")
+                 "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched", "embcache")
 
 
 def _nsplit_cap(cin, cout, taps):
@@ -1095,8 +1095,10 @@ def emb_scales(emb, gpw, gains):
     c_all = conv(emb, gpw).reshape(N, gpw.cout)
     dev = emb.device
     if FUSED_PRELUDE and c_all.is_cuda:
-        key = ("fused", id(gpw), str(dev))
-        cache = _emb_idx_cache.get(key)
+        # (kept ON the group object: a dictionary keyed by id(gpw) handed a recycled id the tables of a dead net)
+        cache = getattr(gpw, "embcache", None)
+        if cache is not None and cache[1].device != dev:
+            cache = None
         if cache is None:
             sizes, seg, start = [], [], [0]
             for k, m in enumerate(gpw.members):
@@ -1107,8 +1109,8 @@ def emb_scales(emb, gpw, gains):
                 seg += [k] * w
                 start.append(start[-1] + w)
             assert start[-1] == gpw.cout, (start[-1], gpw.cout)
-            cache = _emb_idx_cache[key] = (tuple(sizes), torch.tensor(seg, dtype=torch.int32, device=dev),
-                                           torch.tensor(start, dtype=torch.int32, device=dev))
+            cache = gpw.embcache = (tuple(sizes), torch.tensor(seg, dtype=torch.int32, device=dev),
+                                    torch.tensor(start, dtype=torch.int32, device=dev))
         sizes, seg, start = cache
         pack = direct_pack(gains, gpw, "_gain_pack") if torch.is_grad_enabled() else None
         if pack is not None:
@@ -1125,8 +1127,6 @@ def emb_scales(emb, gpw, gains):
         return res
     return _prelude_ref("emb_scales")(c_all, gpw, gains, _SplitCols)
 
-
-_emb_idx_cache = {}
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -37,9 +37,6 @@ def embedding(unet, cn, conditioning):
     return emb.to(BF16)[:, None, None, :].contiguous()
 
 
-_idx_cache = {}
-
-
 def emb_scales(c_all, gpw, gains, split_cols):
     from autoregressive_diffusion_amd.ops import roundup
     dev = c_all.device
@@ -51,9 +48,7 @@ def emb_scales(c_all, gpw, gains, split_cols):
         if pad:
             sizes.append(pad)
             seg += [k] * pad
-    cache = _idx_cache.get((id(gpw), str(dev)))
-    if cache is None:
-        cache = _idx_cache[(id(gpw), str(dev))] = torch.tensor(seg, dtype=torch.int64, device=dev)
+    cache = torch.tensor(seg, dtype=torch.int64, device=dev)
     g_col = torch.stack(list(gains)).float().index_select(0, cache)                 # (Ctot,)
     c = torch.addcmul(torch.ones((), dtype=torch.float32, device=dev), c_all.float(), g_col)
     outs = split_cols.apply(c, tuple(sizes))
