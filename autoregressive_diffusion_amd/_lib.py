@@ -60,7 +60,8 @@ class AttnArgs(C.Structure):
                 ("dout", c_void_p), ("doutt", c_void_p), ("delta", c_void_p),
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
                 ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("pad_", c_int32),
-                ("sched", c_void_p), ("sched_wgs", c_int32), ("sched_slots", c_int32), ("v_bstride", c_int64)]
+                ("sched", c_void_p), ("sched_wgs", c_int32), ("sched_slots", c_int32), ("v_bstride", c_int64),
+                ("k_bstride", c_int64)]
 
 
 EPI_NONE, EPI_EMB_SILU, EPI_MPSUM = 0, 1, 2
@@ -126,7 +127,9 @@ _SIGS = {
     "oniris_embed_post": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "oniris_embed_post_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_void_p]),
     "oniris_rope": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                            c_int, c_int, c_int, c_int64, c_void_p]),
+                            c_int, c_int, c_int, c_int64, c_int64, c_void_p]),
+    "oniris_qkv_norm_rope_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_int64, c_int, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "oniris_attn_fwd": (c_int, [C.POINTER(AttnArgs), c_void_p]),
     "oniris_attn_bwd_prep": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                      c_void_p]),

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
     kvo[i] = (row * C + head * 64 + (pp ^ ((row >> 1) & 7)) * 8) * 2;
     vvo[i] = (row * C + head * 64 + (pp ^ (4 * ((row >> 1) & 1))) * 8) * 2;
   }
-  const i32x4 rs_k = make_rsrc((const bf16*)a.k + (size_t)b * Lk * C, Lk * C * 2);
+  const i32x4 rs_k = make_rsrc((const bf16*)a.k + (size_t)b * (a.k_bstride ? (size_t)a.k_bstride : (size_t)Lk * C), Lk * C * 2);
   const i32x4 rs_v = make_rsrc((const bf16*)a.v + (size_t)b * (a.v_bstride ? (size_t)a.v_bstride : (size_t)Lk * C), Lk * C * 2);
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
   auto issue = [&](int key0, int bsel) __attribute__((always_inline)) {
@@ -845,6 +845,53 @@ __global__ void qkv_norm_rope_kernel(const bf16* __restrict__ qkv, bf16* __restr
   *(bf16x8*)(dst + tok * C + hd * 64 + part * 8) = o;
 }
 
+// One NEW frame per sequence of the KV-cached sampler (attention_modules.py:51-70): normalisation of q, k, v and the rotary
+// embedding of q and k at the frame's position `pos` (= n_keys - 1: tables row pos) in one pass.  Outputs: q rotated (with
+// the softmax scale), k UN-rotated and v into the KV ring behind the committed frames (the cache keeps un-rotated keys:
+// every later frame count re-rotates them, RoPe.py:55-57), k rotated into the ring's ROTATED image `kr`, whose committed
+// frames were rotated once for this frame count (KVRing.rotate_committed) instead of once per UNet evaluation.
+__global__ void qkv_norm_rope_eval_kernel(const bf16* __restrict__ qkv, bf16* __restrict__ q, bf16* __restrict__ k,
+                                          bf16* __restrict__ v, bf16* __restrict__ kr, const float* __restrict__ cos_t,
+                                          const float* __restrict__ sin_t, const float* __restrict__ scale_t, long long nvec,
+                                          int C, long long kv_tpb, long long kv_bstride, long long kv_off, int pos) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long vec = gid >> 3;
+  const int part = (int)(gid & 7);
+  if (vec >= nvec) return;                            // (nvec * 8 is a multiple of 64: whole waves leave together)
+  const int hpt = 3 * C / 64;
+  const long long tok = vec / hpt;
+  const int vi = (int)(vec % hpt);
+  const int s = vi / (C / 64), hd = vi % (C / 64);
+  const bf16x8 x = *(const bf16x8*)(qkv + tok * 3 * C + (size_t)vi * 64 + part * 8);
+  float f[8], ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { f[i] = bf2f(x[i]); ss += f[i] * f[i]; }
+  ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
+  const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
+  const size_t tb = (size_t)pos * 64 + part * 8;
+  const float sg = (part < 4) ? -1.f : 1.f;          // rotate_half: [-x2, x1]
+  bf16x8 plain, rot;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    // like the two-launch path (qkv_norm, then rope on its bf16 output) the rotation sees the bf16-rounded vector, so that
+    // the rotated key of a frame is the same number whether it is rotated now or re-rotated from the ring later
+    const float u = bf2f(f2bf(f[i] * inv));
+    const float up = __shfl_xor(u, 4);
+    plain[i] = f2bf(u);
+    float val = u;
+    if (s != 2) {
+      val = u * cos_t[tb + i] + sg * up * sin_t[tb + i];
+      const float scl = scale_t[tb + i];
+      val = (s == 0) ? val * scl : val / scl;
+    }
+    rot[i] = f2bf(val);
+  }
+  const long long ring = (tok / kv_tpb) * kv_bstride + (kv_off + tok % kv_tpb) * C + hd * 64 + part * 8;
+  if (s == 0) *(bf16x8*)(q + tok * C + hd * 64 + part * 8) = rot;
+  else if (s == 1) { *(bf16x8*)(k + ring) = plain; *(bf16x8*)(kr + ring) = rot; }
+  else *(bf16x8*)(v + ring) = plain;
+}
+
 // adjoint of qkv_norm_rope_kernel: dq (w.r.t. the UNSCALED rotated q, as the attention backward returns it), dk, dv ->
 // dqkv.  R^T g = g cos - rot(g sin) and the scale vector is equal in both halves, so it commutes with the rotation.
 __global__ void qkv_norm_rope_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dq,
@@ -893,7 +940,7 @@ __global__ __launch_bounds__(256) void rope_kernel(const bf16* __restrict__ x, b
                                                    bf16* __restrict__ xt, const float* __restrict__ cos_t,
                                                    const float* __restrict__ sin_t, const float* __restrict__ scale_t,
                                                    int mode, int L, int P, int C, int heads, int pos_offset,
-                                                   int pos_mod, long long x_bstride) {
+                                                   int pos_mod, long long x_bstride, long long xr_bstride) {
   __shared__ float tile[64][65];
   const int tid = threadIdx.x;
   const int tok0 = blockIdx.x * 64, head = blockIdx.y, b = blockIdx.z;
@@ -948,7 +995,7 @@ __global__ __launch_bounds__(256) void rope_kernel(const bf16* __restrict__ x, b
       bf16x8 v0, v1;
 #pragma unroll
       for (int i = 0; i < 8; ++i) { v0[i] = f2bf(tile[row][part * 16 + i]); v1[i] = f2bf(tile[row][part * 16 + 8 + i]); }
-      bf16* dst = xr + (size_t)b * L * C + head * 64 + (size_t)tok * C + part * 16;
+      bf16* dst = xr + (size_t)b * xr_bstride + head * 64 + (size_t)tok * C + part * 16;
       *(bf16x8*)dst = v0;
       *(bf16x8*)(dst + 8) = v1;
     }
@@ -1044,6 +1091,8 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.out, "attn_fwd: null pointer");
   ONIRIS_CHECK_ARG(d.a.v_bstride == 0 || (!d.a.sched && d.a.v_bstride >= (int64_t)d.a.Lk * d.a.C),
                    "attn_fwd: v_bstride is served by the grid kernel only and must cover a sequence");
+  ONIRIS_CHECK_ARG(d.a.k_bstride == 0 || (!d.a.sched && d.a.k_bstride >= (int64_t)d.a.Lk * d.a.C),
+                   "attn_fwd: k_bstride is served by the grid kernel only and must cover a sequence");
   if (d.a.sched) {                                  // persistent, statically balanced, wave-specialised kernel (attention_ws.h)
     ONIRIS_CHECK_ARG(d.a.sched_wgs > 0 && d.a.sched_slots > 0, "attn_fwd: empty schedule");
     ONIRIS_CHECK_ARG(d.a.mask_mode != 0, "attn_fwd: the scheduled kernel serves the table-driven masks");
@@ -1145,6 +1194,22 @@ extern "C" int oniris_qkv_norm_rope(const void* qkv, void* q, void* k, void* v, 
   return ONIRIS_OK;
 }
 
+extern "C" int oniris_qkv_norm_rope_eval(const void* qkv, void* q, void* k, void* v, void* kr, const float* cos_t,
+                                         const float* sin_t, const float* scale_t, int64_t n_tokens, int C,
+                                         int64_t kv_tokens_per_batch, int64_t kv_batch_stride, int64_t kv_token_offset, int pos,
+                                         oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(qkv && q && k && v && kr && cos_t && sin_t && scale_t && n_tokens > 0 && C % 64 == 0 && pos >= 0 &&
+                   kv_tokens_per_batch > 0 && n_tokens % kv_tokens_per_batch == 0 && n_tokens % 8 == 0 &&
+                   kv_batch_stride >= (kv_token_offset + kv_tokens_per_batch) * C, "qkv_norm_rope_eval: bad arguments");
+  const long long nvec = (long long)n_tokens * (3 * C / 64);
+  hipLaunchKernelGGL(qkv_norm_rope_eval_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
+                     (const bf16*)qkv, (bf16*)q, (bf16*)k, (bf16*)v, (bf16*)kr, cos_t, sin_t, scale_t, nvec, C,
+                     (long long)kv_tokens_per_batch, (long long)kv_batch_stride, (long long)kv_token_offset, pos);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
 extern "C" int oniris_qkv_norm_rope_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv,
                                         const float* cos_t, const float* sin_t, const float* scale_t, int64_t n_tokens, int C,
                                         int P, int pos_mod, oniris_stream_t stream_) {
@@ -1189,7 +1254,7 @@ extern "C" int oniris_qkv_norm_bwd(const void* qkv, const void* dq, const void* 
 
 extern "C" int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const float* sin_t,
                            const float* scale_t, int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod,
-                           int64_t x_batch_stride, oniris_stream_t stream_) {
+                           int64_t x_batch_stride, int64_t xr_batch_stride, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(x && (xr || xt) && B > 0 && frames > 0 && P > 0 && C % 64 == 0 && mode >= 0 && mode <= 4,
                    "rope: bad arguments");
@@ -1197,10 +1262,12 @@ extern "C" int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t
   const int L = frames * P;
   ONIRIS_CHECK_ARG(L % 8 == 0, "rope: frames*P must be a multiple of 8");
   ONIRIS_CHECK_ARG(x_batch_stride == 0 || x_batch_stride >= (int64_t)L * C, "rope: batch stride smaller than a sequence");
+  ONIRIS_CHECK_ARG(xr_batch_stride == 0 || xr_batch_stride >= (int64_t)L * C, "rope: output batch stride smaller than a sequence");
   const dim3 grid(cdiv(L, 64), C / 64, B);
   hipLaunchKernelGGL(rope_kernel, grid, dim3(256), 0, stream, (const bf16*)x, (bf16*)xr, (bf16*)xt, cos_t, sin_t,
                      scale_t, mode, L, P, C, C / 64, pos_offset, pos_mod > 0 ? pos_mod : 1,
-                     (long long)(x_batch_stride > 0 ? x_batch_stride : (int64_t)L * C));
+                     (long long)(x_batch_stride > 0 ? x_batch_stride : (int64_t)L * C),
+                     (long long)(xr_batch_stride > 0 ? xr_batch_stride : (int64_t)L * C));
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -1214,6 +1281,6 @@ extern "C" int oniris_attn_bwd_prep(const void* dout, const void* out, float* de
   hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)dout, (const bf16*)out, delta, lse, neg, nvec, L, C, heads);
   ONIRIS_LAUNCH_CHECK();
-  if (doutt) return oniris_rope(dout, nullptr, doutt, nullptr, nullptr, nullptr, 0, B, L, 1, C, 0, 1, 0, stream_);
+  if (doutt) return oniris_rope(dout, nullptr, doutt, nullptr, nullptr, nullptr, 0, B, L, 1, C, 0, 1, 0, 0, stream_);
   return ONIRIS_OK;
 }

@@ -328,6 +328,8 @@ class UNet(BetterModule):
                 ring = ops.KVRing.of(kv, kv[0].shape[0], P, kv[0].shape[2], 1, dev)
                 if ring is not getattr(kv[0], "_oniris_ring", None):
                     cache[(side, name)]["attn"] = ring.views()
+                # the committed keys rotated ONCE for the next frame count (every evaluation of the frame reads them)
+                ring.rotate_committed((att.rope.inv_freq, att.rope.scale))
 
     def _gate_layers(self, cache):
         convs, caches = [], []

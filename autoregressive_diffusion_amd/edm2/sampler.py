@@ -62,6 +62,12 @@ def edm_sampler_with_mse(net, cache, target=None, gnet=None, conditioning=None, 
     B, _, C, H, W = cache.get("shape", (None,) * 5)
     device = net.device
 
+    # per-frame-count preparation shared by all 31 evaluations of this frame (graphed or eager): RoPE tables, gate counters,
+    # room in the KV rings, and the cached keys rotated ONCE for the new key count (ops.KVRing.rotate_committed)
+    unet = getattr(net, "unet", None)
+    if hasattr(unet, "prewarm_eval") and torch.device(device).type == "cuda":
+        unet.prewarm_eval(cache)
+
     graphed = None
     if (SAMPLER_GRAPH and guidance == 1 and torch.device(device).type == "cuda" and dtype == torch.float32
             and num_steps >= 4):

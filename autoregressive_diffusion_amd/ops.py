@@ -1151,10 +1151,10 @@ def rope_tables(inv_freq, scale_vec, n_pos, device, scale_base=64):
     return _rope_cache[key]
 
 
-def _rope(x, xr, xt, tabs, mode, B, frames, P, C, pos_offset, pos_mod, x_bstride=0):
+def _rope(x, xr, xt, tabs, mode, B, frames, P, C, pos_offset, pos_mod, x_bstride=0, xr_bstride=0):
     cs, sn, sc = tabs if tabs is not None else (None, None, None)
     check(lib.oniris_rope(_p(x), _p(xr), _p(xt), _p(cs), _p(sn), _p(sc), mode, B, frames, P, C, pos_offset, pos_mod,
-                          x_bstride, _stream()), "rope")
+                          x_bstride, xr_bstride, _stream()), "rope")
 
 
 def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mode, P, T):
@@ -1309,6 +1309,23 @@ class KVRing:
         self.B, self.P, self.C, self.cap, self.n = B, P, C, cap, 0
         self.K = torch.empty((B, cap * P, C), dtype=BF16, device=device)
         self.V = torch.empty((B, cap * P, C), dtype=BF16, device=device)
+        # ROTATED image of K for ONE key count (RoPe.py:55-57 re-rotates every key whenever the count changes): the
+        # committed frames are rotated once per generated frame (rotate_committed, from UNet.prewarm_eval), the new frame's
+        # key is added by the fused qkv kernel of each of the frame's 31 evaluations -- instead of one pass over the whole
+        # ring per evaluation.  kr_state = (committed frames, key count) the image is valid for.
+        self.KR = torch.empty((B, cap * P, C), dtype=BF16, device=device)
+        self.kr_state = None
+
+    @torch.no_grad()
+    def rotate_committed(self, rope_bufs):
+        n, nk = self.n, self.n + 1
+        if self.kr_state == (n, nk):
+            return
+        if n > 0:
+            tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], nk, self.K.device)
+            bstride = self.cap * self.P * self.C
+            _rope(self.K, self.KR, None, tabs_r, 2, self.B, n, self.P, self.C, 0, nk, x_bstride=bstride, xr_bstride=bstride)
+        self.kr_state = (n, nk)
 
     def views(self):
         k, v = self.K[:, :self.n * self.P], self.V[:, :self.n * self.P]
@@ -1349,8 +1366,25 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     n = ring.n
     q = torch.empty((N, P, C), dtype=BF16, device=dev)
     bstride = ring.cap * P * C
-    check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(ring.K), _p(ring.V), N * P, C, t * P, bstride, n * P, _stream()), "qkv_norm")
     nk = n + t
+    if t == 1 and ring.kr_state == (n, nk):
+        # one new frame, and the ring's rotated image is ready for this key count (UNet.prewarm_eval): normalisation + the
+        # rotation of the new q / k in ONE launch, dense attention straight over the ring -- 4 launches per layer and
+        # evaluation instead of 6, and no pass over all cached keys
+        cs_, sn_, sc_ = rope_tables(rope_bufs[0], rope_bufs[1], nk, dev)
+        check(lib.oniris_qkv_norm_rope_eval(_p(qkv), _p(q), _p(ring.K), _p(ring.V), _p(ring.KR), _p(cs_), _p(sn_), _p(sc_),
+                                            N * P, C, P, bstride, n * P, n, _stream()), "qkv_norm_rope_eval")
+        if update_cache:
+            ring.n = nk
+            new_cache = ring.views()
+        else:
+            new_cache = kv_cache
+        out = torch.empty((N, P, C), dtype=BF16, device=dev)
+        a = _attn_args(q, ring.KR, ring.V, None, None, None, out, None, None, B, heads, P, nk * P, C, 0, P, 0)
+        a.v_bstride = a.k_bstride = bstride
+        check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+        return out, new_cache
+    check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(ring.K), _p(ring.V), N * P, C, t * P, bstride, n * P, _stream()), "qkv_norm")
     if update_cache:
         ring.n = nk
         new_cache = ring.views()

@@ -321,7 +321,15 @@ int oniris_qkv_norm_rope_bwd(const void* qkv, const void* dq, const void* dk, co
 int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const float* sin_t, const float* scale_t,
                 int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod,
                 int64_t x_batch_stride /* elements between the sequences of x (KV ring); 0 = frames*P*C */,
-                oniris_stream_t stream);
+                int64_t xr_batch_stride /* the same for xr */, oniris_stream_t stream);
+/* One new frame per sequence in the KV-cached sampler (edm2/sampler.py:12-85; attention_modules.py:51-70): oniris_qkv_norm
+ * + the rotation of the frame's q and k at table row `pos` (= number of keys - 1) in one pass.  k (un-rotated) and v go
+ * into the KV ring as in oniris_qkv_norm; kr receives the ROTATED k at the same ring position: the ring's rotated image,
+ * whose committed frames the host rotates once per frame count (oniris_rope mode 2 with xr_batch_stride) instead of once
+ * per UNet evaluation (31 per generated frame).                                                                     */
+int oniris_qkv_norm_rope_eval(const void* qkv, void* q, void* k, void* v, void* kr, const float* cos_t, const float* sin_t,
+                              const float* scale_t, int64_t n_tokens, int C, int64_t kv_tokens_per_batch,
+                              int64_t kv_batch_stride, int64_t kv_token_offset, int pos, oniris_stream_t stream);
 
 /* Block-sparse flash attention forward (replaces compiled_flex_attention / F.scaled_dot_product_attention,
  * attention_modules.py:41,66,70,75,115).  q [B][Lq][C], k,v [B][Lk][C] bf16 (head h = channels 64h..64h+63),
@@ -359,6 +367,7 @@ typedef struct OnirisAttnArgs {
   const int32_t* sched;
   int32_t sched_wgs, sched_slots;
   int64_t v_bstride;                      /* elements between the sequences of v (a KV ring); 0 = Lk*C (forward only) */
+  int64_t k_bstride;                      /* the same for k (the ring's rotated image)                                */
 } OnirisAttnArgs;
 
 /* Static load balancing of block-sparse attention [host]: n_pairs (batch, head) pairs x n_blocks work items per pair

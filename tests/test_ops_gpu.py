@@ -402,10 +402,20 @@ def test_decode_attention_at_rollout_depth_vs_oracle():
     cache = ring.views()
     outs = []
     rk, rv = kc, vc
+    rb = (inv.to(DEV), sc.to(DEV))
     for step in range(2):                                  # frame 256 (fills the ring), frame 257 (grows it)
         a = bfr(torch.randn(B, 3 * C, H, H))
         perm = a.reshape(B, m * 64, 3, H, H).permute(0, 2, 1, 3, 4).reshape(B, 3 * C, H, H)
-        out, cache = ops.attention_eval(nhwc(perm).reshape(B, P, 3 * C), B, m, (inv.to(DEV), sc.to(DEV)), cache, True, P)
+        if step == 0:
+            # the sampler's path: the cached keys rotated once for this key count (UNet.prewarm_eval), then ONE launch for
+            # the new frame's q / k / v (oniris_qkv_norm_rope_eval) and the decode kernel straight over the ring; the
+            # three-launch path without preparation must give the same answer
+            o3, _ = ops.attention_eval(nhwc(perm).reshape(B, P, 3 * C), B, m, rb, cache, False, P)
+            cache[0]._oniris_ring.rotate_committed(rb)
+            assert cache[0]._oniris_ring.kr_state == (n_old, n_old + 1)
+            o1, _ = ops.attention_eval(nhwc(perm).reshape(B, P, 3 * C), B, m, rb, cache, False, P)
+            assert rel(o1, o3) < 2e-3, rel(o1, o3)
+        out, cache = ops.attention_eval(nhwc(perm).reshape(B, P, 3 * C), B, m, rb, cache, True, P)
         q, k, v = O._split_qkv(a, m)
         q, k, v = (z.reshape(B, 1, m, P, 64).permute(0, 2, 1, 3, 4) for z in (q, k, v))
         rk, rv = torch.cat([rk, k], 2), torch.cat([rv, v], 2)
