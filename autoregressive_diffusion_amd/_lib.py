@@ -61,7 +61,7 @@ class AttnArgs(C.Structure):
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
                 ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("pad_", c_int32),
                 ("sched", c_void_p), ("sched_wgs", c_int32), ("sched_slots", c_int32), ("v_bstride", c_int64),
-                ("k_bstride", c_int64)]
+                ("k_bstride", c_int64), ("split_ws", c_void_p), ("kv_splits", c_int32), ("pad2_", c_int32)]
 
 
 EPI_NONE, EPI_EMB_SILU, EPI_MPSUM = 0, 1, 2

@@ -149,10 +149,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int qwv = wave % QW, st = wave / QW, tis = tid % NTS;
-  const int nqb = gridDim.x;
+  // split-KV (decode of one frame against a long KV ring: Lq / 128 query blocks x heads x B workgroups is a handful):
+  // kv_splits workgroups share a query block, each walks a contiguous range of its key tiles and leaves an un-normalised
+  // partial (O, l) in split_ws; attn_split_reduce_kernel adds them (no running maximum here: partials simply add)
+  const int nsp = (MODE == 0 && KS == 1 && a.kv_splits > 1) ? a.kv_splits : 1;
+  const int nqb = gridDim.x / nsp;
   int bx_, head, b;
   attn_block_decode(bx_, head, b);
-  const int qbw = nqb - 1 - bx_;                   // heaviest (latest) query blocks first
+  const int sp = bx_ % nsp;
+  const int qbw = nqb - 1 - bx_ / nsp;             // heaviest (latest) query blocks first
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
   const int qw0 = qbw * (32 * QW) + qwv * 32;
   const int qrow = qw0 + r;
@@ -226,16 +231,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   };
 
   int bsel = 0;
-  if (st < nsub) issue(key_start(st), 0);
-  const int niter = (nsub + KS - 1) / KS;
+  const int sub0 = (int)((long long)nsub * sp / nsp), sub1 = (int)((long long)nsub * (sp + 1) / nsp);   // this split's tiles
+  if (sub0 + st < sub1) issue(key_start(sub0 + st), 0);
+  const int niter = (sub1 - sub0 + KS - 1) / KS;
 #pragma unroll 1
   for (int it = 0; it < niter; ++it) {
-    const int idx = it * KS + st;
-    const bool act = idx < nsub;
+    const int idx = sub0 + it * KS + st;
+    const bool act = idx < sub1;
     const int key0 = act ? key_start(idx) : 0;
     dma_wait();
     __syncthreads();                               // tile idx has landed for everybody; buffer bsel^1 is free again
-    if (idx + KS < nsub) issue(key_start(idx + KS), bsel ^ 1);
+    if (idx + KS < sub1) issue(key_start(idx + KS), bsel ^ 1);
     const unsigned char* Kt = smem + (st * 2 + bsel) * 2 * TB;
     const unsigned char* Vt = Kt + TB;
     bsel ^= 1;
@@ -309,6 +315,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   }
   if (qrow >= Lq) return;
   l += __shfl_xor(l, 32);                          // the other half of the keys of every tile lives in lane ^ 32
+  if (nsp > 1) {                                   // partial of this split: [split][b][head][q][64 channels | l] fp32
+    float* pw = a.split_ws + ((((size_t)sp * a.B + b) * a.heads + head) * Lq + qrow) * 65;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pw[dt * 32 + 8 * g + 4 * h + k] = o[dt][4 * g + k];
+    if (h == 0) pw[64] = l;
+    return;
+  }
   const float inv = (l > 0.f) ? 1.f / l : 0.f;
   bf16* og = (bf16*)a.out + ((size_t)b * Lq + qrow) * C + head * 64;
 #pragma unroll
@@ -322,6 +339,32 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
     }
   if (a.lse && h == 0) a.lse[(size_t)(b * a.heads + head) * Lq + qrow] = SOFTMAX_OFF + log2f(fmaxf(l, 1e-30f));
 #endif
+}
+
+// out[b][q][head*64 + c] = sum_s O_s / sum_s l_s over the kv_splits partials of attn_fwd_kernel (one thread per (b, head, q, 8 channels))
+__global__ void attn_split_reduce_kernel(const float* __restrict__ ws, bf16* __restrict__ out, float* __restrict__ lse, int nsp,
+                                         int B, int heads, int Lq, int C) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int part = (int)(gid & 7);
+  const long long row = gid >> 3;                  // (b * heads + head) * Lq + q
+  if (row >= (long long)B * heads * Lq) return;
+  const int q = (int)(row % Lq), head = (int)((row / Lq) % heads), b = (int)(row / ((long long)Lq * heads));
+  float acc[8], l = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+  const size_t plane = (size_t)B * heads * Lq * 65;
+  for (int s_ = 0; s_ < nsp; ++s_) {
+    const float* p = ws + (size_t)s_ * plane + (size_t)row * 65;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[i] += p[part * 8 + i];
+    l += p[64];
+  }
+  const float inv = (l > 0.f) ? 1.f / l : 0.f;
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = f2bf(acc[i] * inv);
+  *(bf16x8*)(out + ((size_t)b * Lq + q) * C + head * 64 + part * 8) = o;
+  if (lse && part == 0) lse[row] = SOFTMAX_OFF + log2f(fmaxf(l, 1e-30f));
 }
 
 #include "attention_ws.h"
@@ -1109,6 +1152,18 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
   }
   // two key streams per workgroup (64 query rows) when the key lists are long and causal, else one (128 rows)
   const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048 && d.a.pad_ == 0;
+  if (d.a.kv_splits > 1) {                           // split-KV decode: partials + reduction (two launches)
+    ONIRIS_CHECK_ARG(d.a.mask_mode == 0 && d.a.split_ws && d.a.kv_splits <= 256,
+                     "attn_fwd: kv_splits serves the dense (mask_mode 0) kernel and needs split_ws");
+    const dim3 gs(cdiv(d.a.Lq, 128) * d.a.kv_splits, d.a.heads, d.a.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<0, 1>), gs, dim3(256), 0, stream, d);
+    ONIRIS_LAUNCH_CHECK();
+    const long long nthr = (long long)d.a.B * d.a.heads * d.a.Lq * 8;
+    hipLaunchKernelGGL(attn_split_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+                       (const float*)d.a.split_ws, (bf16*)d.a.out, d.a.lse, d.a.kv_splits, d.a.B, d.a.heads, d.a.Lq, d.a.C);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
   const dim3 grid(cdiv(d.a.Lq, split ? 64 : 128), d.a.heads, d.a.B);
   if (split) {
     if (d.a.mask_mode == 1) hipLaunchKernelGGL((attn_fwd_kernel<1, 2>), grid, dim3(256), 0, stream, d);

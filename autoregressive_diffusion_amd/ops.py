@@ -1352,6 +1352,22 @@ class KVRing:
         return new
 
 
+DECODE_SPLIT_MIN_KEYS = int(_os.environ.get("ONIRIS_DECODE_SPLIT_MIN", "2048"))   # split-KV decode from this many keys on
+
+
+def _decode_splits(a, B, heads, Lq, Lk, dev):
+    """One new frame against a long KV ring: ceil(Lq / 128) * heads * B workgroups (4 at B = 1) would walk all keys serially
+    (~0.5 us per 64-key tile: 130 us per layer at 264 cached frames); deal the key tiles to kv_splits workgroups each."""
+    if Lk < DECODE_SPLIT_MIN_KEYS:
+        return
+    wgs = -(-Lq // 128) * heads * B
+    ns = max(1, min(64, Lk // 512, 512 // max(1, wgs)))
+    if ns > 1:
+        ws = torch.empty((ns, B, heads, Lq, 65), dtype=torch.float32, device=dev)
+        a.split_ws, a.kv_splits = _p(ws), ns
+        a._keep = ws                                # (keeps the workspace alive until the launch is queued)
+
+
 @torch.no_grad()
 def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     """Eval-mode VideoAttention core (attention_modules.py:51-77): qkv (B*t, P, 3C) of the NEW frames.
@@ -1382,6 +1398,7 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
         out = torch.empty((N, P, C), dtype=BF16, device=dev)
         a = _attn_args(q, ring.KR, ring.V, None, None, None, out, None, None, B, heads, P, nk * P, C, 0, P, 0)
         a.v_bstride = a.k_bstride = bstride
+        _decode_splits(a, B, heads, P, nk * P, dev)
         check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
         return out, new_cache
     check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(ring.K), _p(ring.V), N * P, C, t * P, bstride, n * P, _stream()), "qkv_norm")
@@ -1406,6 +1423,8 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
         raise NotImplementedError("The inference mask is not implemented for this case")
     a = _attn_args(qr, kr, ring.V, None, None, None, out, None, tabs, B, heads, Lq, Lk, C, mask_mode, P, 0)
     a.v_bstride = bstride
+    if t == 1:
+        _decode_splits(a, B, heads, Lq, Lk, dev)
     check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
     return out, new_cache
 

@@ -368,6 +368,11 @@ typedef struct OnirisAttnArgs {
   int32_t sched_wgs, sched_slots;
   int64_t v_bstride;                      /* elements between the sequences of v (a KV ring); 0 = Lk*C (forward only) */
   int64_t k_bstride;                      /* the same for k (the ring's rotated image)                                */
+  /* split-KV decode (oniris_attn_fwd, mask_mode 0, no schedule): kv_splits > 1 deals the key tiles of every query block to
+   * that many workgroups, which leave un-normalised partials (O, l) in split_ws [kv_splits][B][heads][Lq][65] fp32; a
+   * second kernel adds them and normalises (one new frame against a long KV ring would otherwise run on heads * B CUs)  */
+  float* split_ws;
+  int32_t kv_splits, pad2_;
 } OnirisAttnArgs;
 
 /* Static load balancing of block-sparse attention [host]: n_pairs (batch, head) pairs x n_blocks work items per pair
