@@ -118,7 +118,7 @@ def rollout(args):
     unet = UNet(**GYM_CFG).to(dev)
     torch.nn.init.constant_(unet.out_gain, 1.0)
     net = Precond(unet, sigma_data=1.0).to(dev).eval()
-    B, ctx_frames = args.batch, 8
+    B, ctx_frames = args.batch, args.ctx_frames
     with torch.no_grad():
         ctx = torch.randn(B, ctx_frames, 8, 64, 64, device=dev)
         lab = torch.randint(0, 4, (B, ctx_frames), device=dev)
@@ -202,6 +202,7 @@ def main():
     ap.add_argument("--mode", choices=["train", "rollout"], default="train",
                     help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
     ap.add_argument("--gen-frames", type=int, default=8)
+    ap.add_argument("--ctx-frames", type=int, default=8, help="rollout: frames of the prefill (+ 2 warm-up frames) before the timed ones")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--accum", type=int, default=1,
                     help="gradient accumulation as in the reference loops (gym_train.py:96-112, cs_train.py:105-127): the optimizer "
