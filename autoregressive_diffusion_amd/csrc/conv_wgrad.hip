@@ -243,11 +243,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradDev d) {
   bf16* slab = (bf16*)a.dwp + (size_t)bx * a.taps_total * a.CoutP * a.CinP;
 #pragma unroll
   for (int tap = 0; tap < TAPS; ++tap) {
-    bf16* base = slab + (size_t)(a.tap0 + tap) * a.CoutP * a.CinP;
+    bf16* base = slab + (size_t)(a.tap0 + tap) * a.CinP;               // slab layout [co][tap][ci]: a weight row is contiguous
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) {
       const int co = co0 + ct * 32 + mfma_row(rr, lane);
-      if (co < a.CoutP && cj < a.CinP) base[(size_t)co * a.CinP + cj] = f2bf(acc[tap][rr]);
+      if (co < a.CoutP && cj < a.CinP) base[(size_t)co * a.taps_total * a.CinP + cj] = f2bf(acc[tap][rr]);
     }
   }
 }

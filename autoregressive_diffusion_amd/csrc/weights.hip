@@ -130,7 +130,8 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
   const int nsp = d->nsplit ? *d->nsplit : 1;
   if (nsp <= 0) return;                                         // no wgrad ran for this weight in this step
   const size_t slab = (size_t)taps * d->CoutP * d->CinP;
-  // pass 1 (packed order: ci contiguous -> coalesced slab reads): G = fp32 sum over the bf16 split-K slabs, kept in dws
+  // pass 1 (slab layout [co][tap][ci]: the row of this workgroup is ONE contiguous run of taps * CinP values per slab): G = fp32
+  // sum over the bf16 split-K slabs, kept in dws
   float dot = 0.f, nn = 0.f;
   if ((cin & 7) == 0) {
     // 16 bytes (8 slab values) per lane and up to 8 independent slab reads in flight (a thread with 4-byte loads and 4
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
     const int c8 = cin >> 3, items = taps * c8;
     for (int it = threadIdx.x; it < items; it += 256) {
       const int tap = it / c8, ci = (it - tap * c8) * 8;
-      const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
+      const size_t pi = ((size_t)cop * taps + tap) * d->CinP + ci;
       float G[4][8];
 #pragma unroll
       for (int u = 0; u < 4; ++u)
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
   } else
   for (int q = threadIdx.x; q < fan; q += 256) {
     const int tap = q / cin, ci = q - tap * cin;
-    const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
+    const size_t pi = ((size_t)cop * taps + tap) * d->CinP + ci;
     float G0 = 0.f, G1 = 0.f, G2 = 0.f, G3 = 0.f;            // 4 independent load chains (HBM latency)
     int s_ = 0;
     for (; s_ + 3 < nsp; s_ += 4) {
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
   const float k2 = (n > 0.f) ? c * dot * rs / (s * s * n) : 0.f;
   for (int q = threadIdx.x; q < fan; q += 256) {
     const int tap = q / cin, ci = q - tap * cin;
-    const size_t pi = ((size_t)tap * d->CoutP + cop) * d->CinP + ci;
+    const size_t pi = ((size_t)cop * taps + tap) * d->CinP + ci;
     const int e = ci * taps + tap;
     g[e] += k1 * dws[pi] - k2 * w[e];
   }

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256 * NG, NG) void wgrad1x1_glds_kernel(const Wgrad
       }
     if (kg != 0) return;
   }
-  bf16* slab = (bf16*)a.dwp + (size_t)bx * a.taps_total * a.CoutP * a.CinP + (size_t)a.tap0 * a.CoutP * a.CinP;
+  bf16* slab = (bf16*)a.dwp + (size_t)bx * a.taps_total * a.CoutP * a.CinP + (size_t)a.tap0 * a.CinP;   // [co][tap][ci]
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256 * NG, NG) void wgrad1x1_glds_kernel(const Wgrad
 #pragma unroll
       for (int rr = 0; rr < 16; ++rr) {
         const int co = co0 + wr * 64 + m * 32 + mfma_row(rr, lane);
-        if (co < a.CoutP && cj < a.CinP) slab[(size_t)co * a.CinP + cj] = f2bf(acc[m][n][rr]);
+        if (co < a.CoutP && cj < a.CinP) slab[(size_t)co * a.taps_total * a.CinP + cj] = f2bf(acc[m][n][rr]);
       }
     }
 #endif

@@ -60,10 +60,10 @@ typedef struct OnirisWeightDesc {
   float* grad;     /* fp32 gradient, same shape; oniris_weight_bwd ACCUMULATES into it                           */
   void* wf;        /* bf16 packed forward weight  [taps][CoutP][CinP]   (ci contiguous)                          */
   void* wb;        /* bf16 packed dgrad weight    [taps][CoutPb][CinPb] = flipped/transposed copy (may be NULL)  */
-  void* dwp;       /* bf16 split-K slabs [nsplit_cap][taps][CoutP][CinP]: oniris_conv_wgrad workgroup column s   *
+  void* dwp;       /* bf16 split-K slabs [nsplit_cap][CoutP][taps][CinP]: oniris_conv_wgrad workgroup column s   *
                     * overwrites slab s with plain stores (its fp32 partial sum rounded once); oniris_weight_bwd  *
                     * adds the first *nsplit slabs in fp32                                                         */
-  float* dws;      /* fp32 [taps][CoutP][CinP]: the sum of the slabs (scratch of oniris_weight_bwd)               */
+  float* dws;      /* fp32 [CoutP][taps][CinP]: the sum of the slabs (scratch of oniris_weight_bwd)               */
   int32_t cout, cin, taps, kt;     /* taps = kt*kh*kw (1, 9 or 18); kt = temporal taps (1 or 2)                  */
   int32_t CoutP, CinP;             /* CoutP = roundup(cout,32), CinP = roundup(cin,64)                           */
   int32_t CoutPb, CinPb;           /* CoutPb = roundup(cin,32), CinPb = roundup(cout,64)                         */
@@ -221,7 +221,7 @@ typedef struct OnirisConvArgs {
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);
 
 /* Weight gradient of the same operator (replaces the autograd of F.conv2d / F.conv3d wrt the weight):
- *   slab[s][tap0+tap][co][ci] = sum_{(n,p) in split s} scale[n] * dy[n][p][co] * xframe(n)[p + tap][ci]
+ *   slab[s][co][tap0+tap][ci] = sum_{(n,p) in split s} scale[n] * dy[n][p][co] * xframe(n)[p + tap][ci]
  * Split-K over position tiles: workgroup column s (gridDim.x = *nsplit_out <= nsplit_cap) owns slab s and writes
  * it with plain stores (no fp32 atomics: those run at ~1.3 TB/s chip-wide and dominated the first version).
  * path 0: xframe(n) = x[n] for all B*S*T frames.  path 1+j: frames n = (b,t), xframe = ctxframe(b, t+coff[j]),
@@ -229,7 +229,7 @@ int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t str
 typedef struct OnirisWgradArgs {
   const void* x;          /* bf16 input frames   [B*xb_stride][H][W][Cin]                                         */
   const void* dy;         /* bf16 output grads   [B*T][H][W][Cout]                                                */
-  void* dwp;              /* bf16 slabs [nsplit_cap][taps_total][CoutP][CinP]                                      */
+  void* dwp;              /* bf16 slabs [nsplit_cap][CoutP][taps_total][CinP]                                      */
   const float* scale;     /* [B*T] or NULL                                                                        */
   int32_t B, T, H, W, Cin, CinP, Cout, CoutP, taps;
   int32_t xb_stride, x_T, coff;   /* xframe(b,t) = x[b*xb_stride + t + coff] if 0 <= t+coff < x_T else fill       */

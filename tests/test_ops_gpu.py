@@ -67,8 +67,8 @@ def test_weight_prep_and_bwd(shape):
     assert rel(wb, refb) < 5e-3, "packed dgrad weight (flipped, transposed)"
     # backward: random packed gradient
     G = bfr(torch.randn(cout, cin, taps))               # (the split-K slabs are bf16: power-of-two multiples are exact)
-    dwp = torch.zeros(taps, pw.CoutP, pw.CinP)          # two split-K slabs: 0.5*G + 1.5*G = 2*G
-    dwp[:, :cout, :cin] = G.permute(2, 0, 1)
+    dwp = torch.zeros(pw.CoutP, taps, pw.CinP)          # two split-K slabs [co][tap][ci]: 0.5*G + 1.5*G = 2*G
+    dwp[:cout, :, :cin] = G.permute(0, 2, 1)
     assert pw.nsplit_cap >= 2 and pw.dwp.dtype == torch.bfloat16
     pw.dwp[:dwp.numel()].copy_(0.5 * dwp.reshape(-1))
     pw.dwp[dwp.numel():2 * dwp.numel()].copy_(bfr(1.5 * dwp.reshape(-1)))
