@@ -25,17 +25,24 @@ class _AttentionBase(nn.Module):
         self.attn_qkv.weight.perm3 = True          # packed rows (m c s) -> (s m c): q | k | v contiguous
         self.attn_proj = MPConv(channels, channels, kernel=[1, 1])
 
-    def _proj(self, x, o, clip):
+    def _proj(self, x, o, clip, slot=None):
         t = self.attn_balance
         den = 1.0 / math.sqrt((1 - t) ** 2 + t ** 2)
         # proj conv with fused epilogue  out = clip((1-t)/den' * x + t/den' * conv(o))
-        return self.attn_proj._cl(o, res=x, ta=(1 - t) * den, tb=t * den, clip=clip)
+        return self.attn_proj._cl(o, res=x, ta=(1 - t) * den, tb=t * den, clip=clip, res_slot=slot)
+
+    @staticmethod
+    def _slot(x):
+        """x has two consumers here (attn_qkv and the residual of attn_proj).  The residual gradient comes first in
+        backward: it is parked in a GradSlot and the qkv dgrad adds it in its epilogue (no torch add of the two)."""
+        return ops.GradSlot() if (torch.is_grad_enabled() and x.requires_grad) else None
 
     def _frame_cl(self, x, clip):
         N, H, W, C = x.shape
-        qkv = self.attn_qkv._cl(x).reshape(N, H * W, 3 * C)
+        slot = self._slot(x)
+        qkv = self.attn_qkv._cl(x, in_slot=slot).reshape(N, H * W, 3 * C)
         o = ops.attention_train(qkv, "frame", N, 1, self.num_heads)
-        return self._proj(x, o.reshape(N, H, W, C), clip)
+        return self._proj(x, o.reshape(N, H, W, C), clip, slot)
 
 
 class VideoAttention(_AttentionBase):
@@ -55,14 +62,15 @@ class VideoAttention(_AttentionBase):
         N, H, W, C = x.shape
         P = H * W
         self.__dict__["_tokens_per_frame"] = P               # (UNet.prewarm_eval sizes the next RoPE table from it)
-        qkv = self.attn_qkv._cl(x).reshape(N, P, 3 * C)
+        slot = self._slot(x)
+        qkv = self.attn_qkv._cl(x, in_slot=slot).reshape(N, P, 3 * C)
         rope_bufs = (self.rope.inv_freq, self.rope.scale)
         if self.training:
             T = N // (2 * batch_size)
             o = ops.attention_train(qkv, "video", batch_size, T, self.num_heads, rope_bufs)
         else:
             o, cache = ops.attention_eval(qkv, batch_size, self.num_heads, rope_bufs, cache, update_cache, P)
-        return self._proj(x, o.reshape(N, H, W, C), clip), cache
+        return self._proj(x, o.reshape(N, H, W, C), clip, slot), cache
 
     def forward(self, x, batch_size, cache=None, update_cache=False, just_2d=False):
         if self.num_heads == 0:

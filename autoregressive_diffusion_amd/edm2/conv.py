@@ -68,8 +68,8 @@ class MPConv(nn.Module):
         self.weight = NormalizedWeight(in_channels, out_channels, kernel)
         assert dilation == 1
 
-    def _cl(self, x, res=None, ta=0.0, tb=0.0, clip=0.0, in_slot=None):
-        return ops.conv(x, self.weight.pw, res, ta, tb, clip, in_slot=in_slot)
+    def _cl(self, x, res=None, ta=0.0, tb=0.0, clip=0.0, in_slot=None, res_slot=None):
+        return ops.conv(x, self.weight.pw, res, ta, tb, clip, in_slot=in_slot, res_slot=res_slot)
 
     def forward(self, x, gain=1):
         with weights_ready(self):

@@ -55,7 +55,7 @@ class Block(nn.Module):
         elif skip is not None:
             x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True, in_slot=in_slot, skip_slot=skip_slot)   # x <- mp_cat(x, skip); a = mp_silu(x)
         else:
-            a = ops.act(x, in_slot=in_slot)
+            x, a = ops.act(x, want_xo=True, in_slot=in_slot)               # x comes back as an alias of itself (see _ActFn)
         N = x.shape[0]
         if c is None:          # (the UNet hands in all of its blocks' scales from one grouped GEMM: ops.emb_scales)
             c = (self.emb_linear._cl(emb).reshape(N, -1).float() * self.emb_gain + 1)      # (N, Cout) fp32

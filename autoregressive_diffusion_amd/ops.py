@@ -587,12 +587,14 @@ def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb
 
 class ConvCfg:
     """Static configuration of one conv op (not a tensor: passed through autograd untouched)."""
-    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad", "in_slot")
+    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad", "in_slot", "res_slot")
 
-    def __init__(self, pw2, pw3=None, B=1, T=1, epi="none", ta=0.0, tb=0.0, clip=0.0, need_grad=True, in_slot=None):
+    def __init__(self, pw2, pw3=None, B=1, T=1, epi="none", ta=0.0, tb=0.0, clip=0.0, need_grad=True, in_slot=None,
+                 res_slot=None):
         self.pw2, self.pw3, self.B, self.T = pw2, pw3, B, T
         self.epi, self.ta, self.tb, self.clip, self.need_grad = epi, ta, tb, clip, need_grad
         self.in_slot = in_slot             # GradSlot of the input (plain convs): a second gradient of x joins in the dgrad epilogue
+        self.res_slot = res_slot           # GradSlot that receives the gradient of `res` (mp_sum epilogue) instead of autograd
 
 
 def _rows_f32(t):
@@ -730,6 +732,9 @@ class _ConvOp(torch.autograd.Function):
                 _wgrad_launch(x, dout, pw2, None, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
         if pw2.param.requires_grad or (gated and pw3.param.requires_grad):
             pw2.bank.request_finish()
+        if cfg.res_slot is not None and dres is not None:
+            cfg.res_slot.put(dres)                   # joins the other gradient of `res` inside that consumer's kernel
+            dres = None
         return dx, None, None, dca, dcb, dcs, dres, None
 
 
@@ -751,11 +756,12 @@ def gate_coefs(gate):
     return (1 - gate) * den, gate * den
 
 
-def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None):
+def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None, res_slot=None):
     """MPConv forward on packed weights.  Optional fused epilogues: res -> clip(ta*res + tb*conv(x));
-    cscale (N,Cout) fp32 -> silu(conv(x)*cscale)/0.596.  in_slot: GradSlot of x."""
+    cscale (N,Cout) fp32 -> silu(conv(x)*cscale)/0.596.  in_slot: GradSlot of x; res_slot: GradSlot that takes d res."""
     epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
-    cfg = ConvCfg(pw, None, epi=epi, ta=ta, tb=tb, clip=clip, need_grad=torch.is_grad_enabled(), in_slot=in_slot)
+    cfg = ConvCfg(pw, None, epi=epi, ta=ta, tb=tb, clip=clip, need_grad=torch.is_grad_enabled(), in_slot=in_slot,
+                  res_slot=res_slot)
     return _ConvOp.apply(x, pw.param, None, None, None, cscale, res, cfg)
 
 
@@ -826,7 +832,11 @@ class _ActFn(torch.autograd.Function):
         npix = x.numel() // C1
         shape = (*x.shape[:-1], C1 + C2)
         a = torch.empty(shape, dtype=BF16, device=x.device)
-        xo = torch.empty(shape, dtype=BF16, device=x.device) if (want_xo or norm) else None
+        # want_xo without norm / cat: xo IS x -- the input itself is handed back (autograd aliases it), so that a tensor
+        # with two consumers (the activation and the residual / skip-conv path of a Block) reaches this node's backward
+        # as (dxo, da) and the two gradients are added inside act_bwd instead of by a torch add over three tensors
+        alias = want_xo and not norm and skip is None and x.is_contiguous()
+        xo = torch.empty(shape, dtype=BF16, device=x.device) if ((want_xo or norm) and not alias) else None
         sden = torch.empty(npix, dtype=torch.float32, device=x.device) if norm else None
         x = x.contiguous()
         skip = skip.contiguous() if skip is not None else None
@@ -836,6 +846,8 @@ class _ActFn(torch.autograd.Function):
         ctx.slots = (in_slot, skip_slot)
         # without norm/cat xo would just be x itself: reuse the input for the silu' evaluation
         ctx.save_for_backward(xo if xo is not None else x, sden)
+        if alias:
+            return x, a
         if want_xo or norm:
             return xo, a
         return a
