@@ -86,7 +86,7 @@ _SIGS = {
                                       c_float, c_void_p]),
     "oniris_sqnorm": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "oniris_dart_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_float, c_void_p]),
+                                  c_float, c_void_p, c_void_p]),
     "oniris_dart_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_float, c_void_p]),
     "oniris_dart_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
@@ -116,6 +116,8 @@ _SIGS = {
                                          c_int, c_int, c_int, c_void_p]),
     "oniris_precond_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p]),
+    "oniris_sampler_update": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,
+                                      c_void_p, c_int, c_float, c_void_p]),
     "oniris_embed_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                   c_int, c_void_p]),
     "oniris_gates": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

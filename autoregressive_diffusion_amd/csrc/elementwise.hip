@@ -330,9 +330,10 @@ extern "C" int oniris_resample(const void* in, void* out, const void* add, int64
 //   dart_loss_bwd: dF (bf16, zero for the clean slots) and per-frame partial sums of d out_gain
 __global__ __launch_bounds__(256) void dart_input_kernel(const float* __restrict__ img, const float* __restrict__ noise,
                                                          const float* __restrict__ sigma, bf16* __restrict__ xcl, int S,
-                                                         int T, int C, int HW, float sd) {
+                                                         int T, int C, int HW, float sd, float* __restrict__ c_noise_out) {
   const int n = blockIdx.y, b = n / (S * T), st = n % (S * T), t = st % T;
   const float sg = sigma[b * S * T + st];
+  if (c_noise_out && blockIdx.x == 0 && threadIdx.x == 0) c_noise_out[n] = logf(sg) / 4.f;     // c_noise (networks_edm2.py:291)
   const float cin = 1.f / sqrtf(sd * sd + sg * sg);
   const float* ip = img + (size_t)(b * T + t) * C * HW;
   const bool has_noise = noise != nullptr;        // NULL: no noise term (Precond's input side in eval)
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(256) void dart_loss_kernel(const bf16* __restrict__
 }
 
 extern "C" int oniris_dart_input(const float* images, const float* noise, const float* sigma, void* xcl, int B, int S,
-                                 int T, int C, int H, int W, float sigma_data, oniris_stream_t stream_) {
+                                 int T, int C, int H, int W, float sigma_data, float* c_noise_out, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(images && sigma && xcl && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 && C < 16 && H > 0 && W > 0,
                    "dart_input: bad arguments");
@@ -411,7 +412,7 @@ extern "C" int oniris_dart_input(const float* images, const float* noise, const 
   int gx = cdiv(HW, 256);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(dart_input_kernel, dim3(gx, B * S * T), dim3(256), 0, stream, images, noise, sigma, (bf16*)xcl, S, T, C,
-                     HW, sigma_data);
+                     HW, sigma_data, c_noise_out);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -527,6 +528,47 @@ extern "C" int oniris_precond_out(const void* F, const float* x, const float* si
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(precond_out_kernel, dim3(gx, N), dim3(256), 0, stream, (const bf16*)F, x, sigma, out_gain, D, C, H * W,
                      sigma_data);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// The sampler's update between two UNet evaluations (edm2/sampler.py:66-76 of the reference) in one launch, fp32:
+//   mode 0 (Euler):  d = (x_hat - x_pred) / t_a ;  x_out = x_hat + dt * d ;  d_io <- d
+//   mode 1 (Heun):   d' = (x_aux - x_pred) / t_a ; x_out = x_hat <- x_hat + dt * (0.5 * d_io + 0.5 * d')
+// (same operations in the same order as the reference's tensor expressions).  sigma_buf (nsig floats, optional) receives
+// the NEXT evaluation's sigma, so the graph replay that follows needs no fill kernel of its own.
+__global__ __launch_bounds__(256) void sampler_update_kernel(int mode, float* x_hat, const float* __restrict__ x_pred,
+                                                             float* __restrict__ d_io, const float* x_aux,   // (x_aux, x_out, x_hat
+                                                             float* x_out, size_t n, float t_a, float dt,     //  may be one buffer)
+                                                             float* __restrict__ sigma_buf, int nsig, float sigma_next) {
+#pragma clang fp contract(off)     // every product and sum is rounded on its own, like the separate tensor operations
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (sigma_buf && i < (size_t)nsig) sigma_buf[i] = sigma_next;
+  if (i >= n) return;
+  const float xh = x_hat[i];
+  if (mode == 0) {
+    const float d = (xh - x_pred[i]) / t_a;
+    d_io[i] = d;
+    const float s_ = dt * d;
+    x_out[i] = xh + s_;
+  } else {
+    const float dp = (x_aux[i] - x_pred[i]) / t_a;
+    const float a_ = 0.5f * d_io[i], b_ = 0.5f * dp;
+    const float m_ = dt * (a_ + b_);
+    const float xn = xh + m_;
+    x_hat[i] = xn;
+    if (x_out != x_hat) x_out[i] = xn;
+  }
+}
+
+extern "C" int oniris_sampler_update(int mode, float* x_hat, const float* x_pred, float* d_io, const float* x_aux, float* x_out,
+                                     size_t n, float t_a, float dt, float* sigma_buf, int nsig, float sigma_next,
+                                     oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG((mode == 0 || mode == 1) && x_hat && x_pred && d_io && x_out && n > 0 && t_a != 0.f && (mode == 0 || x_aux) &&
+                   nsig >= 0 && (size_t)nsig <= n, "sampler_update: bad arguments");
+  hipLaunchKernelGGL(sampler_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mode, x_hat, x_pred, d_io,
+                     x_aux, x_out, n, t_a, dt, sigma_buf, nsig, sigma_next);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

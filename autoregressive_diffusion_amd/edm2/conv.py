@@ -89,6 +89,9 @@ class MPConv(nn.Module):
         self.weight.weight.copy_(state_dict)
 
 
+DEFER_CACHE_SHIFT = [False]         # set by edm2/sampler.py around the capture of a frame's evaluation graph
+
+
 class Gating(nn.Module):
     """edm2/conv.py:104-127 (tiny, fp32, stays in torch autograd)."""
 
@@ -120,9 +123,12 @@ def nctx_tensor(n_ctx, dev):
     evaluates the net 31 times per frame; cached so that the evaluation is hipGraph-capturable)."""
     key = (tuple(n_ctx), str(dev))
     if key not in _nctx_cache:
+        prev = _nctx_cache.get((tuple(n - 1 for n in n_ctx), str(dev)))
         if len(_nctx_cache) > 64:
             _nctx_cache.clear()
-        _nctx_cache[key] = torch.tensor(list(n_ctx), device=dev).reshape(-1, 1, 1)
+        # a rollout bumps every counter by one per generated frame: derive the vector on the device (an upload from
+        # pageable memory would wait for everything queued on the stream -- the previous frame's 31 evaluations)
+        _nctx_cache[key] = prev + 1 if prev is not None else torch.tensor(list(n_ctx), device=dev).reshape(-1, 1, 1)
     return _nctx_cache[key]
 
 
@@ -152,9 +158,10 @@ _nctx_i32_cache = {}
 def _nctx_i32(n_ctx, dev):
     key = (tuple(n_ctx), str(dev))
     if key not in _nctx_i32_cache:
+        prev = _nctx_i32_cache.get((tuple(n - 1 for n in n_ctx), str(dev)))
         if len(_nctx_i32_cache) > 64:
             _nctx_i32_cache.clear()
-        _nctx_i32_cache[key] = torch.tensor(list(n_ctx), dtype=torch.int32, device=dev)
+        _nctx_i32_cache[key] = prev + 1 if prev is not None else torch.tensor(list(n_ctx), dtype=torch.int32, device=dev)
     return _nctx_i32_cache[key]
 
 
@@ -230,7 +237,12 @@ class MPCausal3DGatedConv(nn.Module):
         if pad is None:
             pad = torch.ones(batch_size, 2, H, W, C, dtype=BF16, device=x.device)
         if t == 1:              # one generated frame (the sampler's 31 evaluations): its context IS the cached pair
-            if update_cache:
+            if update_cache and DEFER_CACHE_SHIFT[0]:
+                # captured evaluation of the sampler's frame graph: the shifted pair is built once, after the frame's last
+                # replay (sampler.finish_cache), from the old pair and this layer's input -- not by every replay
+                cache["activations"] = pad
+                cache["_pending_frame"] = x.reshape(batch_size, 1, H, W, C)
+            elif update_cache:
                 cache["activations"] = torch.cat([pad[:, 1:], x.reshape(batch_size, 1, H, W, C)], dim=1)
             return ops.gated_conv_eval(x, gate, pw2, pw3, batch_size, 1, pad.contiguous(), coefs, ctx_T=2, **epi), cache
         ctx = torch.cat([pad, x.reshape(batch_size, t, H, W, C)], dim=1).contiguous()

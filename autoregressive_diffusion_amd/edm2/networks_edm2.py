@@ -315,6 +315,9 @@ class UNet(BetterModule):
             nctx_tensor(n_ctx, dev)
             _nctx_i32(n_ctx, dev)
         _packed_gate_params(convs, dev)
+        eb, groups = self.__dict__.get("_oniris_emb_blocks"), self.__dict__.get("_oniris_groups")
+        if eb is not None and groups:
+            ops.eval_gain_vector(groups[0], eb[1])                 # (cached outside the capture, see there)
         for side, blocks in (("enc", self.enc), ("dec", self.dec)):
             for name, block in blocks.items():
                 att = getattr(block, "attn", None)
@@ -416,8 +419,8 @@ class Precond(BetterModule):
             # instead of ~25 tiny torch launches -- c_in * x packed channels-last with the ones channel, and
             # D = c_skip * x + c_out * out_gain * F read straight from the raw channels-last output
             sg = sigma.to(torch.float32).contiguous()
-            xcl = ops.dart_input(x, None, sg, 1, self.sigma_data)
-            Fcl, cache = self.unet.forward(xcl, sg.log() / 4, conditioning, cache, update_cache, just_2d,
+            xcl, c_noise = ops.dart_input(x, None, sg, 1, self.sigma_data, want_c_noise=True)
+            Fcl, cache = self.unet.forward(xcl, c_noise, conditioning, cache, update_cache, just_2d,
                                            _cl_io=tuple(x.shape[:2]))
             return ops.precond_out(Fcl, x, sg, self.unet.out_gain, self.sigma_data), cache
         sigma = sigma.to(torch.float32)[:, :, None, None, None]

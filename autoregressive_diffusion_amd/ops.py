@@ -134,7 +134,7 @@ def attn_schedule(weights, n_pairs, device, n_wg=None):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched", "embcache")
+                 "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched", "embcache", "gaincache")
 
 
 def _nsplit_cap(cin, cout, taps):
@@ -385,7 +385,7 @@ class KernelProfile:
     """Optional per-launch HIP-event timing of the MFMA kernels (bench.py's roofline leg), on the stream the kernel is
     launched on (torch's current stream): see _timed_launch."""
     enabled = False
-    records = []          # (key, algorithmic flops, start_event, end_event)
+    records = []          # (key, algorithmic flops, start_event, end_event[, algorithmic HBM bytes])
 
     @classmethod
     def start(cls):
@@ -396,11 +396,12 @@ class KernelProfile:
         cls.enabled = False
         torch.cuda.synchronize()
         agg = {}
-        for key, flops, e0, e1 in cls.records:
-            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0))
+        for key, flops, e0, e1, *rest in cls.records:
+            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
             a["launches"] += 1
             a["flops"] += flops
             a["ms"] += e0.elapsed_time(e1)
+            a["bytes"] += rest[0] if rest else 0.0
         cls.records = []
         return agg
 
@@ -478,7 +479,15 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
                                                         emb_gain, out2, ta, tb, clip, ctx_out))
         finally:
             KernelProfile.enabled = True
-        KernelProfile.records.append((key, flops, e0, e1))
+        # algorithmic HBM bytes of the launch (every operand read once, every result written once; the context
+        # frames of a training launch are frames of x itself and are not counted twice)
+        px = B * T * H * W
+        nbytes = 2.0 * (S * px * Cin + S * px * Cout * (1 + (out2 is not None) + (res is not None))
+                        + (px * Cout if ctx_out is not None else 0)
+                        + taps * CoutP * CinP * (3 if ctx is not None else 1))
+        if ctx is not None and ctx.data_ptr() != x.data_ptr():
+            nbytes += 2.0 * B * ctx_T * H * W * Cin
+        KernelProfile.records.append((key, flops, e0, e1, nbytes))
         return
     a = _lib.ConvArgs()
     a.x, a.ctx, a.w_own, a.w_ctx, a.out = _p(x), _p(ctx), _p(w_own), _p(w_ctx), _p(out)
@@ -796,6 +805,18 @@ def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, t
     return ret
 
 
+def sampler_update(mode, x_hat, x_pred, d_io, x_aux, x_out, t_a, dt, sigma_buf=None, sigma_next=0.0):
+    """One launch for the sampler's update between two UNet evaluations (reference edm2/sampler.py:66-76), fp32 tensors
+    of one shape: mode 0 (Euler) d_io = (x_hat - x_pred)/t_a, x_out = x_hat + dt*d_io; mode 1 (Heun) x_hat = x_out =
+    x_hat + dt*(0.5*d_io + 0.5*(x_aux - x_pred)/t_a).  sigma_buf (optional, fp32): filled with sigma_next."""
+    _need_gpu(x_hat)
+    for t in (x_hat, x_pred, d_io, x_out) + ((x_aux,) if x_aux is not None else ()):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.numel() == x_hat.numel()
+    check(lib.oniris_sampler_update(mode, _p(x_hat), _p(x_pred), _p(d_io), _p(x_aux), _p(x_out), x_hat.numel(), float(t_a),
+                                    float(dt), _p(sigma_buf), sigma_buf.numel() if sigma_buf is not None else 0,
+                                    float(sigma_next), _stream()), "sampler_update")
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # fused magnitude-preserving glue (HBM-bound single-pass kernels, csrc/elementwise.hip)
 
@@ -1099,6 +1120,20 @@ def gates_train(c_noise, params, nctx, T, sink=None, anchor=None):
     return _GatesFn.apply(c_noise, params, nctx, T, sink, anchor)
 
 
+def eval_gain_vector(gpw, gains):
+    """The emb_gain parameters as one fp32 vector for the eval path (31 evaluations per generated frame): rebuilt only when
+    a parameter changed (torch writes bump ._version, the raw-pointer optimizer bumps _weights_epoch).  Inside a hipGraph
+    capture nothing is cached (the tensor would live in the graph's memory): UNet.prewarm_eval fills the cache before."""
+    sig = (_weights_epoch, tuple(x._version for x in gains), tuple(x.data_ptr() for x in gains))
+    hit = getattr(gpw, "gaincache", None)
+    if hit is not None and hit[0] == sig:
+        return hit[1]
+    g = torch.cat([x.reshape(1) for x in gains]).float()
+    if not (g.is_cuda and torch.cuda.is_current_stream_capturing()):
+        gpw.gaincache = (sig, g)
+    return g
+
+
 def emb_scales(emb, gpw, gains):
     """All `c = emb_linear(emb) * emb_gain + 1` of a UNet (networks_edm2.py:78 in every Block) at once:
     emb (N,1,1,Cemb) bf16, gpw the row-concatenated emb_linear group (WeightBank.add_group), gains the emb_gain
@@ -1127,6 +1162,8 @@ def emb_scales(emb, gpw, gains):
         pack = direct_pack(gains, gpw, "_gain_pack") if torch.is_grad_enabled() else None
         if pack is not None:
             g = pack.values()
+        elif not torch.is_grad_enabled():
+            g = eval_gain_vector(gpw, gains)
         else:
             g = torch.cat([x.reshape(1) for x in gains])
             if g.dtype != torch.float32:
@@ -1149,18 +1186,28 @@ _rope_cache = {}
 
 def rope_tables(inv_freq, scale_vec, n_pos, device, scale_base=64):
     """fp32 cos/sin/scale tables (n_pos, 64) built from fp16-ROUNDED angles and scales exactly like
-    RotaryEmbedding.make_rotary_embedding (RoPe.py:21-32: the fp16 rounding is part of the numerical spec)."""
-    key = (n_pos, str(device), inv_freq.data_ptr(), scale_vec.data_ptr())
-    if key not in _rope_cache:
+    RotaryEmbedding.make_rotary_embedding (RoPe.py:21-32: the fp16 rounding is part of the numerical spec).
+    The three are row ranges of MASTER tables kept per RotaryEmbedding: cos / sin of position t do not depend on n_pos,
+    and the xPos scale of position t is scale**((t - n_pos // 2) / scale_base), a function of the integer t - n_pos // 2
+    only -- so a rollout, whose key count grows by one per generated frame, uploads nothing per frame (a host->device
+    copy from pageable memory waits for everything queued on the stream: it used to stall the host once per frame and
+    layer, with the previous frame's 31 evaluations still in the queue)."""
+    key = (str(device), inv_freq.data_ptr(), scale_vec.data_ptr(), scale_base)
+    m = _rope_cache.get(key)
+    if m is None or m[0] < n_pos:
+        cap = max(64, 2 * n_pos, 2 * (m[0] if m is not None else 0))
         inv, sv = inv_freq.detach().float().cpu(), scale_vec.detach().float().cpu()
-        t = torch.arange(n_pos, dtype=torch.float32)
+        t = torch.arange(cap, dtype=torch.float32)
         ang = torch.outer(t, inv)
         ang = torch.cat([ang, ang], -1).to(torch.float16)
-        power = (t - (n_pos // 2)) / scale_base
+        d0 = cap // 2                                              # row r of the scale master <-> offset t - n_pos//2 = r - d0
+        power = (torch.arange(-d0, cap, dtype=torch.float32)) / scale_base
         sc = sv[None, :] ** power[:, None]
         sc = torch.cat([sc, sc], -1).to(torch.float16)
-        _rope_cache[key] = tuple(z.float().contiguous().to(device) for z in (ang.cos(), ang.sin(), sc))
-    return _rope_cache[key]
+        m = _rope_cache[key] = (cap, d0) + tuple(z.float().contiguous().to(device) for z in (ang.cos(), ang.sin(), sc))
+    _, d0, cos, sin, sc = m
+    off = d0 - n_pos // 2
+    return cos[:n_pos], sin[:n_pos], sc[off:off + n_pos]
 
 
 def _rope(x, xr, xt, tabs, mode, B, frames, P, C, pos_offset, pos_mod, x_bstride=0, xr_bstride=0):
@@ -1444,15 +1491,17 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
 # ------------------------------------------------------------------------------------------------------------------
 # optimizer
 
-def dart_input(images, noise, sigma, S, sigma_data):
+def dart_input(images, noise, sigma, S, sigma_data, want_c_noise=False):
     """Packed UNet input of a DART training step (oniris_dart_input): images (B,T,C,H,W), noise (B,S*T,C,H,W), sigma
-    (B,S*T) fp32 -> (B*S*T, H, W, 16) bf16 = c_in * (images + sigma*noise) with the ones channel."""
+    (B,S*T) fp32 -> (B*S*T, H, W, 16) bf16 = c_in * (images + sigma*noise) with the ones channel.
+    want_c_noise: also return c_noise = log(sigma)/4 like sigma (networks_edm2.py:291), from the same launch."""
     _need_gpu(images, noise, sigma)                 # (noise None: c_in * images, Precond's input side in eval)
     B, T, C, H, W = images.shape
     xcl = torch.empty((B * S * T, H, W, 16), dtype=BF16, device=images.device)
-    check(lib.oniris_dart_input(_p(images), _p(noise), _p(sigma), _p(xcl), B, S, T, C, H, W, float(sigma_data), _stream()),
-          "dart_input")
-    return xcl
+    cn = torch.empty((B, S * T), dtype=torch.float32, device=images.device) if want_c_noise else None
+    check(lib.oniris_dart_input(_p(images), _p(noise), _p(sigma), _p(xcl), B, S, T, C, H, W, float(sigma_data), _p(cn),
+                                _stream()), "dart_input")
+    return (xcl, cn) if want_c_noise else xcl
 
 
 @torch.no_grad()

@@ -415,7 +415,9 @@ def main():
         achieved = v["flops"] / (v["ms"] * 1e-3)
         roof = dict(bound="mfma", kernel=dom, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
                     flops_per_launch=v["flops"] / v["launches"], achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12,
-                    unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=_pmc_traffic(dom))
+                    unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=_pmc_traffic(dom),
+                    # operands read once + results written once, mean over the same launches (to set `traffic` against)
+                    algorithmic_bytes=v["bytes"] / v["launches"])
         roof_attn = None
         if attn:                                                  # the north star's second roofline: VideoAttention forward
             k, v = max(attn.items(), key=lambda kv: kv[1]["ms"])

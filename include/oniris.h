@@ -93,7 +93,9 @@ int oniris_weight_bwd(const OnirisWeightDesc* descs, int ndesc, int total_rows, 
  *                  UNet's channels-last output bf16 [B*S*T][H][W][8], out_gain a device scalar             (C <= 8)
  *   dart_loss_bwd: dF (bf16, zero for clean slots) and dgain_part[b][t] (sum them for d out_gain) from dlosses[b][t] */
 int oniris_dart_input(const float* images, const float* noise, const float* sigma, void* xcl, int B, int S, int T, int C,
-                      int H, int W, float sigma_data, oniris_stream_t stream);
+                      int H, int W, float sigma_data, float* c_noise_out, oniris_stream_t stream);
+/*   c_noise_out (may be NULL): [B*S*T] fp32 = log(sigma) / 4, the UNet's noise conditioning (networks_edm2.py:291), written by
+ *   the same launch (the sampler's evaluations save two tiny launches each)                                           */
 int oniris_dart_loss(const void* F, const float* images, const float* noise, const float* sigma, const float* out_gain,
                      float* losses, int B, int S, int T, int C, int H, int W, float sigma_data, oniris_stream_t stream);
 int oniris_dart_loss_bwd(const void* F, const float* images, const float* noise, const float* sigma,
@@ -119,6 +121,13 @@ int oniris_loss_tail(const float* mse, const float* sigma, const float* coef, fl
  *   outputs the gate coefficients ca, cb [L][N] of mp_sum(y2, y3, g) (utils.py:118-123).                              */
 int oniris_precond_out(const void* F, const float* x, const float* sigma, const float* out_gain, float* D, int N, int C,
                        int H, int W, float sigma_data, oniris_stream_t stream);
+/* oniris_sampler_update: the Euler / Heun update between two UNet evaluations of edm_sampler_with_mse (reference
+ *   edm2/sampler.py:66-76), one fp32 launch over n elements:
+ *   mode 0: d = (x_hat - x_pred) / t_a; x_out = x_hat + dt * d; d_io <- d
+ *   mode 1: d' = (x_aux - x_pred) / t_a; x_hat <- x_out <- x_hat + dt * (0.5 * d_io + 0.5 * d')
+ *   sigma_buf (nsig floats, may be NULL): filled with sigma_next (the sigma input of the evaluation that follows).      */
+int oniris_sampler_update(int mode, float* x_hat, const float* x_pred, float* d_io, const float* x_aux, float* x_out, size_t n,
+                          float t_a, float dt, float* sigma_buf, int nsig, float sigma_next, oniris_stream_t stream);
  /* oniris_embed_eval: the UNet's noise / label embedding (networks_edm2.py:204-216) in one fp32 launch: emb [N][cemb] bf16
  *   = mp_silu(mp_sum(MPConv_noise(MPFourier(c_noise)), MPConv_label(onehot(labels) * sqrt(L)), 1/3)); w_noise [cemb][cnoise],
  *   w_label [cemb][L] are the RAW fp32 parameters (normalised per row inside); labels / w_label NULL: no label term.      */
@@ -397,7 +406,7 @@ int oniris_attn_bwd_dkv(const OnirisAttnArgs* args /* [host] */, oniris_stream_t
 /* The gradient exchange of the data-parallel loop (cs_train.py:53-54,108-114,168) is issued by the host through
  * torch.distributed ("nccl" == RCCL on ROCm) on the flat gradient buffer: autoregressive_diffusion_amd/parallel.py.
  * This library exports no collective wrappers (the four pass-through oniris_comm_* entry points of ABI <= 7 carried no
- * logic and are gone in ABI 8).                                                                                    */
+ * logic and are gone since ABI 8).                                                                                    */
 
 #ifdef __cplusplus
 }

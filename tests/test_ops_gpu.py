@@ -668,6 +668,27 @@ def test_conv_epilogues(gated, H):
         assert all(v_ < 3e-2 for v_ in e.values()), e
 
 
+def test_sampler_update_matches_tensor_expressions():
+    """oniris_sampler_update against the reference's tensor expressions (edm2/sampler.py:66-76), sigmas as 0-dim device
+    tensors like there: bit-exact (same fp32 operations in the same order), in-place aliasing as the frame loop uses it."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(3)
+    shape = (2, 1, 8, 16, 16)
+    x_hat, x_pred, x_pred2 = (torch.randn(shape, device=DEV) * s for s in (40.0, 1.0, 1.0))
+    t_hat, t_next = torch.tensor(37.25, device=DEV), torch.tensor(21.125, device=DEV)
+    d_cur = (x_hat - x_pred) / t_hat
+    x_e = x_hat + (t_next - t_hat) * d_cur
+    d_prime = (x_e - x_pred2) / t_next
+    x_n = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
+    th, tn = t_hat.item(), t_next.item()
+    xh, d, xin, sig = x_hat.clone(), torch.empty_like(x_hat), torch.empty_like(x_hat), torch.zeros(2, 1, device=DEV)
+    ops.sampler_update(0, xh, x_pred, d, None, xin, th, tn - th, sig, tn)
+    assert torch.equal(d, d_cur) and torch.equal(xin, x_e) and torch.equal(xh, x_hat)
+    assert torch.equal(sig, torch.full((2, 1), tn, device=DEV))
+    ops.sampler_update(1, xh, x_pred2, d, xin, xin, tn, tn - th)
+    assert torch.equal(xh, x_n) and torch.equal(xin, x_n)
+
+
 def test_eval_side_kernels_match_torch_formulation():
     """oniris_gates / oniris_embed_eval / oniris_precond_out (+ oniris_dart_input without noise) against the torch
     formulation of the same reference lines (conv.py:113-127, networks_edm2.py:204-216, :278-297)."""
