@@ -102,7 +102,7 @@ _SIGS = {
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                        c_float, c_float, c_float, c_int, c_void_p]),
     "oniris_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
-                               c_int, c_void_p]),
+                               c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                c_float, c_float, c_int, c_void_p]),
     "oniris_emb_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

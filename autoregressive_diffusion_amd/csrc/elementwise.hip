@@ -19,11 +19,14 @@ __device__ __forceinline__ float dsilu_f(float z) {
 // ---------------------------------------------------------------------------------------------------------------
 // v = concat(w1 * x[C1], w2 * skip[C2]) ; NORM: v <- v / (eps + |v|/sqrt(C)) ; xo = v ; a = silu(v)/0.596
 // one thread = 8 channels of one pixel; G = C/8 threads per pixel (NORM needs G to be a power of two <= 64)
+// rs != 0: x is resampled on the way in (Block.forward resamples before anything else, networks_edm2.py:63): rs = 1 the
+// 2x2 mean, rs = 2 nearest x2, Ho x Wo = the OUTPUT grid (= the grid of pix); the resampled value is rounded to bf16 first,
+// exactly what the separate resample pass stored.
 template <bool NORM>
 __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ skip,
                                                       bf16* __restrict__ xo, bf16* __restrict__ a,
                                                       float* __restrict__ sden, long long npix, int C1, int C2, float w1,
-                                                      float w2) {
+                                                      float w2, int rs, int Ho, int Wo) {
   const int C = C1 + C2, G = C >> 3;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long pix = gid / G;
@@ -36,7 +39,32 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x
     const int c = cg * 8;
     bf16x8 in;
     float w;
-    if (c < C1) { in = *(const bf16x8*)(x + pix * C1 + c); w = w1; }
+    if (c < C1) {
+      w = w1;
+      if (rs == 0) in = *(const bf16x8*)(x + pix * C1 + c);
+      else {
+        const int xo_ = (int)(pix % Wo), yo_ = (int)((pix / Wo) % Ho);
+        const long long n = pix / ((long long)Wo * Ho);
+        if (rs == 1) {
+          const int Hi = Ho * 2, Wi = Wo * 2;
+          float acc[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+          for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+              const bf16x8 t = *(const bf16x8*)(x + ((n * Hi + 2 * yo_ + dy) * Wi + 2 * xo_ + dx) * C1 + c);
+#pragma unroll
+              for (int i = 0; i < 8; ++i) acc[i] += bf2f(t[i]);
+            }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) in[i] = f2bf(acc[i] * 0.25f);
+        } else {
+          in = *(const bf16x8*)(x + ((n * (Ho >> 1) + (yo_ >> 1)) * (Wo >> 1) + (xo_ >> 1)) * C1 + c);
+        }
+      }
+    }
     else { in = *(const bf16x8*)(skip + pix * C2 + (c - C1)); w = w2; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = bf2f(in[i]) * w;
@@ -125,16 +153,19 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ d
 }
 
 extern "C" int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sden, int64_t npix, int C1,
-                              int C2, float w1, float w2, int norm, oniris_stream_t stream_) {
+                              int C2, float w1, float w2, int norm, int resample, int Ho, int Wo, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int C = C1 + C2;
   ONIRIS_CHECK_ARG(x && a && npix > 0 && C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || skip),
                    "act_fwd: bad arguments");
+  ONIRIS_CHECK_ARG(resample == 0 || ((resample == 1 || resample == 2) && Ho > 0 && Wo > 0 && npix % ((int64_t)Ho * Wo) == 0 &&
+                                     (resample == 1 || (Ho % 2 == 0 && Wo % 2 == 0))),
+                   "act_fwd: resample needs the output grid (even for nearest x2)");
   ONIRIS_CHECK_ARG(!norm || ((C / 8) <= 64 && ((C / 8) & (C / 8 - 1)) == 0 && sden), "act_fwd: pixel norm needs C/8 = 2^k <= 64");
   const long long nthr = npix * (C / 8);
   const dim3 grid((unsigned)((nthr + 255) / 256));
-  if (norm) hipLaunchKernelGGL(act_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2);
-  else hipLaunchKernelGGL(act_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2);
+  if (norm) hipLaunchKernelGGL(act_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2, resample, Ho, Wo);
+  else hipLaunchKernelGGL(act_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2, resample, Ho, Wo);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -46,16 +46,18 @@ class Block(nn.Module):
             cache = {}
         # in_slot / skip_slot (ops.GradSlot): x / skip is an encoder output with a second consumer; the block's first op
         # adds the other consumer's gradient inside its own backward kernel, the mp_cat parks the skip gradient for it
-        if self.resample_mode != "keep":
-            x, in_slot = ops.resample(x, self.resample_mode, in_slot), None
+        # the resampling (reference :63) runs inside the block's first activation kernel when that is the next op
+        rs = self.resample_mode
+        if rs != "keep" and (skip is not None or (self.flavor == "enc" and self.conv_skip is not None)):
+            x, in_slot, rs = ops.resample(x, rs, in_slot), None, "keep"
         if self.flavor == "enc":
             if self.conv_skip is not None:
                 x, in_slot = self.conv_skip._cl(x, in_slot=in_slot), None
-            x, a = ops.act(x, norm=True, in_slot=in_slot)                  # x <- pixel norm(x); a = mp_silu(x)
+            x, a = ops.act(x, norm=True, in_slot=in_slot, resample=rs)     # x <- pixel norm(x); a = mp_silu(x)
         elif skip is not None:
             x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True, in_slot=in_slot, skip_slot=skip_slot)   # x <- mp_cat(x, skip); a = mp_silu(x)
         else:
-            x, a = ops.act(x, want_xo=True, in_slot=in_slot)               # x comes back as an alias of itself (see _ActFn)
+            x, a = ops.act(x, want_xo=True, in_slot=in_slot, resample=rs)  # (no resampling: x comes back as an alias of itself)
         N = x.shape[0]
         if c is None:          # (the UNet hands in all of its blocks' scales from one grouped GEMM: ops.emb_scales)
             c = (self.emb_linear._cl(emb).reshape(N, -1).float() * self.emb_gain + 1)      # (N, Cout) fp32

@@ -843,27 +843,38 @@ class GradSlot:
 
 class _ActFn(torch.autograd.Function):
     """(xo, a) = act(x[, skip]):  v = cat(w1*x, w2*skip); norm: v /= eps + |v|/sqrt(C); xo = v; a = silu(v)/0.596.
-    in_slot / skip_slot: GradSlots of x / of skip (see GradSlot)."""
+    in_slot / skip_slot: GradSlots of x / of skip (see GradSlot).  rs: x is resampled first (1 = 2x2 mean, 2 = nearest
+    x2; Block.forward's first line) inside the same forward launch; the backward runs the resample adjoint behind
+    act_bwd, and in_slot then belongs to the un-resampled x."""
 
     @staticmethod
-    def forward(ctx, x, skip, w1, w2, norm, want_xo, in_slot=None, skip_slot=None):
+    def forward(ctx, x, skip, w1, w2, norm, want_xo, in_slot=None, skip_slot=None, rs=0):
         _need_gpu(x)
         C1 = x.shape[-1]
         C2 = skip.shape[-1] if skip is not None else 0
-        npix = x.numel() // C1
-        shape = (*x.shape[:-1], C1 + C2)
+        if rs:
+            N_, Hi, Wi = x.shape[0], x.shape[1], x.shape[2]
+            Ho, Wo = (Hi // 2, Wi // 2) if rs == 1 else (Hi * 2, Wi * 2)
+            oshape = (N_, Ho, Wo)
+        else:
+            Ho = Wo = 0
+            oshape = tuple(x.shape[:-1])
+        npix = 1
+        for d_ in oshape:
+            npix *= d_
+        shape = (*oshape, C1 + C2)
         a = torch.empty(shape, dtype=BF16, device=x.device)
-        # want_xo without norm / cat: xo IS x -- the input itself is handed back (autograd aliases it), so that a tensor
-        # with two consumers (the activation and the residual / skip-conv path of a Block) reaches this node's backward
-        # as (dxo, da) and the two gradients are added inside act_bwd instead of by a torch add over three tensors
-        alias = want_xo and not norm and skip is None and x.is_contiguous()
-        xo = torch.empty(shape, dtype=BF16, device=x.device) if ((want_xo or norm) and not alias) else None
+        # want_xo without norm / cat / resample: xo IS x -- the input itself is handed back (autograd aliases it), so that a
+        # tensor with two consumers (the activation and the residual / skip-conv path of a Block) reaches this node's
+        # backward as (dxo, da) and the two gradients are added inside act_bwd instead of by a torch add over three tensors
+        alias = want_xo and not norm and skip is None and not rs and x.is_contiguous()
+        xo = torch.empty(shape, dtype=BF16, device=x.device) if ((want_xo or norm or rs) and not alias) else None
         sden = torch.empty(npix, dtype=torch.float32, device=x.device) if norm else None
         x = x.contiguous()
         skip = skip.contiguous() if skip is not None else None
-        check(lib.oniris_act_fwd(_p(x), _p(skip), _p(xo), _p(a), _p(sden), npix, C1, C2, w1, w2, int(norm), _stream()),
-              "act_fwd")
-        ctx.meta = (C1, C2, w1, w2, norm, npix, x.shape, skip.shape if skip is not None else None)
+        check(lib.oniris_act_fwd(_p(x), _p(skip), _p(xo), _p(a), _p(sden), npix, C1, C2, w1, w2, int(norm), rs, Ho, Wo,
+                                 _stream()), "act_fwd")
+        ctx.meta = (C1, C2, w1, w2, norm, npix, (*oshape, C1), skip.shape if skip is not None else None, rs, tuple(x.shape))
         ctx.slots = (in_slot, skip_slot)
         # without norm/cat xo would just be x itself: reuse the input for the silu' evaluation
         ctx.save_for_backward(xo if xo is not None else x, sden)
@@ -875,7 +886,7 @@ class _ActFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        C1, C2, w1, w2, norm, npix, xshape, sshape = ctx.meta
+        C1, C2, w1, w2, norm, npix, xshape, sshape, rs, xin_shape = ctx.meta
         xo, sden = ctx.saved_tensors
         if len(grads) == 2:
             dxo, da = grads
@@ -891,17 +902,27 @@ class _ActFn(torch.autograd.Function):
         dadd = in_slot.take() if in_slot is not None else None
         if dadd is not None:
             dadd = dadd.contiguous()
-            assert dadd.shape == dx.shape
-        check(lib.oniris_act_bwd(_p(da), _p(dxo), _p(xo), _p(sden), _p(dx), _p(dskip), _p(dadd), npix, C1, C2, w1, w2,
-                                 int(norm), _stream()), "act_bwd")
+            assert tuple(dadd.shape) == (tuple(xin_shape) if rs else tuple(dx.shape))
+        check(lib.oniris_act_bwd(_p(da), _p(dxo), _p(xo), _p(sden), _p(dx), _p(dskip), _p(None if rs else dadd), npix, C1, C2,
+                                 w1, w2, int(norm), _stream()), "act_bwd")
+        if rs:                                           # adjoint of the resampling (+ the second gradient of the input)
+            N_, Ho, Wo = xshape[0], xshape[1], xshape[2]
+            dpre = torch.empty(xin_shape, dtype=BF16, device=xo.device)
+            if rs == 1:    # adjoint of the 2x2 mean: nearest x2 scaled by 1/4
+                check(lib.oniris_resample(_p(dx), _p(dpre), _p(dadd), N_, Ho, Wo, C1, 1, 0.25, _stream()), "resample")
+            else:          # adjoint of nearest x2: 2x2 sum = 4 * mean
+                check(lib.oniris_resample(_p(dx), _p(dpre), _p(dadd), N_, Ho, Wo, C1, 0, 4.0, _stream()), "resample")
+            dx = dpre
         if skip_slot is not None and dskip is not None:
             skip_slot.put(dskip)                      # joins the encoder-side gradient inside that consumer's kernel
             dskip = None
-        return dx, dskip, None, None, None, None, None, None
+        return dx, dskip, None, None, None, None, None, None, None
 
 
-def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, skip_slot=None):
-    return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo), in_slot, skip_slot)
+def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, skip_slot=None, resample="keep"):
+    """resample 'down' / 'up': x is resampled first, in the same launch (the reference's Block.forward, :63)."""
+    rs = {"keep": 0, "down": 1, "up": 2}[resample]
+    return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo), in_slot, skip_slot, rs)
 
 
 class _ResampleFn(torch.autograd.Function):

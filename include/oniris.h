@@ -289,7 +289,9 @@ int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void*
  * oniris_resample: mode 0 = 2x2 mean (H,W = input size), mode 1 = nearest x2; result * scale (+ add, optional, shaped
  *   like out: see dadd above)  (utils.py:94-107 with f = [1,1]; adjoints: down^T = up * 0.25, up^T = down * 4).   */
 int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sden, int64_t npix, int C1, int C2,
-                   float w1, float w2, int norm, oniris_stream_t stream);
+                   float w1, float w2, int norm, int resample, int Ho, int Wo, oniris_stream_t stream);
+/*   resample != 0: x is resampled on the way in (Block.forward's first line, networks_edm2.py:63): 1 = 2x2 mean, 2 = nearest
+ *   x2, rounded to bf16 like oniris_resample stores it; npix and Ho x Wo describe the OUTPUT grid.                      */
 int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
                    const void* dadd, int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream);
 int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P, int C,

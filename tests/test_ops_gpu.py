@@ -590,6 +590,33 @@ def test_act_fused(C1, C2, norm):
     assert max(e) < 1e-2
 
 
+@pytest.mark.parametrize("mode,norm", [("down", True), ("up", False), ("down", False)])
+def test_act_with_resample_equals_resample_then_act(mode, norm):
+    """ops.act(..., resample=mode) (one forward launch) against ops.resample followed by ops.act: outputs and the input
+    gradient bit for bit, including a second gradient of the input parked in a GradSlot (an encoder output that is also a
+    skip connection)."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(12)
+    x0 = nhwc(bfr(torch.randn(3, 64, 8, 8) * 1.3))
+    extra = nhwc(bfr(torch.randn(3, 64, 8, 8)))
+    outs = []
+    for fused in (False, True):
+        x = x0.clone().requires_grad_(True)
+        slot = ops.GradSlot()
+        if fused:
+            xo, a = ops.act(x, norm=norm, want_xo=True, in_slot=slot, resample=mode)
+        else:
+            xo, a = ops.act(ops.resample(x, mode, slot), norm=norm, want_xo=True)
+        g = torch.Generator().manual_seed(7)
+        ga, gx = (bfr(torch.randn(a.shape, generator=g)).to(DEV) for _ in range(2))
+        slot.put(extra.clone())
+        ((a.float() * ga.float()).sum() + (xo.float() * gx.float()).sum()).backward()
+        outs.append((xo.detach().clone(), a.detach().clone(), x.grad.clone()))
+        assert slot.g is None
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+
+
 def test_resample_fused():
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(10)
