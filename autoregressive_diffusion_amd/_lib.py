@@ -114,6 +114,8 @@ _SIGS = {
                                      c_int, c_void_p]),
     "oniris_qkv_norm_rope_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_int, c_int, c_int, c_void_p]),
+    "oniris_qkv_eval": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                c_int, c_int, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "oniris_precond_out": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                    c_void_p]),
     "oniris_sampler_update": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_float, c_float,

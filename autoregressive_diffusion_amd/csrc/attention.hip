@@ -935,6 +935,106 @@ __global__ void qkv_norm_rope_eval_kernel(const bf16* __restrict__ qkv, bf16* __
   else *(bf16x8*)(v + ring) = plain;
 }
 
+// The sampler's attention input in ONE launch (31 evaluations per generated frame, every graph node costs ~5 us): the
+// attn_qkv 1x1 convolution of the new frame(s) (MPConv, attention_modules.py:47), the per-head normalisation and -- when
+// tables are given -- the rotary embedding at table row `pos`, written where qkv_norm_rope_eval_kernel / qkv_norm_kernel
+// write: q [tok][C] (with the softmax scale), k / v dense or behind the committed frames of the KV ring, kr = the rotated
+// key into the ring's rotated image.  One workgroup = 128 tokens x one (q|k|v, head) slice of 64 output channels; wave w
+// owns tokens 32w..32w+31 (MFMA D[channel][token]: a lane holds 32 of the head's 64 channels of ONE token, lane ^ 32 the
+// others; the rotation partner c + 32 of channel c is the other accumulator of the same lane).  The convolution result is
+// rounded to bf16 before the normalisation, like the tensor the two-launch path stores in between.
+template <int KC>
+__global__ __launch_bounds__(256) void qkv_eval_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                       bf16* __restrict__ q, bf16* __restrict__ k, bf16* __restrict__ v,
+                                                       bf16* __restrict__ kr, const float* __restrict__ cos_t,
+                                                       const float* __restrict__ sin_t, const float* __restrict__ scale_t,
+                                                       long long M, int C, int CinP, long long kv_tpb, long long kv_bstride,
+                                                       long long kv_off, int pos) {
+  // K is staged KC input channels at a time (the whole K for C <= 256: every load of the tile is in flight at once -- the
+  // launch is pure latency, ~10 us with four 64-channel rounds of load / barrier / multiply, half of that in one round)
+  constexpr int ROWB = KC * 2 + 16;                          // + 16 bytes: conflict-free 16-byte fragment reads
+  constexpr int PCS = KC / 8;                                // 16-byte pieces per row
+  __shared__ __attribute__((aligned(16))) unsigned char xs[128 * ROWB];
+  __shared__ __attribute__((aligned(16))) unsigned char ws[64 * ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  const long long m0 = (long long)blockIdx.x * 128;
+  const int vi = blockIdx.y, hpc = C / 64, s = vi / hpc, hd = vi % hpc;
+  const bf16* wrow = w + (size_t)vi * 64 * CinP;
+  const int mrows = (M - m0 < 128) ? (int)(M - m0) : 128;    // rows beyond M are never read back by a valid token
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  for (int c0 = 0; c0 < C; c0 += KC) {
+    if (c0) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 64 * PCS / 256; ++i) {               // weight tile: 64 rows
+      const int e = i * 256 + tid, row = e / PCS, pc = e % PCS;
+      *(u32x4*)(ws + row * ROWB + pc * 16) = *(const u32x4*)(wrow + (size_t)row * CinP + c0 + pc * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < 128 * PCS / 256; ++i) {              // x tile: 128 rows
+      const int e = i * 256 + tid, row = e / PCS, pc = e % PCS;
+      if (row < mrows) *(u32x4*)(xs + row * ROWB + pc * 16) = *(const u32x4*)(x + (size_t)(m0 + row) * C + c0 + pc * 8);
+    }
+    __syncthreads();
+    if (wave * 32 < mrows) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 16; ++ks) {
+        const bf16x8 xf = *(const bf16x8*)(xs + (wave * 32 + r) * ROWB + (ks * 2 + h) * 16);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const bf16x8 wf = *(const bf16x8*)(ws + (n * 32 + r) * ROWB + (ks * 2 + h) * 16);
+          acc[n] = mfma32(wf, xf, acc[n]);
+        }
+      }
+    }
+  }
+  const long long tok = m0 + wave * 32 + r;
+  float f[2][16], ss = 0.f;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { f[n][i] = bf2f(f2bf(acc[n][i])); ss += f[n][i] * f[n][i]; }
+  ss += __shfl_xor(ss, 32);
+  const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
+  if (tok >= M) return;
+  const bool rope = cos_t != nullptr && s != 2;
+  const size_t tb = (size_t)pos * 64;
+  const long long dense = tok * C + hd * 64;
+  const long long ring = (kv_tpb > 0) ? (tok / kv_tpb) * kv_bstride + (kv_off + tok % kv_tpb) * C + hd * 64 : dense;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4 plain[2], rot[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int i = 4 * g + kk, c = 8 * g + 4 * h + kk;       // channel c (first half) and c + 32 (second half) of the head
+      // (as in qkv_norm_rope_eval_kernel the rotation sees the bf16-rounded normalised vector)
+      const float u0 = bf2f(f2bf(f[0][i] * inv)), u1 = bf2f(f2bf(f[1][i] * inv));
+      plain[0][kk] = f2bf(u0); plain[1][kk] = f2bf(u1);
+      float v0 = u0, v1 = u1;
+      if (rope) {
+        v0 = u0 * cos_t[tb + c] - u1 * sin_t[tb + c];         // rotate_half: [-x2, x1]
+        v1 = u1 * cos_t[tb + c + 32] + u0 * sin_t[tb + c + 32];
+        const float s0 = scale_t[tb + c], s1 = scale_t[tb + c + 32];
+        v0 = (s == 0) ? v0 * s0 : v0 / s0;
+        v1 = (s == 0) ? v1 * s1 : v1 / s1;
+      }
+      rot[0][kk] = f2bf(v0); rot[1][kk] = f2bf(v1);
+    }
+    const int co = 8 * g + 4 * h;
+    if (s == 0) {
+      *(bf16x4*)(q + dense + co) = rot[0]; *(bf16x4*)(q + dense + co + 32) = rot[1];
+    } else if (s == 1) {
+      *(bf16x4*)(k + ring + co) = plain[0]; *(bf16x4*)(k + ring + co + 32) = plain[1];
+      if (kr) { *(bf16x4*)(kr + ring + co) = rot[0]; *(bf16x4*)(kr + ring + co + 32) = rot[1]; }
+    } else {
+      *(bf16x4*)(v + ring + co) = plain[0]; *(bf16x4*)(v + ring + co + 32) = plain[1];
+    }
+  }
+}
+
 // adjoint of qkv_norm_rope_kernel: dq (w.r.t. the UNSCALED rotated q, as the attention backward returns it), dk, dv ->
 // dqkv.  R^T g = g cos - rot(g sin) and the scale vector is equal in both halves, so it commutes with the rotation.
 __global__ void qkv_norm_rope_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dq,
@@ -1261,6 +1361,30 @@ extern "C" int oniris_qkv_norm_rope_eval(const void* qkv, void* q, void* k, void
   hipLaunchKernelGGL(qkv_norm_rope_eval_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)qkv, (bf16*)q, (bf16*)k, (bf16*)v, (bf16*)kr, cos_t, sin_t, scale_t, nvec, C,
                      (long long)kv_tokens_per_batch, (long long)kv_batch_stride, (long long)kv_token_offset, pos);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_qkv_eval(const void* x, const void* w, void* q, void* k, void* v, void* kr, const float* cos_t,
+                               const float* sin_t, const float* scale_t, int64_t n_tokens, int C, int CinP,
+                               int64_t kv_tokens_per_batch, int64_t kv_batch_stride, int64_t kv_token_offset, int pos,
+                               oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(x && w && q && k && v && n_tokens > 0 && C > 0 && C % 64 == 0 && CinP >= C && CinP % 8 == 0 && pos >= 0,
+                   "qkv_eval: bad arguments");
+  ONIRIS_CHECK_ARG((cos_t && sin_t && scale_t) || (!cos_t && !sin_t && !scale_t && !kr), "qkv_eval: all rotary tables or none");
+  ONIRIS_CHECK_ARG(kv_tokens_per_batch == 0 || (kv_tokens_per_batch > 0 && n_tokens % kv_tokens_per_batch == 0 &&
+                                                kv_batch_stride >= (kv_token_offset + kv_tokens_per_batch) * C),
+                   "qkv_eval: bad KV ring geometry");
+  const dim3 grid((unsigned)((n_tokens + 127) / 128), (unsigned)(3 * C / 64));
+#define QKV_EVAL_LAUNCH(KC_)                                                                                              \
+  hipLaunchKernelGGL(qkv_eval_kernel<KC_>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)w, (bf16*)q, (bf16*)k,  \
+                     (bf16*)v, (bf16*)kr, cos_t, sin_t, scale_t, (long long)n_tokens, C, CinP,                             \
+                     (long long)kv_tokens_per_batch, (long long)kv_batch_stride, (long long)kv_token_offset, pos)
+  if (C % 256 == 0) QKV_EVAL_LAUNCH(256);
+  else if (C % 128 == 0) QKV_EVAL_LAUNCH(128);
+  else QKV_EVAL_LAUNCH(64);
+#undef QKV_EVAL_LAUNCH
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

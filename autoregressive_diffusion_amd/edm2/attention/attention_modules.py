@@ -39,6 +39,9 @@ class _AttentionBase(nn.Module):
 
     def _frame_cl(self, x, clip):
         N, H, W, C = x.shape
+        if not torch.is_grad_enabled() and x.is_cuda:          # eval: qkv convolution + normalisation in one launch
+            o = ops.frame_attention_eval(x, self.attn_qkv.weight.pw, self.num_heads)
+            return self._proj(x, o.reshape(N, H, W, C), clip)
         slot = self._slot(x)
         qkv = self.attn_qkv._cl(x, in_slot=slot).reshape(N, H * W, 3 * C)
         o = ops.attention_train(qkv, "frame", N, 1, self.num_heads)
@@ -62,9 +65,13 @@ class VideoAttention(_AttentionBase):
         N, H, W, C = x.shape
         P = H * W
         self.__dict__["_tokens_per_frame"] = P               # (UNet.prewarm_eval sizes the next RoPE table from it)
+        rope_bufs = (self.rope.inv_freq, self.rope.scale)
+        if not self.training and not torch.is_grad_enabled() and x.is_cuda:
+            o, cache = ops.attention_eval_x(x, self.attn_qkv.weight.pw, batch_size, self.num_heads, rope_bufs, cache,
+                                            update_cache, P)
+            return self._proj(x, o.reshape(N, H, W, C), clip), cache
         slot = self._slot(x)
         qkv = self.attn_qkv._cl(x, in_slot=slot).reshape(N, P, 3 * C)
-        rope_bufs = (self.rope.inv_freq, self.rope.scale)
         if self.training:
             T = N // (2 * batch_size)
             o = ops.attention_train(qkv, "video", batch_size, T, self.num_heads, rope_bufs)

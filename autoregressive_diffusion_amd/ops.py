@@ -1448,6 +1448,64 @@ def _decode_splits(a, B, heads, Lq, Lk, dev):
         a._keep = ws                                # (keeps the workspace alive until the launch is queued)
 
 
+FUSED_QKV_EVAL = int(_os.environ.get("ONIRIS_FUSED_QKV_EVAL", "1"))     # 0: conv + qkv_norm[_rope_eval] as separate launches (A/B aid)
+
+
+def _qkv_eval(x, pw, q, k, v, kr, tabs, ntok, C, kv_tpb, kv_bstride, kv_off, pos):
+    cs_, sn_, sc_ = tabs if tabs is not None else (None, None, None)
+    check(lib.oniris_qkv_eval(_p(x), _p(pw.wf), _p(q), _p(k), _p(v), _p(kr), _p(cs_), _p(sn_), _p(sc_), ntok, C, pw.CinP,
+                              kv_tpb, kv_bstride, kv_off, pos, _stream()), "qkv_eval")
+
+
+@torch.no_grad()
+def attention_eval_x(x, pw, B, heads, rope_bufs, kv_cache, update_cache, P):
+    """attention_eval from the layer INPUT x (N, H, W, C) and the packed attn_qkv weight: for one new frame against a
+    prepared KV ring the 1x1 convolution, the normalisation and the rotation are one launch (oniris_qkv_eval), 3 launches
+    per VideoAttention layer and evaluation instead of 4; every other case runs the convolution and attention_eval."""
+    N, C = x.shape[0], x.shape[-1]
+    t = N // B
+    dev = x.device
+    ring = KVRing.of(kv_cache, B, P, C, t, dev) if (FUSED_QKV_EVAL and t == 1 and C == 64 * heads and pw.cout == 3 * C) else None
+    if ring is None or ring.kr_state != (ring.n, ring.n + 1):
+        qkv = conv(x, pw).reshape(N, P, 3 * C)
+        return attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P)
+    n, nk = ring.n, ring.n + 1
+    bstride = ring.cap * P * C
+    q = torch.empty((N, P, C), dtype=BF16, device=dev)
+    _qkv_eval(x.contiguous(), pw, q, ring.K, ring.V, ring.KR, rope_tables(rope_bufs[0], rope_bufs[1], nk, dev), N * P, C, P,
+              bstride, n * P, n)
+    if update_cache:
+        ring.n = nk
+        new_cache = ring.views()
+    else:
+        new_cache = kv_cache
+    out = torch.empty((N, P, C), dtype=BF16, device=dev)
+    a = _attn_args(q, ring.KR, ring.V, None, None, None, out, None, None, B, heads, P, nk * P, C, 0, P, 0)
+    a.v_bstride = a.k_bstride = bstride
+    _decode_splits(a, B, heads, P, nk * P, dev)
+    check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+    return out, new_cache
+
+
+@torch.no_grad()
+def frame_attention_eval(x, pw, heads):
+    """FrameAttention without autograd (attention_modules.py:105-119) from the layer input: qkv convolution + normalisation
+    in one launch, dense attention inside every frame."""
+    N, H, W, C = x.shape
+    P = H * W
+    dev = x.device
+    if not (FUSED_QKV_EVAL and C == 64 * heads and pw.cout == 3 * C):
+        return attention_train(conv(x, pw).reshape(N, P, 3 * C), "frame", N, 1, heads)
+    q = torch.empty((N, P, C), dtype=BF16, device=dev)
+    k, v = torch.empty_like(q), torch.empty_like(q)
+    _qkv_eval(x.contiguous(), pw, q, k, v, None, None, N * P, C, 0, 0, 0, 0)
+    out = torch.empty((N, P, C), dtype=BF16, device=dev)
+    lse = torch.empty((N, heads, P), dtype=torch.float32, device=dev)
+    a = _attn_args(q, k, v, None, None, None, out, lse, None, N, heads, P, P, C, 0, P, 1)
+    check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+    return out
+
+
 @torch.no_grad()
 def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     """Eval-mode VideoAttention core (attention_modules.py:51-77): qkv (B*t, P, 3C) of the NEW frames.

@@ -342,6 +342,14 @@ int oniris_qkv_norm_rope_eval(const void* qkv, void* q, void* k, void* v, void* 
                               const float* scale_t, int64_t n_tokens, int C, int64_t kv_tokens_per_batch,
                               int64_t kv_batch_stride, int64_t kv_token_offset, int pos, oniris_stream_t stream);
 
+/* oniris_qkv_eval: the attn_qkv 1x1 convolution + oniris_qkv_norm (tables NULL; kr NULL; kv_tokens_per_batch may be 0 =
+ * dense k, v) or + oniris_qkv_norm_rope_eval (tables given) in ONE launch, for the sampler's evaluations: x [n_tokens][C]
+ * bf16 channels-last, w = the packed forward weight of attn_qkv [3C][CinP] bf16 (rows (s m c), see perm3); outputs as those
+ * entry points write them (attention_modules.py:47-57).                                                               */
+int oniris_qkv_eval(const void* x, const void* w, void* q, void* k, void* v, void* kr, const float* cos_t, const float* sin_t,
+                    const float* scale_t, int64_t n_tokens, int C, int CinP, int64_t kv_tokens_per_batch,
+                    int64_t kv_batch_stride, int64_t kv_token_offset, int pos, oniris_stream_t stream);
+
 /* Block-sparse flash attention forward (replaces compiled_flex_attention / F.scaled_dot_product_attention,
  * attention_modules.py:41,66,70,75,115).  q [B][Lq][C], k,v [B][Lk][C] bf16 (head h = channels 64h..64h+63),
  * (the transposed operands V^T, K^T, Q^T, dO^T are produced inside the kernels by transposing LDS reads; the

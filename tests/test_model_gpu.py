@@ -474,6 +474,41 @@ def test_full_size_cached_equals_uncached():
     assert e1 < 1e-2 and e2 < 1e-2 and max(errs) < 1e-2
 
 
+def test_fused_qkv_eval_equals_conv_then_norm():
+    """One-frame evaluations of the full gym net with the fused attn_qkv launch (oniris_qkv_eval: 1x1 conv + normalisation
+    [+ rotation]) against the same evaluations with the convolution and the normalisation as separate launches: outputs and cached
+    keys / values agree to bf16 rounding."""
+    from edm2.networks_edm2 import UNet, Precond
+    from autoregressive_diffusion_amd import ops
+    outs = {}
+    for mode in (0, 1):
+        ops.FUSED_QKV_EVAL = mode
+        torch.manual_seed(0)
+        unet = UNet(**GYM_FULL).to(DEV)
+        torch.nn.init.constant_(unet.out_gain, 1.0)
+        net = Precond(unet, use_fp16=True, sigma_data=1.0).to(DEV).eval()
+        g = torch.Generator().manual_seed(2)
+        x = torch.randn(1, 4, 8, 64, 64, generator=g).to(DEV)
+        lab = torch.randint(0, 4, (1, 4), generator=g).to(DEV)
+        res = []
+        with torch.no_grad():
+            _, cache = net(x[:, :3], torch.full((1, 3), 0.3, device=DEV), lab[:, :3], update_cache=True)
+            unet.prewarm_eval(cache)
+            D, cache = net(x[:, 3:], torch.full((1, 1), 0.7, device=DEV), lab[:, 3:], cache=cache, update_cache=True)
+            res.append(D.float().cpu())
+            for key, sub in cache.items():
+                if isinstance(sub, dict) and sub.get("attn") is not None:
+                    res.append(sub["attn"][0].float().cpu()); res.append(sub["attn"][1].float().cpu())
+        outs[mode] = res
+    ops.FUSED_QKV_EVAL = 1
+    assert len(outs[0]) == len(outs[1]) and len(outs[0]) > 3
+    # (not bit for bit: the stand-alone 1x1 convolution of a one-frame evaluation is split-K, i.e. sums K in another order)
+    ek = max(rel(b, a.numpy()) for a, b in zip(outs[0][1:], outs[1][1:]))
+    e = rel(outs[1][0], outs[0][0].numpy())
+    print("fused qkv eval vs separate launches: D", e, "cached k / v", ek)
+    assert e < 6e-3 and ek < 1.5e-2          # (bf16 noise: a rounding flip in one layer reaches every later layer's input)
+
+
 def test_cached_decode_at_rollout_depth_equals_uncached():
     """BASELINE configs[4] depth (8 context + 256 generated frames, generation_code.py:83-95) on the FULL gym net: the
     reference's cached == non-cached property (consistency_test.py:129-146) for frame 264 -- denoised alone against the KV /
