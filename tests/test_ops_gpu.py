@@ -45,7 +45,8 @@ def test_mask_tables_bit_exact():
     assert ops.train_mask_table(3, 64) is None
 
 
-@pytest.mark.parametrize("shape", [(24, 16, ()), (40, 24, (1, 1)), (16, 8, (3, 3)), (64, 32, (2, 3, 3))])
+@pytest.mark.parametrize("shape", [(24, 16, ()), (40, 24, (1, 1)), (16, 8, (3, 3)), (64, 32, (2, 3, 3)),
+                                   (32, 160, (3, 3)), (16, 288, (2, 3, 3)), (8, 5, (3, 3))])     # several LDS rounds / odd cin
 def test_weight_prep_and_bwd(shape):
     from autoregressive_diffusion_amd import ops
     cout, cin, k = shape
