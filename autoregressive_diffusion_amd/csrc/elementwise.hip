@@ -236,7 +236,7 @@ __global__ void zero_f32_kernel(float* __restrict__ p, size_t n) {
 }
 
 extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P,
-                                   int C, int c_pitch, oniris_stream_t stream_) {
+                                   int C, int c_pitch, int dc_is_zero, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(du && y && c && dy && dc && N > 0 && P > 0 && C > 0 && C % 8 == 0 && C <= 512,
                    "emb_silu_bwd: bad arguments (C %% 8 == 0, C <= 512)");
@@ -246,7 +246,7 @@ extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c
   while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < 512) slices *= 2;
   const int ppb = cdiv(P, slices);
   const size_t ndc = (size_t)N * C;
-  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
+  if (!dc_is_zero) hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
   const int cp = c_pitch > 0 ? c_pitch : C;
   ONIRIS_CHECK_ARG(cp >= C && cp % 4 == 0, "emb_silu_bwd: c_pitch must be a multiple of 4 and >= C");
   hipLaunchKernelGGL(emb_silu_bwd_kernel, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,

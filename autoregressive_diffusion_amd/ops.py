@@ -696,8 +696,8 @@ class _ConvOp(torch.autograd.Function):
                                              _stream()), "gconv_bwd_fused")
         elif cfg.epi == "emb_silu":
             dout = torch.empty_like(g)
-            dcs = torch.empty((N, Co), dtype=torch.float32, device=dev)
-            check(lib.oniris_emb_silu_bwd(_p(g), _p(raw), _p(cs), _p(dout), _p(dcs), N, H * W, Co, cs.stride(0), _stream()),
+            dcs = pw2.bank.zero_arena.take(N * Co, dev)[:N * Co].view(N, Co)     # (zero-filled once per step with all the others)
+            check(lib.oniris_emb_silu_bwd(_p(g), _p(raw), _p(cs), _p(dout), _p(dcs), N, H * W, Co, cs.stride(0), 1, _stream()),
                   "emb_silu_bwd")
         elif cfg.epi == "mpsum":
             dres, dout = torch.empty_like(g), torch.empty_like(g)

@@ -295,7 +295,9 @@ int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sd
 int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
                    const void* dadd, int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream);
 int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P, int C,
-                        int c_pitch /* floats between rows of c; 0 = C */, oniris_stream_t stream);
+                        int c_pitch /* floats between rows of c; 0 = C */,
+                        int dc_is_zero /* != 0: the caller hands in a zero-filled dc (no fill launch here) */,
+                        oniris_stream_t stream);
 int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv, int64_t numel, float ta, float tb, float clip,
                      oniris_stream_t stream);
 int oniris_resample(const void* in, void* out, const void* add, int64_t N, int H, int W, int C, int mode, float scale,
