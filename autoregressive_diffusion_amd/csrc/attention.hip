@@ -762,6 +762,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv_kernel(const AttnDev d) {
 }
 
 #include "attention_bwd_ws.h"
+#include "attention_bwd_dq_ws.h"
 
 // dk|dv = sum over the chunks (in chunk order) of the fp32 partials; 8 elements per thread
 __global__ void attn_dkv_reduce_kernel(const float* __restrict__ part, bf16* __restrict__ dk, bf16* __restrict__ dv,
@@ -1286,6 +1287,16 @@ extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t st
   if (rc) return rc;
   ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.dout && d.a.lse && d.a.delta && d.a.dq,
                    "attn_bwd_dq: null pointer");
+  if (d.a.sched) {                                  // persistent, statically balanced, wave-specialised kernel (attention_bwd_dq_ws.h):
+    // the forward's work list (query blocks of 128 rows); lse / delta point at the NEGATED rows (oniris_attn_bwd_prep)
+    ONIRIS_CHECK_ARG(d.a.mask_mode == 2 && d.a.kv_num && d.a.kv_idx && d.a.tab_cols <= 64 && d.a.sched_wgs > 0 && d.a.sched_slots > 0,
+                     "attn_bwd_dq: the scheduled kernel needs the DART training table with <= 64 blocks per row");
+    ONIRIS_CHECK_ARG(d.a.Lq % 128 == 0 && d.a.Lq == d.a.Lk && d.a.Lq / 128 < 65536,
+                     "attn_bwd_dq: the scheduled kernel needs Lq == Lk, a multiple of 128 (got %d, %d)", d.a.Lq, d.a.Lk);
+    oniris_launch(attn_bwd_dq_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
   const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048;
   const dim3 grid(cdiv(d.a.Lq, split ? 64 : 128), d.a.heads, d.a.B);
   if (split) {

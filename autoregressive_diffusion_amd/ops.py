@@ -377,6 +377,7 @@ FUSED_ROPE = int(_os.environ.get("ONIRIS_FUSED_ROPE", "1"))        # 0: qkv norm
 ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
 ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
 ATTN_DKV_PERSISTENT = int(_os.environ.get("ONIRIS_DKV_PERSISTENT", "1"))   # 0: grid dK/dV kernel + chunk reduction (A/B, tests)
+ATTN_DQ_PERSISTENT = int(_os.environ.get("ONIRIS_DQ_PERSISTENT", "1"))      # 0: VideoAttention dQ through the grid kernel
 WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
 BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (see OnirisConvArgs.big_tile)
 
@@ -1337,8 +1338,18 @@ class _AttentionFn(torch.autograd.Function):
         a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
         fl = _attn_flops(kind, Bq, T, heads, L, P)
         ks = 2 if (mask_mode != 0 and L >= 2048) else 1
-        _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
-                  lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
+        if dkv_ws and ATTN_DQ_PERSISTENT and ctx.tabs[1].shape[1] <= 64:
+            # persistent dQ kernel on the forward's work list (query blocks, longest first); reads the NEGATED row constants
+            sched = _train_sched(T, P, Bq * heads, dev, "fwd")
+            a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+            a.lse, a.delta = _p(neg[0]), _p(neg[1])
+            _profiled(f"attn_bwd_dq_ws_kernel<MODE={mask_mode}>", 1.5 * fl,
+                      lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
+            a.sched, a.sched_wgs, a.sched_slots = None, 0, 0
+            a.lse, a.delta = _p(lse), _p(delta)
+        else:
+            _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
+                      lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
         if dkv_ws:
             # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
             # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch); it reads the NEGATED row constants
