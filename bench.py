@@ -183,6 +183,16 @@ def dry_run(args, rank, world):
     dist.destroy_process_group()
 
 
+def _claim_stdout():
+    """Exactly ONE line on stdout: the JSON record.  Native libraries print there too (RCCL writes a six-line version banner to
+    fd 1 when its communicator comes up, ROCm tools the odd notice): from here on fd 1 of this process is stderr, and `print`
+    to sys.stdout goes to the ORIGINAL stdout through a private descriptor."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    sys.stdout = os.fdopen(keep, "w", buffering=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,10 +221,11 @@ def main():
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 64 if args.net == "gym" else 32
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.mode == "train":
+        sys.exit(self_launch(args))              # (this process never imports torch, never touches a GPU)
+    _claim_stdout()
     if args.mode == "rollout":
         return rollout(args)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
-        sys.exit(self_launch(args))              # (this process never imports torch, never touches a GPU)
 
     import torch
     import torch.distributed as dist
