@@ -159,7 +159,9 @@ def _fused_frame(net, graphed, cache, conditioning, t_steps, x0, B, num_steps):
         if k == num_steps - 1:             # the evaluation whose cache update is kept (see _GraphedDenoiser.prepare)
             x_pred = graphed.run()
             ops.sampler_update(0, xh, x_pred, d, None, xh, t_hat, t_next - t_hat)
-            cache = graphed.finish_cache()
+            new = graphed.finish_cache()
+            cache.clear()                  # like the reference, the caller's dict itself carries the update (the replays that
+            cache.update(new)              # read the old tensors are ordered before anything queued from here on)
             break
         x_pred = graphed.run()
         ops.sampler_update(0, xh, x_pred, d, None, graphed.x, t_hat, t_next - t_hat, graphed.t, t_next)
