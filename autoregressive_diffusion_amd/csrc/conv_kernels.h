@@ -469,7 +469,9 @@ static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
     long long ks = 256 / nblk;
     if (ks > nphase) ks = nphase;
     if (ks > ks_cap) ks = ks_cap;
-    if (nphase < 6) ks = 1;                 // Cin = 32: three rounds, the second launch costs more than it saves
+    // Cin = 32: three rounds, the second launch costs more than it saves; 1x1 convs: a round is one 64-channel MFMA
+    // sweep (~1 us), and in the sampler's graphs a second node costs ~5 us by itself: split from Cin = 768 on
+    if (nphase < (TAPS == 1 ? 12 : 6)) ks = 1;
     if ((size_t)nblk * ks * per > a.splitk_ws_bytes) ks = (long long)(a.splitk_ws_bytes / (nblk * per));
     if (ks > 1) { d.ksplit = (int)ks; nblk *= ks; }
   }
