@@ -613,7 +613,11 @@ def test_ddp_staged_exchange_single_rank():
     for mode in dg:
         tol = 1e-2 if mode.endswith("bf16") else 1e-3                        # bf16 transport: one rounding of the average
         assert dg[mode] <= tol * gmax, (mode, dg[mode], gmax)
-        assert dp[mode] <= (3e-3 if mode.endswith("bf16") else 1e-5) * pmax + 2.1e-3 * mode.endswith("bf16"), (mode, dp[mode], pmax)
+        # AdamW's first step moves a parameter by lr * g / (|g| + eps), lr = 1e-3: where |g| is of the order of eps, the last
+        # bits of the gradient (the gate / emb-scale sums are fp32 atomics: run-to-run order) move the update by a fraction
+        # of lr -- 2e-4 absolute on top of the relative bound (a wrong exchange moves parameters by +-lr and more)
+        assert dp[mode] <= (3e-3 if mode.endswith("bf16") else 1e-5) * pmax + (2.1e-3 if mode.endswith("bf16") else 2e-4), \
+            (mode, dp[mode], pmax)
 
 
 def test_hipgraph_step_matches_eager():
