@@ -408,8 +408,9 @@ int oniris_attn_schedule(int n_pairs, int n_blocks, const int32_t* weight, int n
 
 int oniris_attn_fwd(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
 /* delta[b][h][q] = sum_c dout*out ; doutt (optional) = transposed dout; neg (optional, needs lse) [2][B][heads][L] =
- * -lse | -delta: the row constants the scheduled dK/dV kernel starts its S / dP accumulators from (its OnirisAttnArgs.lse
- * / .delta point at these two planes)                                                                             */
+ * -lse | -delta: the row constants the scheduled dQ and dK/dV kernels start their S / dP chains from (with
+ * OnirisAttnArgs.sched set, .lse / .delta of oniris_attn_bwd_dq and oniris_attn_bwd_dkv point at these two planes; the dQ
+ * kernel takes the FORWARD's work list -- 128-row query blocks --, the dK/dV kernel the one over 64-key items)       */
 int oniris_attn_bwd_prep(const void* dout, const void* out, float* delta, void* doutt, const float* lse, float* neg, int B,
                          int heads, int L, int C, oniris_stream_t stream);
 int oniris_attn_bwd_dq(const OnirisAttnArgs* args /* [host] */, oniris_stream_t stream);
