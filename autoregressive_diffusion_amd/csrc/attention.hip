@@ -872,6 +872,14 @@ __global__ void qkv_norm_rope_kernel(const bf16* __restrict__ qkv, bf16* __restr
   const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
   const size_t tb = (size_t)((tok / P) % pos_mod) * 64 + part * 8;
   const float sg = (part < 4) ? -1.f : 1.f;          // rotate_half: [-x2, x1]
+  // the three table rows of this lane's 8 channels as 16-byte loads (element-wise 4-byte loads made the pass VMEM-issue
+  // bound: 24 table loads per 16 bytes of output, 1.7 TB/s)
+  float cs[8], sn[8], sc[8];
+  if (s != 2) {
+    *(float4*)&cs[0] = *(const float4*)(cos_t + tb); *(float4*)&cs[4] = *(const float4*)(cos_t + tb + 4);
+    *(float4*)&sn[0] = *(const float4*)(sin_t + tb); *(float4*)&sn[4] = *(const float4*)(sin_t + tb + 4);
+    *(float4*)&sc[0] = *(const float4*)(scale_t + tb); *(float4*)&sc[4] = *(const float4*)(scale_t + tb + 4);
+  }
   bf16x8 o;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -879,9 +887,8 @@ __global__ void qkv_norm_rope_kernel(const bf16* __restrict__ qkv, bf16* __restr
     const float up = __shfl_xor(u, 4);                // (every lane of the 8-lane group takes part: no divergence above)
     float val = u;
     if (s != 2) {
-      val = u * cos_t[tb + i] + sg * up * sin_t[tb + i];
-      const float scl = scale_t[tb + i];
-      val = (s == 0) ? val * scl : val / scl;
+      val = u * cs[i] + sg * up * sn[i];
+      val = (s == 0) ? val * sc[i] : val / sc[i];
     }
     o[i] = f2bf(val);
   }
@@ -1055,18 +1062,21 @@ __global__ void qkv_norm_rope_bwd_kernel(const bf16* __restrict__ qkv, const bf1
   const bf16x8 g = *(const bf16x8*)(gsrc + tok * C + hd * 64 + part * 8);
   const size_t tb = (size_t)((tok / P) % pos_mod) * 64 + part * 8;
   const float sg = (part < 4) ? 1.f : -1.f;          // adjoint of rotate_half
+  float cs[8], sn[8], sc[8];                          // (16-byte table loads, see qkv_norm_rope_kernel)
+  if (s != 2) {
+    *(float4*)&cs[0] = *(const float4*)(cos_t + tb); *(float4*)&cs[4] = *(const float4*)(cos_t + tb + 4);
+    *(float4*)&sn[0] = *(const float4*)(sin_t + tb); *(float4*)&sn[4] = *(const float4*)(sin_t + tb + 4);
+    *(float4*)&sc[0] = *(const float4*)(scale_t + tb); *(float4*)&sc[4] = *(const float4*)(scale_t + tb + 4);
+  }
   float f[8], gg[8], ss = 0.f, dot = 0.f;
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     f[i] = bf2f(x[i]);
     float gv = bf2f(g[i]);
-    if (s != 2) {
-      const float scl = scale_t[tb + i];
-      gv = (s == 0) ? gv * scl : gv / scl;
-    }
-    const float gs = (s != 2) ? gv * sin_t[tb + i] : 0.f;
+    if (s != 2) gv = (s == 0) ? gv * sc[i] : gv / sc[i];
+    const float gs = (s != 2) ? gv * sn[i] : 0.f;
     const float gp = __shfl_xor(gs, 4);               // (g sin) of the partner channel
-    gg[i] = (s != 2) ? gv * cos_t[tb + i] + sg * gp : gv;
+    gg[i] = (s != 2) ? gv * cs[i] + sg * gp : gv;
     ss += f[i] * f[i]; dot += f[i] * gg[i];
   }
   ss += __shfl_xor(ss, 1); ss += __shfl_xor(ss, 2); ss += __shfl_xor(ss, 4);
