@@ -219,8 +219,20 @@ __global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restric
       }
       *(bf16x8*)(dy + off) = o;
     }
+    if ((G & (G - 1)) != 0) {                        // (channel groups not a power of two: every lane adds its own)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) atomicAdd(&acc[cg * 8 + i], part[i]);
+      for (int i = 0; i < 8; ++i) atomicAdd(&acc[cg * 8 + i], part[i]);
+    }
+  }
+  if ((G & (G - 1)) == 0) {
+    // lanes of a wave with the same channel group (cg = lane % G; every thread is a pixel lane then) add up by shuffles:
+    // G lanes per wave reach the LDS accumulators instead of 64 (see gconv_bwd_fused_kernel)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float v = part[i];
+      for (int o = G; o < 64; o <<= 1) v += __shfl_xor(v, o);
+      if ((int)(threadIdx.x & 63) < G) atomicAdd(&acc[cg * 8 + i], v);
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < C; i += 256) atomicAdd(dc + (size_t)n * C + i, acc[i]);

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_prep_kernel(const bf16* __restr
 //   mode 2 (EPI_MPSUM):    g = d out, out = clip(ta*res + tb*v) -> dres = ta*g*mask ; dout = tb*g*mask
 // then S1/S2/dy3 exactly as gconv_bwd_prep_kernel.  raw = y (mode 1) or v (mode 2).
 template <int MODE>
-__global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __restrict__ g, const bf16* __restrict__ raw,
+__global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* __restrict__ g, const bf16* __restrict__ raw,
                                                               const bf16* __restrict__ y3, const float* __restrict__ ca,
                                                               const float* __restrict__ cb, const float* __restrict__ cs,
                                                               const bf16* __restrict__ xo, bf16* __restrict__ dout,
@@ -465,9 +465,10 @@ __global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __rest
   const int bt = blockIdx.x, b = bt / T, t = bt % T;
   const size_t PC = (size_t)P * C;
   const int G8 = C >> 3;
-  const int cg = threadIdx.x % G8, pl = threadIdx.x / G8, npl = 256 / G8;
+  const int NTH = blockDim.x;                      // 256 or 1024 threads (the host picks: see oniris_gconv_bwd_fused)
+  const int cg = threadIdx.x % G8, pl = threadIdx.x / G8, npl = NTH / G8;
   if (MODE == 1)
-    for (int i = threadIdx.x; i < 2 * 512; i += 256) (&accs[0][0])[i] = 0.f;
+    for (int i = threadIdx.x; i < 2 * 512; i += NTH) (&accs[0][0])[i] = 0.f;
   __syncthreads();
   float s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
   float part[2][8];
@@ -533,12 +534,24 @@ __global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __rest
       for (int i = 0; i < 8; ++i) o3[i] = f2bf(acc3[i]);
       *(bf16x8*)(dy3 + (size_t)bt * PC + off) = o3;
     }
-    if (MODE == 1) {
+    if (MODE == 1 && (G8 & (G8 - 1)) != 0) {                      // (channel groups not a power of two: every lane adds its own)
 #pragma unroll
       for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int i = 0; i < 8; ++i) atomicAdd(&accs[s][cg * 8 + i], part[s][i]);
     }
+  }
+  if (MODE == 1 && (G8 & (G8 - 1)) == 0) {
+    // the lanes of a wave that hold the same channel group (cg = lane % G8: G8 a power of two <= 64, every thread of the block
+    // is a pixel lane then) add up by shuffles first; G8 lanes per wave reach the LDS accumulators instead of 64
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        float v = part[s][i];
+        for (int o = G8; o < 64; o <<= 1) v += __shfl_xor(v, o);
+        if ((int)(threadIdx.x & 63) < G8) atomicAdd(&accs[s][cg * 8 + i], v);
+      }
   }
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -547,7 +560,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_fused_kernel(const bf16* __rest
   }
   if (MODE == 1) {
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) {
+    for (int i = threadIdx.x; i < C; i += NTH) {
       atomicAdd(dcs + nn[0] * C + i, accs[0][i]); atomicAdd(dcs + nn[1] * C + i, accs[1][i]);
     }
   }
@@ -566,16 +579,22 @@ extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, 
   // pixel slices so that the launch covers the chip (B*T alone is ~128 blocks); partial sums meet through atomics,
   // so d_coef_own / d_coef_ctx / d_cscale must be ZERO on entry.
   int slices = 1;
-  const int npl = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
-  // mode 1 ends every block with 2*C global atomics (the emb-scale gradient): measured 64 / 54 / 43 / 37 / 42 us at
-  // 4096 / 2048 / 1024 / 512 / 256 blocks (64x64x32ch level), mode 2 is flat from 1024 up
-  const int tgt = (mode == 1) ? 512 : 2048;
+  // mode 1 ends every block with 2*C global atomics (the emb-scale gradient; all slices of a frame add into the same row):
+  // measured 64 / 54 / 43 / 37 / 42 us at 4096 / 2048 / 1024 / 512 / 256 blocks of 256 threads (64x64x32ch level) -- few
+  // blocks, so they are 1024 threads wide (two per CU fill it); mode 2 is flat from 1024 blocks of 256 up
+  static int nth1 = -1;                              // (ONIRIS_GCONV_BWD_THREADS: A/B knob for mode 1)
+  if (nth1 < 0) { const char* e = getenv("ONIRIS_GCONV_BWD_THREADS"); nth1 = e ? atoi(e) : 256; }
+  const int nth = (mode == 1 && (long long)P * (C / 8) >= 4096) ? nth1 : 256;
+  const int npl = nth / (C / 8) > 0 ? nth / (C / 8) : 1;
+  static int tgt1 = -1;                              // (ONIRIS_GCONV_BWD_BLOCKS: A/B knob for mode 1)
+  if (tgt1 < 0) { const char* e = getenv("ONIRIS_GCONV_BWD_BLOCKS"); tgt1 = e ? atoi(e) : 512; }
+  const int tgt = (mode == 1) ? tgt1 : 2048;
   while (slices < 32 && P / (slices * 2) >= npl * 2 && (long long)B * T * slices < tgt) slices *= 2;
   const int ppb = cdiv(P, slices);
   const int csp = cscale_pitch > 0 ? cscale_pitch : C;
   ONIRIS_CHECK_ARG(csp >= C && csp % 4 == 0, "gconv_bwd_fused: cscale_pitch must be a multiple of 4 and >= C");
   if (mode == 1)
-    hipLaunchKernelGGL(gconv_bwd_fused_kernel<1>, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)g,
+    hipLaunchKernelGGL(gconv_bwd_fused_kernel<1>, dim3(B * T, slices), dim3(nth), 0, stream, (const bf16*)g,
                        (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
                        (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp);
   else
