@@ -709,8 +709,8 @@ class _ConvOp(torch.autograd.Function):
         if gated:
             B, T = cfg.B, cfg.T
             if not fused:
-                dca = torch.empty(N, dtype=torch.float32, device=dev)
-                dcb = torch.empty(N, dtype=torch.float32, device=dev)
+                acc = pw2.bank.zero_arena.take(2 * N, dev)           # (accumulated by the launch's pixel slices)
+                dca, dcb = acc[:N], acc[N:2 * N]
                 dy3 = torch.empty_like(y3)
                 check(lib.oniris_gconv_bwd_prep(_p(dout), _p(raw), _p(y3), _p(ca), _p(cb), _p(dca), _p(dcb), _p(dy3), B, 2,
                                                 T, H * W * Co, _stream()), "gconv_bwd_prep")

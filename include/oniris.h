@@ -260,7 +260,8 @@ int oniris_conv_wgrad_group(const OnirisWgradArgs* args /* [host], ngroups entri
  * frame-slot n, d_coef_own[n] = sum(dout*y2) (recovered as (sum(dout*out) - coef_ctx*sum(dout*y3)) / coef_own),
  * d_coef_ctx[n] = sum(dout*y3) (the gate gradient, chained to the 6 gating parameters on the host) and the
  * context-path gradient dy3[b,t] = sum_s coef_ctx[b,s,t] * dout[b,s,t].
- * dout/out bf16 [B][S][T][frame_elems], y3/dy3 [B][T][frame_elems]. */
+ * dout/out bf16 [B][S][T][frame_elems], y3/dy3 [B][T][frame_elems].  d_coef_own / d_coef_ctx are ACCUMULATED (the launch is
+ * split over pixel slices that meet through fp32 atomics): zero them before the call. */
 int oniris_gconv_bwd_prep(const void* dout, const void* out, const void* y3, const float* coef_own,
                           const float* coef_ctx, float* d_coef_own, float* d_coef_ctx, void* dy3, int B, int S, int T,
                           int64_t frame_elems, oniris_stream_t stream);
