@@ -399,8 +399,10 @@ __global__ __launch_bounds__(256) void dart_input_kernel(const float* __restrict
   }
 }
 
+// (1024 threads per block: only the noised half of the frames does work -- 128 blocks at the gym shape --, so the width of
+// a block is what keeps loads in flight; the frame's sum stays ONE block's deterministic reduction)
 template <bool BWD>
-__global__ __launch_bounds__(256) void dart_loss_kernel(const bf16* __restrict__ F, const float* __restrict__ img,
+__global__ __launch_bounds__(1024) void dart_loss_kernel(const bf16* __restrict__ F, const float* __restrict__ img,
                                                         const float* __restrict__ noise, const float* __restrict__ sigma,
                                                         const float* __restrict__ out_gain, const float* __restrict__ g,
                                                         float* __restrict__ losses, bf16* __restrict__ dF,
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void dart_loss_kernel(const bf16* __restrict__
   const int n = blockIdx.x, b = n / (S * T), st = n % (S * T), s = st / T, t = st % T;
   if (s != S - 1) {                               // clean half: not part of the loss (loss.py:38 uses out[:, -T:])
     if (BWD)
-      for (int p = threadIdx.x; p < HW; p += 256) *(uint4*)(dF + ((size_t)n * HW + p) * 8) = make_uint4(0u, 0u, 0u, 0u);
+      for (int p = threadIdx.x; p < HW; p += (int)blockDim.x) *(uint4*)(dF + ((size_t)n * HW + p) * 8) = make_uint4(0u, 0u, 0u, 0u);
     return;
   }
   const float sg = sigma[b * S * T + st], og = out_gain[0];
@@ -420,7 +422,7 @@ __global__ __launch_bounds__(256) void dart_loss_kernel(const bf16* __restrict__
   const float inv = 1.f / (float)(C * HW);
   const float gl = BWD ? g[b * T + t] * 2.f * inv : 0.f;
   float acc = 0.f;
-  for (int p = threadIdx.x; p < HW; p += 256) {
+  for (int p = threadIdx.x; p < HW; p += (int)blockDim.x) {
     const uint4 fv = *(const uint4*)(F + ((size_t)n * HW + p) * 8);
     const bf16* f = (const bf16*)&fv;
     bf16 o[8];
@@ -466,7 +468,7 @@ extern "C" int oniris_dart_loss(const void* F, const float* images, const float*
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(F && images && noise && sigma && out_gain && losses && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 &&
                    C <= 8 && H > 0 && W > 0, "dart_loss: bad arguments");
-  hipLaunchKernelGGL(dart_loss_kernel<false>, dim3(B * S * T), dim3(256), 0, stream, (const bf16*)F, images, noise, sigma,
+  hipLaunchKernelGGL(dart_loss_kernel<false>, dim3(B * S * T), dim3(1024), 0, stream, (const bf16*)F, images, noise, sigma,
                      out_gain, (const float*)nullptr, losses, (bf16*)nullptr, (float*)nullptr, S, T, C, H * W, sigma_data);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -478,7 +480,7 @@ extern "C" int oniris_dart_loss_bwd(const void* F, const float* images, const fl
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(F && images && noise && sigma && out_gain && dlosses && dF && dgain_part && B > 0 && (S == 1 || S == 2) &&
                    T > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "dart_loss_bwd: bad arguments");
-  hipLaunchKernelGGL(dart_loss_kernel<true>, dim3(B * S * T), dim3(256), 0, stream, (const bf16*)F, images, noise, sigma,
+  hipLaunchKernelGGL(dart_loss_kernel<true>, dim3(B * S * T), dim3(1024), 0, stream, (const bf16*)F, images, noise, sigma,
                      out_gain, dlosses, (float*)nullptr, (bf16*)dF, dgain_part, S, T, C, H * W, sigma_data);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
