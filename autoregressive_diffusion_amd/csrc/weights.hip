@@ -36,11 +36,13 @@ __device__ __forceinline__ const OnirisWeightDesc* find_desc_tile(const OnirisWe
 // Pass 1: one workgroup per output-channel row: the two normalisations (training: the first is written back) and the
 // forward packing wf[tap][co][ci] -- written tap by tap with ci along the lanes (128-byte runs; the first version
 // walked the parameter order and wrote 2-byte elements with a stride of CoutP*CinP).
-#define WROW_CH 128          // input channels per LDS transpose round of the row kernels
-#define WROW_TAPS 27
+#define WROW_TAPS 27         // LDS transpose rounds of the row kernels: WROW_LDS floats hold [taps][wrow_ch(taps) + 1]
+#define WROW_LDS 4640
+// input channels per round: as many as fit, so that a round's taps * ch / 8 sixteen-byte slab items keep all 256 lanes busy
+__device__ __forceinline__ int wrow_ch(int taps) { return taps <= 9 ? 512 : taps <= 18 ? 256 : 128; }
 __global__ __launch_bounds__(256) void weight_prep_kernel(const OnirisWeightDesc* descs, int ndesc, int training) {
   __shared__ float red[16];
-  __shared__ float wrow_lds[WROW_TAPS * (WROW_CH + 1)];
+  __shared__ float wrow_lds[WROW_LDS];
   const int row = blockIdx.x;
   const OnirisWeightDesc* d = find_desc(descs, ndesc, row);
   const int co = row - d->row_start;
@@ -75,16 +77,17 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const OnirisWeightDesc
   unsigned short* wf = (unsigned short*)d->wf;
   if (!wf) return;
   if (taps > 1 && taps <= WROW_TAPS && (cin & 7) == 0) {
-    // [ci][tap] -> [tap][ci] through LDS, WROW_CH input channels at a time: the parameters are read in their own order
+    // [ci][tap] -> [tap][ci] through LDS, wrow_ch(taps) input channels at a time: the parameters are read in their own order
     // (consecutive addresses; the form below gathers 4-byte values with a stride of taps*4 bytes: ~64 cache lines per wave
     // instruction, which is what bounded this kernel on the long rows of the 310 M net) and the packed row is written 16
-    // bytes per lane.  Row stride WROW_CH + 1 floats: the transposed accesses are conflict-free.
-    for (int c0 = 0; c0 < cin; c0 += WROW_CH) {
-      const int cw = min(WROW_CH, cin - c0), n = cw * taps;
+    // bytes per lane.  Row stride wrow_ch + 1 floats: the transposed accesses are conflict-free.
+    const int CH = wrow_ch(taps);
+    for (int c0 = 0; c0 < cin; c0 += CH) {
+      const int cw = min(CH, cin - c0), n = cw * taps;
       if (c0) __syncthreads();
       for (int e = threadIdx.x; e < n; e += 256) {
         const int ci = e / taps, tap = e - ci * taps;
-        wrow_lds[tap * (WROW_CH + 1) + ci] = w[c0 * taps + e] * scale;
+        wrow_lds[tap * (CH + 1) + ci] = w[c0 * taps + e] * scale;
       }
       __syncthreads();
       const int c8 = cw >> 3;
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void weight_prep_kernel(const OnirisWeightDesc
         const int tap = it / c8, ci = (it - tap * c8) * 8;
         bf16x8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = f2bf(wrow_lds[tap * (WROW_CH + 1) + ci + j]);
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(wrow_lds[tap * (CH + 1) + ci + j]);
         *(bf16x8*)(wf + ((size_t)tap * d->CoutP + cop) * d->CinP + c0 + ci) = o;
       }
     }
@@ -142,8 +145,8 @@ __global__ __launch_bounds__(256) void weight_wb_kernel(const OnirisWeightDesc* 
 // grad(w_hat) of   W = gain/sqrt(f) * w_hat / (eps + |w_hat|/sqrt(f))   given dW (packed bf16 split-K slabs, from wgrad)
 //
 // One workgroup per output-channel row.  The slabs are laid out [co][tap][ci] (what the wgrad kernels produce), the
-// parameter and its gradient [co][ci][tap]: the row is transposed on the way, WROW_CH input channels at a time through LDS
-// (row stride WROW_CH + 1 floats: conflict-free both ways), so that the slabs are read 16 bytes per lane along ci AND the
+// parameter and its gradient [co][ci][tap]: the row is transposed on the way, wrow_ch(taps) input channels at a time through LDS
+// (row stride wrow_ch + 1 floats: conflict-free both ways), so that the slabs are read 16 bytes per lane along ci AND the
 // parameters / gradients are walked in their own order.  The first version walked w / grad in slab order (4-byte accesses
 // with a stride of taps*4 bytes, ~64 cache lines per wave instruction on three of its four streams): 1.6 TB/s on the 310 M
 // net, where this kernel was 18 % of the step.  The fp32 row sum G is parked in `dws` in PARAMETER order between the two
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void weight_wb_kernel(const OnirisWeightDesc* 
 // 56 KB of LDS per workgroup leave two workgroups per CU, and the kernel lives on loads in flight.
 __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc* descs, int ndesc, int chunk_max_nsp) {
   __shared__ float red[16];
-  __shared__ float Gs[WROW_TAPS * (WROW_CH + 1)];
+  __shared__ float Gs[WROW_LDS];
   const int row = blockIdx.x;
   const OnirisWeightDesc* d = find_desc(descs, ndesc, row);
   if (d->dwp == nullptr || d->dws == nullptr || d->grad == nullptr) return;
@@ -168,16 +171,17 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
   const int nsp = d->nsplit ? *d->nsplit : 1;
   if (nsp <= 0) return;                                         // no wgrad ran for this weight in this step
   const size_t slab = (size_t)taps * d->CoutP * d->CinP;
-  // many slabs (small weights, whose wgrad launches are split over all CUs): the slab reads are the traffic, and they want
-  // every lane of the workgroup issuing them at once, not WROW_CH channels at a time between barriers -- the form below
+  // (chunk_max_nsp: A/B knob -- with 128-channel rounds weights with many slabs were faster in the form below, whose slab
+  // reads keep every lane busy; with rounds sized by wrow_ch() the transposing form wins for every slab count)
   const bool chunked = (cin & 7) == 0 && taps <= WROW_TAPS && nsp <= chunk_max_nsp;
   float* gp = dws + (size_t)co * fan;                           // chunked form: G of this row in parameter order
   // pass 1 (the row of this workgroup is ONE contiguous run of taps * CinP values per slab): G = fp32 sum over the bf16
   // split-K slabs, dot = <G, w>, nn = |w|^2
   float dot = 0.f, nn = 0.f;
   if (chunked) {
-    for (int c0 = 0; c0 < cin; c0 += WROW_CH) {
-      const int cw = min(WROW_CH, cin - c0), c8 = cw >> 3;
+    const int CH = wrow_ch(taps);
+    for (int c0 = 0; c0 < cin; c0 += CH) {
+      const int cw = min(CH, cin - c0), c8 = cw >> 3;
       if (c0) __syncthreads();
       // 16 bytes (8 slab values) per lane and up to 8 independent slab reads in flight
       for (int it = threadIdx.x; it < taps * c8; it += 256) {
@@ -204,13 +208,13 @@ __global__ __launch_bounds__(256) void weight_bwd_kernel(const OnirisWeightDesc*
           for (int j = 0; j < 8; ++j) G[s_ & 3][j] += bf2f(t[j]);
         }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) Gs[tap * (WROW_CH + 1) + ci + j] = (G[0][j] + G[1][j]) + (G[2][j] + G[3][j]);
+        for (int j = 0; j < 8; ++j) Gs[tap * (CH + 1) + ci + j] = (G[0][j] + G[1][j]) + (G[2][j] + G[3][j]);
       }
       __syncthreads();
       const int n = cw * taps;
       for (int e = threadIdx.x; e < n; e += 256) {               // parameter order: e = ci*taps + tap
         const int ci = e / taps, tap = e - ci * taps;
-        const float G = Gs[tap * (WROW_CH + 1) + ci], v = w[c0 * taps + e];
+        const float G = Gs[tap * (CH + 1) + ci], v = w[c0 * taps + e];
         gp[c0 * taps + e] = G;
         dot += G * v; nn += v * v;
       }
@@ -265,7 +269,7 @@ extern "C" int oniris_weight_bwd(const OnirisWeightDesc* descs_dev, int ndesc, i
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(descs_dev && ndesc > 0 && total_rows > 0, "weight_bwd: bad arguments");
   static int chunk_max_nsp = -1;          // (ONIRIS_WBWD_CHUNK_NSP: A/B knob of the transposing form's slab-count limit)
-  if (chunk_max_nsp < 0) { const char* e = getenv("ONIRIS_WBWD_CHUNK_NSP"); chunk_max_nsp = e ? atoi(e) : 2; }
+  if (chunk_max_nsp < 0) { const char* e = getenv("ONIRIS_WBWD_CHUNK_NSP"); chunk_max_nsp = e ? atoi(e) : 1 << 30; }
   hipLaunchKernelGGL(weight_bwd_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc, chunk_max_nsp);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
