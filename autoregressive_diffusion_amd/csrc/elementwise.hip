@@ -5,6 +5,7 @@
 //                         channel) reduction for c; the forward lives in the conv epilogue (ONIRIS_EPI_EMB_SILU)
 //   mpsum_bwd             backward of  out = clip(ta*res + tb*v) (networks_edm2.py:86,93), forward = conv epilogue
 //   resample_down/up      2x2 mean / nearest x2 (utils.py:94-107 with f=[1,1]) and their adjoints
+#include <cstdlib>
 #include "common.h"
 #include "../../include/oniris.h"
 
@@ -255,7 +256,9 @@ extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c
   int slices = 1;
   const int npl = 256 / (C / 8) > 0 ? 256 / (C / 8) : 1;
   // (every block ends with C global atomics: fewer, longer blocks are faster -- see oniris_gconv_bwd_fused)
-  while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < 512) slices *= 2;
+  static int tgt = -1;                               // (ONIRIS_EMB_SILU_BLOCKS: A/B knob)
+  if (tgt < 0) { const char* e = getenv("ONIRIS_EMB_SILU_BLOCKS"); tgt = e ? atoi(e) : 1024; }
+  while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < tgt) slices *= 2;
   const int ppb = cdiv(P, slices);
   const size_t ndc = (size_t)N * C;
   if (!dc_is_zero) hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
