@@ -46,7 +46,7 @@ def test_mask_tables_bit_exact():
 
 
 @pytest.mark.parametrize("shape", [(24, 16, ()), (40, 24, (1, 1)), (16, 8, (3, 3)), (64, 32, (2, 3, 3)),
-                                   (32, 160, (3, 3)), (16, 288, (2, 3, 3)), (8, 5, (3, 3))])     # several LDS rounds / odd cin
+                                   (32, 160, (3, 3)), (16, 288, (2, 3, 3)), (8, 640, (3, 3)), (8, 5, (3, 3))])     # several LDS rounds / odd cin
 def test_weight_prep_and_bwd(shape):
     from autoregressive_diffusion_amd import ops
     cout, cin, k = shape
