@@ -336,7 +336,9 @@ GYM_FULL = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=3
                                                  ("gym-full-net", GYM_FULL, 8, True),
                                                  # BASELINE configs[1] itself: 64 frames, L = 8192 tokens per VideoAttention
                                                  # layer (the oracle needs ~25 GB and about a minute on the GPU box's host)
-                                                 pytest.param("gym-full-net-T64", GYM_FULL, 64, True, marks=pytest.mark.slow)])
+                                                 pytest.param("gym-full-net-T64", GYM_FULL, 64, True, marks=pytest.mark.slow),
+                                                 # BASELINE configs[2] at its own length: the 310 M net on 32-frame sequences
+                                                 pytest.param("cs-full-net-T32", CS_FULL, 32, False, marks=pytest.mark.slow)])
 def test_cs_shaped_unet_vs_oracle(tag, cfg, Tn, labelled):
     """One 3-D training step (loss + every weight gradient) against the fp32 oracle on the same parameters and noise.
     cs-shaped: Counter-Strike topology (cs_train.py:35-45) at reduced width: 32x32 latents, video attention at 4x4
