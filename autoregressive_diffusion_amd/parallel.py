@@ -389,9 +389,15 @@ class OnirisDDP(nn.Module):
 
     def _exchange_mesh(self, lo, hi, world):
         """Reduce-scatter of segment [lo, hi) as ONE all-to-all (chunk r goes straight to rank r) + a local sum; the
-        averaged chunk this rank owns lands in its place of the flat gradient buffer (the other chunks keep this rank's
-        local, un-reduced values: nothing reads them -- the optimizer runs on the owned ranges only)."""
+        averaged chunk this rank owns lands in `flat.grad_reduced` (laid out like the flat buffers; only the owned ranges
+        are ever written or read: the optimizer runs on them).  `flat.grad` itself stays purely LOCAL: an exchange that
+        is not followed by zero_grad -- the reference loop's micro-step 0, cs_train.py:108,119: a synced backward with no
+        optimizer step -- is followed by more local accumulation and another exchange, which must again see every
+        rank's own sum (a reduced chunk left in place would be sent around a second time)."""
         g = self.flat.grad
+        if getattr(self.flat, "grad_reduced", None) is None:
+            self.flat.grad_reduced = torch.zeros_like(g)
+        red = self.flat.grad_reduced
         rank = dist.get_rank(self.process_group)
         n = hi - lo
         assert n % world == 0, "segments are SEG_ALIGN-aligned: divisible by every world size up to 8"
@@ -408,7 +414,7 @@ class OnirisDDP(nn.Module):
         w = dist.all_to_all_single(recv, send, group=self.process_group, async_op=True)
 
         def fin(recv=recv, lo=lo, chunk=chunk, world=world, rank=rank):
-            own = g[lo + rank * chunk: lo + (rank + 1) * chunk]
+            own = red[lo + rank * chunk: lo + (rank + 1) * chunk]
             torch.sum(recv.view(world, chunk).float() if recv.dtype != g.dtype else recv.view(world, chunk), dim=0, out=own)
             own.mul_(1.0 / world)
         self._works.append((w, fin))
@@ -461,6 +467,25 @@ class OnirisDDP(nn.Module):
             chunk = (hi - lo) // world
             mine = p[lo + rank * chunk: lo + (rank + 1) * chunk].clone()       # (input must not alias the output)
             dist.all_gather_into_tensor(p[lo:hi], mine, group=self.process_group)
+
+    def _allgather_like_params(self, buf):
+        world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+        for lo, hi in [self.flat.head] + [(a, b) for _, a, b in self.flat.stages]:
+            if hi <= lo:
+                continue
+            chunk = (hi - lo) // world
+            mine = buf[lo + rank * chunk: lo + (rank + 1) * chunk].clone()
+            dist.all_gather_into_tensor(buf[lo:hi], mine, group=self.process_group)
+
+    def gather_state(self, optimizer):
+        """mesh mode, COLLECTIVE (every rank calls it): complete the optimizer moments on every rank so that
+        `optimizer.state_dict()` -- which the reference loop calls on rank 0 only, cs_train.py:146-159 -- describes all
+        parameters.  Valid until the next optimizer step.  A no-op for exchange="allreduce" (the state is replicated)."""
+        if self.exchange == "mesh" and self._active():
+            with torch.no_grad():
+                self._allgather_like_params(optimizer.m)
+                self._allgather_like_params(optimizer.v)
+        optimizer._state_complete_at = optimizer.steps
 
     def wait(self):
         """Block the current stream until the gradient exchange is done (call before the optimizer step)."""
@@ -577,6 +602,10 @@ class FlatAdamW:
         """torch.optim.AdamW's layout (what gym_train.py:137-138 saves): per-parameter `step` / `exp_avg` /
         `exp_avg_sq`, indexed in module.parameters() order, + param_groups."""
         f = self.flat
+        if getattr(f, "_owned_ranges", None) is not None and getattr(self, "_state_complete_at", None) != self.steps:
+            raise RuntimeError("FlatAdamW.state_dict(): under OnirisDDP(exchange='mesh') every rank holds exp_avg / exp_avg_sq "
+                               "of its OWN chunks only; call OnirisDDP.gather_state(optimizer) on EVERY rank first (a "
+                               "collective), then state_dict() on whichever rank writes the checkpoint")
         pos = {id(p): k for k, p in enumerate(f.params)}
         st = {}
         for i, p in enumerate(f.orig_params):
@@ -644,36 +673,58 @@ class FlatAdamW:
                         cut.append([x, y, st])
             runs = cut
         norm_reduce = getattr(f, "_norm_reduce", None)
-        if f.flat.is_cuda:
-            from . import ops
-            if max_norm is not None:
-                if self._norm_buf is None:
-                    self._norm_buf = torch.zeros(1 + ops.SQNORM_WS, dtype=torch.float32, device=f.flat.device)
-                if owned is None:
-                    ops.sqnorm_(f.grad, self._norm_buf)    # over the whole buffer (parameters without gradient hold zeros)
-                else:                                      # sum of squares of the owned (reduced) chunks, then over the ranks
-                    tot = torch.zeros(1, dtype=torch.float32, device=f.flat.device)
-                    for a, b in owned:
-                        ops.sqnorm_(f.grad[a:b], self._norm_buf)
-                        tot += self._norm_buf[:1]
-                    self._norm_buf[:1].copy_(norm_reduce(tot))
-            for lo, hi, st in runs:
-                if st == 0 and not ema:
-                    continue
-                ops.adamw_(f.flat[lo:hi], f.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
-                           self.betas[1], self.eps, self.weight_decay, st, grad_scale, max_norm, self._norm_buf,
-                           [(e[lo:hi], w) for e, w in ema], norm_ready=True)
-        else:
+        # mesh exchange: the reduced gradients of the owned chunks live in f.grad_reduced (f.grad stays rank-local)
+        gsrc = self.grad_src = f.grad if owned is None else f.grad_reduced
+        if not f.flat.is_cuda and FlatAdamW.cpu_update is None:
             # No CPU arithmetic in the product path: the host-side LOGIC of this class (runs, per-parameter step counters,
             # owned ranges, state_dict layout) is exercised by the CPU tests with a reference update they install themselves
             # (tests/cpu_reference_optimizer.py); without it CPU tensors are refused.
-            if FlatAdamW.cpu_update is None:
-                raise RuntimeError("FlatAdamW needs HIP tensors (no CPU fallback in the product path; the CPU tests "
-                                   "install tests/cpu_reference_optimizer.py)")
-            FlatAdamW.cpu_update(self, runs, grad_scale, max_norm, ema, owned, norm_reduce)
+            raise RuntimeError("FlatAdamW needs HIP tensors (no CPU fallback in the product path; the CPU tests "
+                               "install tests/cpu_reference_optimizer.py)")
+
+        def update(runs_, max_norm_):
+            if not f.flat.is_cuda:
+                return FlatAdamW.cpu_update(self, runs_, grad_scale, max_norm_, ema, owned, norm_reduce)
+            from . import ops
+            for lo, hi, st in runs_:
+                if st == 0 and not ema:
+                    continue
+                ops.adamw_(f.flat[lo:hi], gsrc[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
+                           self.betas[1], self.eps, self.weight_decay, st, grad_scale, max_norm_, self._norm_buf,
+                           [(e[lo:hi], w) for e, w in ema], norm_ready=True)
+
+        if f.flat.is_cuda and max_norm is not None:
+            from . import ops
+            if self._norm_buf is None:
+                self._norm_buf = torch.zeros(1 + ops.SQNORM_WS, dtype=torch.float32, device=f.flat.device)
+            if owned is None:
+                ops.sqnorm_(gsrc, self._norm_buf)          # over the whole buffer (parameters without gradient hold zeros)
+            else:                                          # sum of squares of the owned (reduced) chunks, then over the ranks
+                tot = torch.zeros(1, dtype=torch.float32, device=f.flat.device)
+                for a, b in owned:
+                    ops.sqnorm_(gsrc[a:b], self._norm_buf)
+                    tot += self._norm_buf[:1]
+                self._norm_buf[:1].copy_(norm_reduce(tot))
+        update(runs, max_norm)
         after = getattr(f, "_after_step", None)
         if after is not None:
             after()
+        if owned is not None:
+            # mesh exchange: m / v exist for the owned chunks only (state_dict() refuses until OnirisDDP.gather_state() has
+            # collected them); the EMA copies are a function of the parameter trajectory alone, so every rank brings its
+            # copies of the OTHER ranks' chunks up to date from the parameters the all-gather just delivered -- an EMA-only
+            # pass (step 0) over the complement of the owned ranges: rank 0 can write the reference's checkpoint
+            # (phema.py:110, cs_train.py:146-159) without any collective
+            self._state_complete_at = None
+            if ema:
+                rest, pos = [], 0
+                for a, b in sorted(owned):
+                    if a > pos:
+                        rest.append([pos, a, 0])
+                    pos = max(pos, b)
+                if pos < f.numel:
+                    rest.append([pos, f.numel, 0])
+                update(rest, None)
 
     def zero_grad(self):
         self.flat.zero_grad()

@@ -6,17 +6,18 @@ import torch
 
 def cpu_update(opt, runs, grad_scale, max_norm, ema, owned, norm_reduce):
     f = opt.flat
+    grad = getattr(opt, 'grad_src', f.grad)      # (mesh exchange: the reduced chunks live in f.grad_reduced)
     b1, b2 = opt.betas
     coef = 1.0
     if max_norm is not None:
         if owned is None:
-            sq = (f.grad * grad_scale).pow(2).sum().reshape(1)
+            sq = (grad * grad_scale).pow(2).sum().reshape(1)
         else:
-            sq = norm_reduce(sum((f.grad[a:b] * grad_scale).pow(2).sum() for a, b in owned).reshape(1))
+            sq = norm_reduce(sum((grad[a:b] * grad_scale).pow(2).sum() for a, b in owned).reshape(1))
         coef = min(1.0, max_norm / (float(sq.sqrt()) + 1e-6))
     for lo, hi, st in runs:
         if st:
-            g = f.grad[lo:hi] * (grad_scale * coef)
+            g = grad[lo:hi] * (grad_scale * coef)
             opt.m[lo:hi].mul_(b1).add_(g, alpha=1 - b1)
             opt.v[lo:hi].mul_(b2).addcmul_(g, g, value=1 - b2)
             mh, vh = opt.m[lo:hi] / (1 - b1 ** st), opt.v[lo:hi] / (1 - b2 ** st)

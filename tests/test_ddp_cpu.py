@@ -437,3 +437,81 @@ def test_ddp_stages_and_exchange_modes(exchange, bf16, clip):
     tol = 2e-3 if bf16 else 2e-6
     for k, v in ref.state_dict().items():
         assert torch.allclose(torch.from_numpy(sd0[k]), v, atol=tol), (k, (torch.from_numpy(sd0[k]) - v).abs().max())
+
+
+def _mesh_state_worker(rank, world, port, q, exchange):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autoregressive_diffusion_amd.parallel import OnirisDDP, FlatAdamW, FlatParams, FlatEMA
+    torch.manual_seed(300 + rank)
+    net = MultiStageNet()
+    flat = FlatParams(net)
+    ddp = OnirisDDP(net, flat=flat, bucket_mb=1e-4, exchange=exchange)
+    opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.01)
+    ema = FlatEMA(flat, stds=(0.05, 0.1))
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(7, 2, 5, 6, generator=g)           # [micro-step][rank][batch][features]
+    K = 3
+    # the reference loop's cadence (cs_train.py:105-127): a synced backward at i % K == 0 -- at i = 0 with NO optimizer step
+    # and NO zero_grad behind it -- and no_sync() accumulation in between
+    import contextlib
+    for i in range(7):
+        sync = i % K == 0
+        with (contextlib.nullcontext() if sync else ddp.no_sync()):
+            out, _ = ddp(data[i, rank]); out.pow(2).mean().backward()
+        if sync:
+            ddp.wait()
+            if i != 0:
+                opt.step(ema=ema.weights(8 * i, 8 * K))
+                opt.zero_grad()
+    refused = False
+    if exchange == "mesh":
+        try:
+            opt.state_dict()
+        except RuntimeError as e:
+            refused = "gather_state" in str(e)
+    ddp.gather_state(opt)                                 # collective
+    osd = opt.state_dict() if rank == 0 else None         # ... then rank 0 alone writes the checkpoint
+    esd = ema.state_dict() if rank == 0 else None
+    q.put((rank, refused, flat.flat.numpy().copy(),
+           None if osd is None else {i: {k: v.numpy().copy() for k, v in s.items()} for i, s in osd["state"].items()},
+           None if esd is None else [{k: v.numpy().copy() for k, v in sd.items()} for sd in esd["emas"]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["mesh", "allreduce"])
+def test_mesh_mode_checkpoint_state_and_accumulation_cadence(exchange):
+    """(1) with exchange="mesh" the optimizer runs on the owned chunks only -- the EMA copies must still be
+    complete on every rank and the Adam moments after gather_state(), so that rank 0's checkpoint (cs_train.py:146-159) equals
+    a single process's; (2) an exchange that is not followed by zero_grad (micro-step 0 of the reference loop) must not
+    leave reduced values in the local gradient buffer: both exchange forms give avg(sum of micro-gradients)."""
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW, FlatEMA
+    res = _run2(_mesh_state_worker, exchange)
+    (_, ref0, p0, osd, esd), (_, ref1, p1, _, _) = res
+    assert (p0 == p1).all(), "ranks diverged"
+    if exchange == "mesh":
+        assert ref0 and ref1, "state_dict() before gather_state() must be refused in mesh mode"
+    # single process: same cadence on the mean of the two ranks' gradients, this repository's optimizer classes unsharded
+    torch.manual_seed(300)
+    net = MultiStageNet()
+    flat = FlatParams(net)
+    opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.01)
+    ema = FlatEMA(flat, stds=(0.05, 0.1))
+    g = torch.Generator().manual_seed(11)
+    data = torch.randn(7, 2, 5, 6, generator=g)
+    for i in range(7):
+        for r in range(2):
+            out, _ = net(data[i, r]); (out.pow(2).mean() / 2).backward()
+        if i % 3 == 0 and i != 0:
+            opt.step(ema=ema.weights(8 * i, 24))
+            opt.zero_grad()
+    assert torch.allclose(torch.from_numpy(p0), flat.flat, atol=2e-6), (torch.from_numpy(p0) - flat.flat).abs().max()
+    want_o, want_e = opt.state_dict(), ema.state_dict()
+    assert set(osd) == set(want_o["state"])
+    for i, s in want_o["state"].items():
+        for k in ("step", "exp_avg", "exp_avg_sq"):
+            assert torch.allclose(torch.from_numpy(osd[i][k]), s[k], atol=2e-6), (i, k)
+    for got, want in zip(esd, want_e["emas"]):
+        for k, v in want.items():
+            assert torch.allclose(torch.from_numpy(got[k]), v, atol=2e-6), k
