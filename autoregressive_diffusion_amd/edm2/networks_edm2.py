@@ -206,7 +206,7 @@ class UNet(BetterModule):
             cs = dict(zip(map(id, blocks), ops.emb_scales(emb, self.__dict__["_oniris_groups"][0], gains)))
             skips = []
             # one GradSlot per encoder output (training): it is read by the next block AND by a decoder block (skip)
-            use_slots = torch.is_grad_enabled() and self.training
+            use_slots = torch.is_grad_enabled() and self.training and ops.GRAD_SLOTS
             slot = None
             stage_hooks = self.__dict__.get("_oniris_stage_hooks") or {}    # OnirisDDP: {("enc" | "dec", name): tensor hook}
             for name, block in self.enc.items():

@@ -173,7 +173,9 @@ def _fused_frame(net, graphed, cache, conditioning, t_steps, x0, B, num_steps):
 @torch.no_grad()
 def edm_sampler_with_mse(net, cache, target=None, gnet=None, conditioning=None, num_steps=32, sigma_min=0.002,
                          sigma_max=80, rho=7, guidance=1, S_churn=0, S_min=0, S_max=float("inf"), S_noise=1,
-                         dtype=torch.float32, noise=None):
+                         dtype=torch.float32, noise=None, churn_noise=None):
+    """Reference signature (edm2/sampler.py:12-18) + two optional inputs for reproducible runs: `noise` (B,1,C,H,W) replaces
+    the initial torch.randn draw, `churn_noise[k]` the torch.randn_like draw of step k's noise injection (S_churn > 0)."""
     was_training = net.training
     net.eval()
     B, _, C, H, W = cache.get("shape", (None,) * 5)
@@ -219,7 +221,8 @@ def edm_sampler_with_mse(net, cache, target=None, gnet=None, conditioning=None, 
         if S_churn > 0 and S_min <= t_cur <= S_max:
             gamma = min(S_churn / num_steps, np.sqrt(2) - 1)
             t_hat = t_cur + gamma * t_cur
-            x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * S_noise * torch.randn_like(x_cur)
+            x_hat = x_cur + (t_hat ** 2 - t_cur ** 2).sqrt() * S_noise * (churn_noise[k] if churn_noise is not None else
+                                                                          torch.randn_like(x_cur))
         else:
             t_hat, x_hat = t_cur, x_cur
         x_pred, cache = denoise(x_hat, t_hat, cache, update_cache=(k == num_steps - 1 and target is None))

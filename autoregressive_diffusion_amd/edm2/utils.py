@@ -105,7 +105,13 @@ class BetterModule(nn.Module):
         gradient from the parameter's AccumulateGrad node; the conv / attention weight gradients of this net are written
         into `.grad` through raw pointers by ONE kernel after the backward pass (weights.hip: weight_bwd_kernel), so torch
         DDP would wait for them forever or, worse, exchange stale buffers.  Refuse loudly (cs_train.py:53-54 becomes
-        `OnirisDDP(unet)`: same `.module`, `no_sync()`, broadcast at construction)."""
+        `OnirisDDP(unet)`: same `.module`, `no_sync()`, broadcast at construction).
+        Every OTHER reader (inspect.getmembers, hasattr, debuggers, attribute-copying wrappers) sees a plain missing
+        attribute: the error is raised only when the caller is torch's distributed.py."""
+        import sys
+        caller = sys._getframe(1).f_code.co_filename.replace("\\", "/")
+        if not caller.endswith("torch/nn/parallel/distributed.py"):
+            raise AttributeError("_ddp_params_and_buffers_to_ignore")
         raise RuntimeError(
             "torch.nn.parallel.DistributedDataParallel cannot reduce the gradients of this network: its weight gradients "
             "are written by a HIP kernel at the end of backward, not by autograd.  Use "

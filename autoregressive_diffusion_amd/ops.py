@@ -328,6 +328,7 @@ class WeightBank:
         self._ensure()
         if training or torch.is_grad_enabled():        # (a no_grad evaluation -- the rollout -- never takes from the arena)
             self.zero_arena.reset(self.items[0][0].param.device)   # the previous step's backward is done with its accumulators
+            GradSlot.live = []
         global _weights_epoch
         if training:
             _weights_epoch += 1                        # parameters are rewritten in place (forced normalisation)
@@ -348,7 +349,6 @@ class WeightBank:
         # released -- `loss = model(x); opt.zero_grad(); loss.backward()` with torch's set_to_none=True -- and the table
         # would still hold the freed .grad pointers (the kernel would write into recycled allocator memory)
         self._ensure()
-        join_side_stream()                             # every wgrad kernel (possibly on the side stream) is ordered before
         check(lib.oniris_weight_bwd(_p(self._dev_table), len(self.items), self.total_rows, _stream()), "weight_bwd")
         self.nsplit_all.zero_()        # the slabs are consumed: a second backward() must not add them again
 
@@ -366,13 +366,13 @@ class WeightBank:
         self.backward()
         for h in self.post_backward_hooks:
             h()
+        GradSlot.check_all_taken()
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # convolution
 
 import os as _os
-WGRAD_SIDE_STREAM = int(_os.environ.get("ONIRIS_WGRAD_STREAM", "0"))   # opt-in: weight-gradient kernels on a second HIP stream (round 1: 1-2 % slower; end of round 2: +1.0-1.3 % in same-box A/Bs, but one unexplained failure of a graph-vs-eager test in four runs of the suite with it on -- stays off until that is understood)
 FUSED_ROPE = int(_os.environ.get("ONIRIS_FUSED_ROPE", "1"))        # 0: qkv normalisation and the two rotations as three launches (A/B, tests)
 ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
 ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
@@ -380,6 +380,7 @@ ATTN_DKV_PERSISTENT = int(_os.environ.get("ONIRIS_DKV_PERSISTENT", "1"))   # 0: 
 ATTN_DQ_PERSISTENT = int(_os.environ.get("ONIRIS_DQ_PERSISTENT", "1"))      # 0: VideoAttention dQ through the grid kernel
 WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
 BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (see OnirisConvArgs.big_tile)
+GRAD_SLOTS = int(_os.environ.get("ONIRIS_GRAD_SLOTS", "1"))  # 0: skip / residual gradients are joined by autograd (A/B, partial backward)
 
 
 class KernelProfile:
@@ -398,11 +399,13 @@ class KernelProfile:
         torch.cuda.synchronize()
         agg = {}
         for key, flops, e0, e1, *rest in cls.records:
-            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0))
+            a = agg.setdefault(key, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0, t_min=0.0))
             a["launches"] += 1
             a["flops"] += flops
             a["ms"] += e0.elapsed_time(e1)
             a["bytes"] += rest[0] if rest else 0.0
+            # roofline time of the launch (seconds): SURVEY 8d's max(FLOPs / bf16 MFMA peak, algorithmic bytes / 6.3 TB/s)
+            a["t_min"] += max(flops / 2.5e15, (rest[0] if rest else 0.0) / 6.3e12)
         cls.records = []
         return agg
 
@@ -535,9 +538,8 @@ def _wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_s
     return a
 
 
-def _wgrad_launch_group(arglist, keep=None):
-    """One launch for 1..3 weight-gradient problems of the same geometry (oniris_conv_wgrad_group).
-    keep: the tensors the kernel reads (needed when it is queued on the side stream)."""
+def _wgrad_launch_group(arglist):
+    """One launch for 1..3 weight-gradient problems of the same geometry (oniris_conv_wgrad_group)."""
     if KernelProfile.enabled:
         a0 = arglist[0]
         tile = 2 if (a0.Cin > 32 and a0.Cout > 32) else 1
@@ -552,47 +554,18 @@ def _wgrad_launch_group(arglist, keep=None):
         flops = sum(2.0 * a.B * a.T * a.H * a.W * a.Cout * a.Cin * a.taps for a in arglist)
         KernelProfile.enabled = False
         try:
-            e0, e1 = _timed_launch(lambda: _wgrad_launch_group(arglist))          # (profiled launches stay on the main stream)
+            e0, e1 = _timed_launch(lambda: _wgrad_launch_group(arglist))
         finally:
             KernelProfile.enabled = True
         KernelProfile.records.append((key, flops, e0, e1))
         return
     arr = (_lib.WgradArgs * len(arglist))(*arglist)
-    if WGRAD_SIDE_STREAM and keep is not None and not torch.cuda.is_current_stream_capturing():
-        # Weight gradients are off the critical path (only weight_bwd at the end of backward consumes the slabs): on
-        # a second HIP stream they fill the CUs that the dgrad / elementwise kernels of the main stream leave idle at
-        # their heads and tails (consecutive kernels of ONE stream never overlap).
-        main = torch.cuda.current_stream()
-        side = _side_stream(main.device)
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            check(lib.oniris_conv_wgrad_group(arr, len(arglist), _stream()), "conv_wgrad")
-        for t in keep:
-            if t is not None:
-                t.record_stream(side)           # the caching allocator must not recycle it before the side kernel ran
-        return
     check(lib.oniris_conv_wgrad_group(arr, len(arglist), _stream()), "conv_wgrad")
-
-
-_side_streams = {}
-
-
-def _side_stream(device):
-    s = _side_streams.get(device)
-    if s is None:
-        s = _side_streams[device] = torch.cuda.Stream(device=device)
-    return s
-
-
-def join_side_stream():
-    """Make the current stream wait for everything queued on the weight-gradient stream."""
-    for dev, s in _side_streams.items():
-        torch.cuda.current_stream(dev).wait_stream(s)
 
 
 def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
     _wgrad_launch_group([_wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff,
-                                     fill, tap0)], keep=(x, dy, scale))
+                                     fill, tap0)])
 
 
 class ConvCfg:
@@ -727,7 +700,7 @@ class _ConvOp(torch.autograd.Function):
                     grp.append(_wgrad_args(x, dy3, pw3, None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T, coff,
                                            1.0, tap0=9 * j))
             if grp:
-                _wgrad_launch_group(grp, keep=(x, dout, dy3, ca))
+                _wgrad_launch_group(grp)
         else:
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
@@ -830,9 +803,25 @@ class GradSlot:
     it inside its own backward kernel (`dadd` of oniris_act_bwd / `add` of oniris_resample / the mp_sum epilogue of the
     1x1 dgrad).  One slot per skip tensor and per forward pass."""
     __slots__ = ("g",)
+    live = []            # the slots of the current forward pass (cleared by WeightBank.prepare, checked at the end of backward)
 
     def __init__(self):
         self.g = None
+        GradSlot.live.append(self)
+
+    @classmethod
+    def check_all_taken(cls):
+        """End of backward: a slot that is still filled means its encoder-side consumer never ran -- a PARTIAL backward
+        (torch.autograd.grad on decoder-side inputs only, a graph cut before the consumer) -- and the skip gradient would
+        be dropped silently.  ONIRIS_GRAD_SLOTS=0 routes these gradients through autograd instead."""
+        left = sum(1 for s in cls.live if s.g is not None)
+        for s in cls.live:
+            s.g = None
+        cls.live = []
+        if left:
+            raise RuntimeError(f"{left} skip-connection gradient(s) were parked for an encoder-side backward kernel that "
+                               "never ran (partial backward through the UNet?): they would have been dropped.  Run the "
+                               "whole backward, or set ONIRIS_GRAD_SLOTS=0 to let autograd join these gradients")
 
     def put(self, g):
         self.g = g if self.g is None else self.g + g

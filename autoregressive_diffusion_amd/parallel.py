@@ -32,7 +32,7 @@ class ParamPack:
 class FlatParams:
     """Re-homes every trainable parameter of `module` (and its .grad) as a view into one flat fp32 buffer."""
 
-    _registry = {}                 # id(parameter) -> weakref to the FlatParams that re-homed it (graphs.GraphedStep)
+    _registry = {}                 # id(parameter) -> weakref to the FlatParams that re-homed it (ops.direct_pack)
     SEG_ALIGN = 3360               # = 2^5 * 3 * 5 * 7 elements: a segment splits evenly, in 16-byte units, over 1..8 ranks
 
     _instances = None              # WeakSet of the live FlatParams
@@ -207,18 +207,6 @@ class FlatParams:
                 out.append(True)
         got.clear()
         return out
-
-    def snapshot_touched(self):
-        """Host-side gradient bookkeeping of the backward that just ran (for graphs.GraphedStep: a replay runs no Python):
-        the weights a weight-gradient launch targeted and the parameters a fused backward delivered into the flat buffer."""
-        return ([m.pw for m in self._owner.values() if getattr(m, "pw", None) is not None and m.pw.touched],
-                [i for i in self._got if i in self._direct])
-
-    def restore_touched(self, snap):
-        pws, got = snap
-        for pw in pws:
-            pw.touched = True
-        self._got.update(got)
 
     def check(self):
         """True while every parameter still aliases the flat buffers (a .to()/deepcopy breaks the aliasing)."""

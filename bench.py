@@ -32,32 +32,45 @@ CS_CFG = dict(img_resolution=32, img_channels=8, label_dim=4, model_channels=128
               frame_attn_resolutions=[8])                       # cs_train.py:35-45 (BASELINE configs 3/4), 310.0 M
 
 
+def _git_blob_sha1(path):
+    """The git blob id of a file's bytes (what `git hash-object` prints), so that the JSON line names the exact committed
+    PMC summary its `traffic` figure was read from."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
 def _pmc_traffic(key):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/rNN_pmc_traffic.json of the latest round:
-    separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench, summarised by
-    scratch/pmc_traffic.py with the gfx950 correction 2*FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be collected
-    from inside the timed process, so the number is only as fresh as that file; None when the kernel is not in it."""
+    """(HBM bytes per launch of kernel `key`, source) from the committed PMC passes (profiles/rNN_pmc_traffic.json of the
+    latest round: separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this same bench, summarised by
+    scratch/pmc_traffic.py with the gfx950 correction 2*FETCH_SIZE + WRITE_SIZE).  PMC counters cannot be collected from
+    inside the timed process, so the number is only as fresh as that file: `source` = {file, git_blob} says which one it
+    was.  (None, source) when the kernel is not in it."""
     import re
     prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
     path = next((p for p in (os.path.join(prof, f"r{r:02d}_pmc_traffic.json") for r in range(9, 0, -1)) if os.path.exists(p)), None)
     if path is None:                                             # (the newest round's passes)
-        return None
+        return None, None
     try:
         table = json.load(open(path))
+        source = {"file": os.path.relpath(path, ROOT), "git_blob": _git_blob_sha1(path),
+                  "note": "committed rocprofv3 --pmc passes of this bench (not collected in this run)"}
     except Exception:
-        return None
+        return None, None
     name = key.split("<")[0]
     want = [int(v) for v in re.findall(r"=(\d+)", key)]          # template arguments in KernelProfile's key order
     for k, v in table.items():
         if name in k:
             have = [int(x) if x.isdigit() else (1 if x == "true" else 0) for x in re.findall(r"[<,]\s*(\d+|true|false)", k)]
             if have[:len(want)] == want:
-                return v["hbm_bytes_per_launch"]
-    return None
+                return v["hbm_bytes_per_launch"], source
+    return None, source
 
 
 MFMA_BF16_PEAK = 2.5e15          # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
-# algorithmic forward FLOPs per sample of the 3-D step at T=64 (BASELINE.md section 4): 1.82 TFLOP; x3 fwd+bwd
+HBM_ACHIEVABLE = 6.3e12          # B/s, the figure SURVEY 8d / BASELINE.md section 3 price memory-bound layers with
+# algorithmic forward FLOPs per sample of the 3-D step (BASELINE.md section 4); x3 forward + backward
+ALGO_FWD_FLOPS = {("gym", 64): 1.82e12, ("cs", 32): 2.58e12, ("cs", 64): 5.16e12}
 
 
 C1_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=16, channel_mult=[1, 2, 4, 8], num_blocks=1,
@@ -107,7 +120,7 @@ def cpu_baseline(frames):
                                f"{dt1:.2f} s"))
 
 
-def rollout(args):
+def rollout(args, quiet=False):
     """BASELINE config 5: edm2/sampler.py autoregressive rollout with KV / activation caches (plotting.py:163-166
     settings: num_steps=16, rho=2, sigma in [0.01, 80], S_churn=0, guidance=1 -> 31 UNet evaluations per frame)."""
     import torch
@@ -134,10 +147,13 @@ def rollout(args):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     evals = 31 * args.gen_frames
-    print(json.dumps({"metric": "rollout generated frames/s (config 5, KV-cached sampler)", "value": B * args.gen_frames / dt,
-                      "unit": "frames/s", "n_gpus": 1, "ms_per_unet_eval": dt / evals * 1e3, "frames_generated": args.gen_frames,
-                      "context_frames": ctx_frames + 2, "batch": B, "dtype": "bf16", "data": "synthetic",
-                      "finite": bool(torch.isfinite(x).all())}))
+    out = {"metric": "rollout generated frames/s (config 5, KV-cached sampler)", "value": B * args.gen_frames / dt,
+           "unit": "frames/s", "n_gpus": 1, "ms_per_unet_eval": dt / evals * 1e3, "frames_generated": args.gen_frames,
+           "context_frames": ctx_frames + 2, "batch": B, "dtype": "bf16", "data": "synthetic",
+           "finite": bool(torch.isfinite(x).all())}
+    if not quiet:
+        print(json.dumps(out))
+    return out
 
 
 def self_launch(args):
@@ -159,22 +175,62 @@ def self_launch(args):
     return subprocess.run(cmd, env=env).returncode
 
 
+class Watchdog:
+    """Multi-rank runs only: a daemon thread that ends THIS rank with a non-zero exit code and the name of the stage it
+    was in when no progress has been reported for `limit` seconds -- a hung collective (a rank that died, a mismatched
+    exchange) otherwise blocks the whole job until the driver's timeout with nothing to read.  os._exit from the thread:
+    no re-exec, no signal to other processes; torch.distributed.run then takes the other ranks down."""
+
+    def __init__(self, rank, limit):
+        import threading
+        self.rank, self.limit, self.stage, self.t = rank, limit, "start", time.monotonic()
+        self._stop = False
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        if limit > 0:
+            self.thread.start()
+
+    def beat(self, stage):
+        self.stage, self.t = stage, time.monotonic()
+
+    def stop(self):
+        self._stop = True
+
+    def _run(self):
+        while not self._stop:
+            time.sleep(1.0)
+            idle = time.monotonic() - self.t
+            if idle > self.limit and not self._stop:
+                print(f"bench.py watchdog: rank {self.rank} made no progress for {idle:.0f} s in stage '{self.stage}' "
+                      f"(hung collective / dead peer?) -- exiting 124", file=sys.stderr, flush=True)
+                os._exit(124)
+
+
 def dry_run(args, rank, world):
     """--dry-run: only the multi-rank plumbing of this script (rendezvous, barrier, max-over-ranks timing, rank 0's JSON
-    line) on the gloo backend with no GPU -- what the CPU test of the launcher path runs (tests/test_bench_launch.py)."""
+    line, the watchdog) on the gloo backend with no GPU -- what the CPU test of the launcher path runs
+    (tests/test_bench_launch.py)."""
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    wd = Watchdog(rank, args.watchdog)
+    wd.beat("init_process_group(gloo)")
     dist.init_process_group("gloo", init_method="env://")
+    wd.beat("first barrier")
     dist.barrier()
     if os.environ.get("ONIRIS_DRY_RUN_FAIL_RANK") == str(rank):     # (test hook: a rank that dies after the rendezvous)
         os._exit(3)
+    if os.environ.get("ONIRIS_DRY_RUN_HANG_RANK") == str(rank):     # (test hook: a rank that stops answering)
+        wd.stop()
+        time.sleep(3600)
     t0 = time.perf_counter()
     tt = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    wd.beat("all_reduce(MAX) of the step time")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     ranks = [None] * world
     dist.all_gather_object(ranks, (rank, int(os.environ.get("LOCAL_RANK", "0"))))
+    wd.beat("last barrier")
     dist.barrier()
+    wd.stop()
     if rank == 0:
         print(json.dumps({"metric": "dry run (launcher plumbing only, NOT a measurement)", "value": 0.0, "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "rccl_world": dist.get_world_size(), "backend": "gloo",
@@ -193,6 +249,286 @@ def _claim_stdout():
     sys.stdout = os.fdopen(keep, "w", buffering=1)
 
 
+def train(args, netname, steps, warmup, rank, world, dev, wd, light=False):
+    """The timed training job on this rank: build the net, W warm-up + K timed steps between fences, max over ranks.
+    light: an extra measurement inside the headline run (no per-kernel profile, no CPU baseline): {frames_s, ms_per_step, ...}.
+    Returns the JSON record (rank 0) or None."""
+    import torch
+    import torch.distributed as dist
+    from edm2.networks_edm2 import UNet, Precond
+    from edm2.loss import EDM2Loss
+    from autoregressive_diffusion_amd.parallel import FlatParams, OnirisDDP, FlatAdamW, FlatEMA
+    from autoregressive_diffusion_amd import ops
+
+    force_dist = bool(os.environ.get("ONIRIS_FORCE_DIST"))          # debug: run the RCCL/DDP path with a single rank
+    share = bool(os.environ.get("ONIRIS_SHARE_GPU"))
+    multi = world > 1 or force_dist
+    rccl_world, devices = 1, [torch.cuda.current_device()]
+    if multi:                                      # what the collective library itself saw (goes into the JSON line)
+        wd.beat("all_gather_object(devices)")
+        rccl_world = dist.get_world_size()
+        devices = [None] * rccl_world
+        dist.all_gather_object(devices, torch.cuda.current_device())
+
+    torch.manual_seed(0)
+    cs = netname == "cs"
+    unet = UNet(**(CS_CFG if cs else GYM_CFG)).to(dev)
+    for m in unet.modules():                      # give the zero-initialised gains a value so every branch carries signal
+        if hasattr(m, "emb_gain"):
+            torch.nn.init.constant_(m.emb_gain, 0.3)
+    torch.nn.init.constant_(unet.out_gain, 1.0)
+    flat = FlatParams(unet, lazy_small=True)
+    # exchange form / transport: ONIRIS_DDP_EXCHANGE=allreduce|mesh, ONIRIS_DDP_BF16=1 (parallel.OnirisDDP; default: fp32 all-reduce per stage)
+    wd.beat("OnirisDDP construction (parameter / buffer broadcast)")
+    model = OnirisDDP(unet, flat=flat, force_collectives=force_dist) if multi else unet
+    net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
+    opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
+    # optimizer side as in the reference loops: clip_grad_norm_(0.1) (gym_train.py:105 only) + AdamW +
+    # PowerFunctionEMA(stds 0.05 / 0.10).update (gym_train.py:108, cs_train.py:121) -- one fused pass
+    ema = FlatEMA(flat, stds=(0.050, 0.100))
+    max_norm = None if cs else 0.1
+    nimg = [0]
+    loss_fn = (EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1) if cs else   # cs_train.py:75
+               EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5))         # gym_train.py:66-67
+
+    B = args.batch
+    T = (args.frames if not light else None) or (32 if cs else 64)
+    g = torch.Generator(device=dev).manual_seed(1234 + rank)
+    res = unet.img_resolution
+    latents = torch.randn(B, T, 8, res, res, device=dev, generator=g)
+    actions = None if cs else torch.randint(0, 4, (B, T), device=dev, generator=g)      # cs_train.py:103 conditioning=None
+
+    _host_t = [0.0, 0.0, 0.0] if os.environ.get("ONIRIS_HOST_TIMING") else None
+    def fwd_bwd(just_2d):
+        opt.zero_grad()
+        if _host_t is None:
+            loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
+            loss.backward()
+            return loss
+        ta, ca_ = time.perf_counter(), time.thread_time()         # ONIRIS_HOST_TIMING: host enqueue time, forward / backward
+        loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
+        tb = time.perf_counter()
+        _host_t[2] += time.thread_time() - ca_                   # CPU time of the forward (wall - CPU = blocked, not computing)
+        loss.backward()
+        _host_t[0] += tb - ta; _host_t[1] += time.perf_counter() - tb
+        return loss
+
+    _only = os.environ.get("ONIRIS_ONLY_MODE")
+
+    accum = max(1, args.accum) if not light else 1
+    from edm2.loss import learning_rate_schedule
+    ref_lr, sched_steps = 1e-2, 100000 / 50                      # gym_train.py:69,110-112 (total_number_of_steps / 50)
+    micro = [0]                                                  # micro-steps taken (the reference's loop index i)
+    comm_events = []                                             # (before, after) model.wait() on the compute stream
+
+    def wait_exchange():
+        """model.wait() makes the compute stream wait for RCCL's: the events around it measure how long the compute stream
+        stood still for communication that the backward pass did not hide (+ the bf16 / mesh finishing passes)."""
+        if comm_events is not None and len(comm_events) < 4096:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); model.wait(); e1.record()
+            comm_events.append((e0, e1))
+        else:
+            model.wait()
+
+    def step(i):
+        just_2d = (i % 4 == 0)                                   # gym_train.py:96
+        if _only:                                                # profiling aid: ONIRIS_ONLY_MODE=2d|3d (not the metric)
+            just_2d = _only == "2d"
+        if accum > 1:
+            return accum_step(just_2d)
+        loss = fwd_bwd(just_2d)
+        if multi:
+            wait_exchange()
+        nimg[0] += world * B
+        opt.step(max_norm=max_norm, ema=ema.weights(nimg[0], world * B))      # t_next = images seen so far (gym_train.py:108)
+        return loss
+
+    def accum_step(just_2d):
+        """One micro-step of the reference loops with accumulation_steps = K (cs_train.py:105-127): backward under
+        no_sync() unless i % K == 0; on those i (except i = 0) optimizer.step, zero_grad, EMA update and the learning-rate
+        schedule written into param_groups."""
+        i = micro[0]
+        micro[0] += 1
+        sync_now = i % accum == 0
+        with (contextlib.nullcontext() if sync_now else model.no_sync()):
+            loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
+            loss.backward()
+        nimg[0] += world * B
+        if sync_now:
+            if multi:
+                wait_exchange()
+            if i != 0:
+                opt.step(max_norm=max_norm, ema=ema.weights(nimg[0], accum * world * B))
+                opt.zero_grad()
+                for g_ in opt.param_groups:
+                    g_["lr"] = learning_rate_schedule(i, ref_lr, sched_steps, sched_steps)
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    tag = f"[{netname}] "
+    dbg = os.environ.get("ONIRIS_DEBUG_LOSS")
+    for i in range(warmup):
+        wd.beat(f"{tag}warm-up step {i}")
+        l_ = step(i)
+        if dbg:
+            print("warmup", i, float(l_.item()), file=sys.stderr)
+    wd.beat(f"{tag}fence before the timed steps")
+    fence()
+    if _host_t:
+        _host_t[0] = _host_t[1] = _host_t[2] = 0.0
+    del comm_events[:]
+    t0 = time.perf_counter()
+    hist = []
+    for i in range(steps):
+        wd.beat(f"{tag}timed step {i}")
+        last = step(i)
+        if dbg == "2":
+            print("timed", i, float(last.item()), file=sys.stderr)
+        if dbg == "3":
+            hist.append(last.detach().clone())
+    t_enq = time.perf_counter() - t0                               # host time to ENQUEUE the K steps (before the fence)
+    wd.beat(f"{tag}fence after the timed steps")
+    fence()
+    if dbg == "3":
+        print("timed losses", [round(float(h.item()), 4) for h in hist], file=sys.stderr)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        wd.beat(f"{tag}all_reduce(MAX) of the step time")
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss_val = float(last.item())
+    exposed = (sum(a.elapsed_time(b) for a, b in comm_events) / max(1, steps)) if (multi and comm_events) else None
+    comm_events = None                                            # (no events in the extra steps below)
+    if light:
+        return dict(frames_s=world * B * T * steps / dt, ms_per_step=dt / steps * 1e3, steps=steps, warmup=warmup,
+                    seq_len=T, seq_per_gpu=B, loss=loss_val,
+                    workload=("Counter-Strike latents, EDM2 UNet 310.0M (cs_train.py:35-45)" if cs else "gym UNet 46.2M")) if rank == 0 else None
+    if os.environ.get("ONIRIS_HOST_TIMING") == "2":
+        from autoregressive_diffusion_amd import _lib as _l
+        tot = sum(v[1] for v in _l.call_stats.values())
+        print(f"C-ABI calls: {sum(v[0] for v in _l.call_stats.values())} calls, {tot * 1e3:.1f} ms in total (whole process)", file=sys.stderr)
+        for k, v in sorted(_l.call_stats.items(), key=lambda kv: -kv[1][1])[:8]:
+            print(f"   {k:28s} n={v[0]:6d}  {v[1] / v[0] * 1e6:7.1f} us/call", file=sys.stderr)
+    if os.environ.get("ONIRIS_HOST_TIMING"):
+        print(f"host enqueue {t_enq / steps * 1e3:.2f} ms/step of {dt / steps * 1e3:.2f} ms/step "
+              f"(forward {_host_t[0] / steps * 1e3:.2f} [cpu {_host_t[2] / steps * 1e3:.2f}], backward {_host_t[1] / steps * 1e3:.2f})", file=sys.stderr)
+
+    # per-mode step times (one 3-D and one 2-D step, timed separately, not part of `value`; median of 3)
+    per_mode = {}
+    for name, i in (("ms_3d_step", 1), ("ms_2d_step", 0)):
+        ts = []
+        for _ in range(3):
+            wd.beat(f"{tag}per-mode step ({name})")
+            fence(); t1 = time.perf_counter(); step(i); fence()
+            ts.append((time.perf_counter() - t1) * 1e3)
+        per_mode[name] = sorted(ts)[1]
+
+    roof, kernels, roof_attn, roof_attn_bwd, roof_step = None, None, None, None, None
+    if rank == 0 and not args.no_profile:
+        # one full 3:1 cycle (eager), every MFMA launch bracketed by HIP events on its own stream; the 2-D step and the three
+        # 3-D steps are aggregated separately (roofline_step is the 3-D step's)
+        agg, agg3 = {}, {}
+        for i in range(4):
+            wd.beat(f"{tag}profiled step {i}")
+            ops.KernelProfile.start()
+            step(i)
+            part = ops.KernelProfile.stop()
+            for k, v in part.items():
+                for tgt in ((agg, agg3) if i % 4 else (agg,)):
+                    a = tgt.setdefault(k, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0, t_min=0.0))
+                    for f_ in ("launches", "flops", "ms", "bytes", "t_min"):
+                        a[f_] += v[f_]
+        kernels = {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
+                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), frac=round(v["flops"] / (v["ms"] * 1e-3) / MFMA_BF16_PEAK, 3))
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:14]}
+        attn = {k: v for k, v in agg.items() if k.startswith("attn_fwd") and "MODE=2" in k}      # VideoAttention forward
+        dom, v = max(((k, v) for k, v in agg.items() if not k.startswith("attn_")), key=lambda kv: kv[1]["ms"])
+        achieved = v["flops"] / (v["ms"] * 1e-3)
+        traffic, traffic_src = _pmc_traffic(dom)
+        roof = dict(bound="mfma", kernel=dom, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
+                    flops_per_launch=v["flops"] / v["launches"], achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12,
+                    unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=traffic, traffic_source=traffic_src,
+                    # operands read once + results written once, mean over the same launches (to set `traffic` against)
+                    algorithmic_bytes=v["bytes"] / v["launches"])
+        if attn:                                                  # the north star's second roofline: VideoAttention forward
+            k, v = max(attn.items(), key=lambda kv: kv[1]["ms"])
+            ach = v["flops"] / (v["ms"] * 1e-3)
+            roof_attn = dict(bound="mfma", kernel=k, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
+                             flops_per_launch=v["flops"] / v["launches"], achieved=ach / 1e12, peak=MFMA_BF16_PEAK / 1e12,
+                             unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK,
+                             note="algorithmic FLOPs = unmasked token pairs x 4 x 64 x heads x B (SURVEY 8d)")
+        # ... and its backward: dQ + dK/dV launches of a layer together, priced on the ALGORITHMIC backward FLOPs = 2.5 x the
+        # forward's (five products S, dP, dV, dK, dQ; the two kernels execute seven: each recomputes S and dP)
+        bq = {k: v for k, v in agg.items() if k.startswith("attn_bwd_dq") and "MODE=2" in k}
+        bkv = {k: v for k, v in agg.items() if k.startswith("attn_bwd_dkv") and "MODE=2" in k}
+        if attn and bq and bkv:
+            fwd = max(attn.values(), key=lambda v: v["ms"])
+            n = fwd["launches"]
+            ms = sum(v["ms"] for v in bq.values()) + sum(v["ms"] for v in bkv.values())
+            fl = 2.5 * fwd["flops"]
+            ach = fl / (ms * 1e-3)
+            roof_attn_bwd = dict(bound="mfma", kernels=sorted(bq) + sorted(bkv), layers=n, avg_layer_ms=ms / n,
+                                 flops_per_layer=fl / n, achieved=ach / 1e12, peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s",
+                                 frac=ach / MFMA_BF16_PEAK,
+                                 note="dQ + dK/dV launches of one VideoAttention layer; algorithmic FLOPs = 2.5 x forward")
+        # the WHOLE 3-D step against the roofline (SURVEY 8d "achieved = sum t_min / t_measured", BASELINE.md section 3/4):
+        # frac = algorithmic FLOPs of a forward + backward step / its wall time / MFMA peak; sum_t_min = the sum over the step's
+        # MFMA launches (conv forward / dgrad / wgrad, attention) of max(FLOPs / MFMA peak, algorithmic bytes / 6.3 TB/s)
+        if agg3:
+            algo = ALGO_FWD_FLOPS.get((netname, T))
+            prof_fl = sum((2.5 / 3.5 if k.startswith("attn_bwd") and "MODE=2" in k else 1.0) * v["flops"] for k, v in agg3.items()) / 3
+            fl = 3.0 * algo * B if algo is not None else prof_fl
+            ms3 = per_mode["ms_3d_step"]
+            tmin = sum(v["t_min"] for v in agg3.values()) / 3 * 1e3
+            mfma_ms = sum(v["ms"] for v in agg3.values()) / 3
+            roof_step = dict(bound="mfma", flops_per_step=fl, flops_source=("BASELINE.md section 4 x 3 x B" if algo is not None else
+                                                                            "sum of the launches' algorithmic FLOPs"),
+                             flops_profiled=prof_fl, ms_3d_step=ms3, achieved=fl / (ms3 * 1e-3) / 1e12, peak=MFMA_BF16_PEAK / 1e12,
+                             unit="TFLOP/s", frac=fl / (ms3 * 1e-3) / MFMA_BF16_PEAK, sum_t_min_ms=tmin, frac_t_min=tmin / ms3,
+                             mfma_kernels_ms=mfma_ms,
+                             note="3-D step (3 of 4 steps; the 2-D step does a third of the work): forward + backward + optimizer; "
+                                  "sum_t_min over its MFMA launches = sum of max(FLOPs / 2.5 PF, algorithmic bytes / 6.3 TB/s); "
+                                  "mfma_kernels_ms = their measured time, the rest of ms_3d_step is elementwise / weight / optimizer "
+                                  "passes and launch boundaries")
+    elif world > 1:
+        for i in range(4):
+            wd.beat(f"{tag}unprofiled cycle step {i} (collectives matched across ranks)")
+            step(i)                                               # keep collectives matched across ranks
+    if rank != 0:
+        return None
+    frames = world * B * T * steps
+    return {"metric": "denoiser-step frames/sec at 1/2/4/8 MI355X; 64-frame Lunar-Lander seq",
+            "value": frames / dt, "unit": "latent-frames/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": dt / steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "rccl_world": rccl_world, "devices": sorted(set(devices)), "device_of_rank": devices,
+            "backend": (dist.get_backend() if multi else None),
+            "ddp": ({"exchange": model.exchange, "grad_dtype": str(model.grad_dtype or "fp32"), "stages": len(flat.stages),
+                     "stage_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for _, lo, hi in flat.stages],
+                     "head_mb": round((flat.head[1] - flat.head[0]) * 4 / 2 ** 20, 1),
+                     "exposed_comm_ms_per_step": exposed,
+                     "exposed_comm_note": "compute-stream time spent inside OnirisDDP.wait() per timed step on rank 0 (HIP events): "
+                                          "what of the gradient exchange the backward pass did not hide"}
+                    if multi else None),
+            "config": {"workload": (f"Counter-Strike latents {T}-frame seq, EDM2 UNet 310.0M (cs_train.py:35-45), " if cs else
+                                    f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), ") +
+                                   f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
+                                   f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
+                       "parallelism": f"dp{world}", "hip_graph": False,
+                       **({"accum_NOT_THE_HEADLINE": accum, "lr": opt.param_groups[0]["lr"]} if accum > 1 else {}),
+                       **({"shared_gpu_gloo_NOT_A_MEASUREMENT": True} if share else {}),
+                       **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
+                       **{k: round(v, 2) for k, v in per_mode.items()}},
+            "loss": loss_val, "roofline": roof, "roofline_step": roof_step, "roofline_attention": roof_attn,
+            "roofline_attention_bwd": roof_attn_bwd, "kernels": kernels}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -203,17 +539,20 @@ def main():
     ap.add_argument("--net", choices=["gym", "cs"], default="gym",
                     help="gym = BASELINE configs[1] (the headline metric); cs = the Counter-Strike net of configs[2]/[3] "
                          "(32x32 latents, 310 M parameters, no conditioning) as an extra measurement")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=64,
+                    help="frames of the CPU-baseline sample: 64 = BASELINE configs[1] at B = 1 (BASELINE.md section 3: about two "
+                         "minutes of host time); smaller = a shorter sample; 0 = skip")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay captured hipGraphs instead of launching eagerly (the step is GPU-bound either way; on ROCm "
-                         "7.0 replays of graphs that contain the 8-wave / 98 KB-LDS conv kernel were observed to be "
-                         "nondeterministic, so eager launch is the default -- DESIGN.md section 8)")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the `extra` records (Counter-Strike T = 32 training steps, a KV-cached rollout) the default "
+                         "1-GPU gym run appends to its JSON line")
     ap.add_argument("--mode", choices=["train", "rollout"], default="train",
                     help="train = the BASELINE headline metric (default); rollout = config 5 (KV-cached sampler), extra line")
     ap.add_argument("--gen-frames", type=int, default=8)
     ap.add_argument("--ctx-frames", type=int, default=8, help="rollout: frames of the prefill (+ 2 warm-up frames) before the timed ones")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--watchdog", type=float, default=120.0,
+                    help="multi-rank runs: seconds without progress after which a rank exits 124 naming its stage (0 = off)")
     ap.add_argument("--accum", type=int, default=1,
                     help="gradient accumulation as in the reference loops (gym_train.py:96-112, cs_train.py:105-127): the optimizer "
                          "(+ clip, EMA, learning-rate schedule) runs every K-th micro-step, the K-1 others run their backward "
@@ -242,246 +581,43 @@ def main():
     share = bool(os.environ.get("ONIRIS_SHARE_GPU"))
     if share:
         local = 0
+    wd = Watchdog(rank, args.watchdog if (world > 1 or force_dist) else 0)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        wd.beat(f"init_process_group({'gloo' if share else 'nccl'}) on device {local}")
         if share:
             dist.init_process_group("gloo", init_method="env://")
         else:
             dist.init_process_group("nccl", init_method="env://", device_id=dev)
-    rccl_world, devices = 1, [torch.cuda.current_device()]
-    if world > 1 or force_dist:                    # what the collective library itself saw (goes into the JSON line)
-        rccl_world = dist.get_world_size()
-        devices = [None] * rccl_world
-        dist.all_gather_object(devices, torch.cuda.current_device())
 
-    from edm2.networks_edm2 import UNet, Precond
-    from edm2.loss import EDM2Loss
-    from autoregressive_diffusion_amd.parallel import FlatParams, OnirisDDP, FlatAdamW, FlatEMA
-    from autoregressive_diffusion_amd import ops
-
-    torch.manual_seed(0)
-    cs = args.net == "cs"
-    unet = UNet(**(CS_CFG if cs else GYM_CFG)).to(dev)
-    for m in unet.modules():                      # give the zero-initialised gains a value so every branch carries signal
-        if hasattr(m, "emb_gain"):
-            torch.nn.init.constant_(m.emb_gain, 0.3)
-    torch.nn.init.constant_(unet.out_gain, 1.0)
-    flat = FlatParams(unet, lazy_small=True)
-    # exchange form / transport: ONIRIS_DDP_EXCHANGE=allreduce|mesh, ONIRIS_DDP_BF16=1 (parallel.OnirisDDP; default: fp32 all-reduce per stage)
-    model = OnirisDDP(unet, flat=flat, force_collectives=force_dist) if (world > 1 or force_dist) else unet
-    net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
-    opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
-    # optimizer side as in the reference loops: clip_grad_norm_(0.1) (gym_train.py:105 only) + AdamW +
-    # PowerFunctionEMA(stds 0.05 / 0.10).update (gym_train.py:108, cs_train.py:121) -- one fused pass
-    ema = FlatEMA(flat, stds=(0.050, 0.100))
-    max_norm = None if cs else 0.1
-    nimg = [0]
-    loss_fn = (EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1) if cs else   # cs_train.py:75
-               EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5))         # gym_train.py:66-67
-
-    B, T = args.batch, args.frames
-    g = torch.Generator(device=dev).manual_seed(1234 + rank)
-    res = unet.img_resolution
-    latents = torch.randn(B, T, 8, res, res, device=dev, generator=g)
-    actions = None if cs else torch.randint(0, 4, (B, T), device=dev, generator=g)      # cs_train.py:103 conditioning=None
-
-    _host_t = [0.0, 0.0, 0.0] if os.environ.get("ONIRIS_HOST_TIMING") else None
-    def fwd_bwd(just_2d):
-        opt.zero_grad()
-        if _host_t is None:
-            loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
-            loss.backward()
-            return loss
-        ta, ca_ = time.perf_counter(), time.thread_time()         # ONIRIS_HOST_TIMING: host enqueue time, forward / backward
-        loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
-        tb = time.perf_counter()
-        _host_t[2] += time.thread_time() - ca_                   # CPU time of the forward (wall - CPU = blocked, not computing)
-        loss.backward()
-        _host_t[0] += tb - ta; _host_t[1] += time.perf_counter() - tb
-        return loss
-
-    use_graph = bool(args.graph)
-    graphed = {}
-    if use_graph:
-        from autoregressive_diffusion_amd.graphs import GraphedStep
-        if world > 1:      # the graph holds forward+backward only; the RCCL exchange is issued eagerly after the replay
-            def make(j2d):
-                def f():
-                    with model.no_sync():
-                        return fwd_bwd(j2d)
-                return f
-        else:
-            def make(j2d):
-                return lambda: fwd_bwd(j2d)
-        graphed = {False: GraphedStep(make(False), params=flat.params, flat=flat),
-                   True: GraphedStep(make(True), params=flat.params, flat=flat)}
-
-    _only = os.environ.get("ONIRIS_ONLY_MODE")
-
-    accum = max(1, args.accum)
-    from edm2.loss import learning_rate_schedule
-    ref_lr, sched_steps = 1e-2, 100000 / 50                      # gym_train.py:69,110-112 (total_number_of_steps / 50)
-    micro = [0]                                                  # micro-steps taken (the reference's loop index i)
-
-    def step(i, profile=False):
-        just_2d = (i % 4 == 0)                                   # gym_train.py:96
-        if _only:                                                # profiling aid: ONIRIS_ONLY_MODE=2d|3d (not the metric)
-            just_2d = _only == "2d"
-        if accum > 1:
-            return accum_step(just_2d)
-        if use_graph and not profile:
-            loss = graphed[just_2d]()
-            if world > 1:
-                model.allreduce_grads()
-        else:
-            loss = fwd_bwd(just_2d)
-        if world > 1 or force_dist:
-            model.wait()
-        nimg[0] += world * B
-        opt.step(max_norm=max_norm, ema=ema.weights(nimg[0], world * B))      # t_next = images seen so far (gym_train.py:108)
-        return loss
-
-    def accum_step(just_2d):
-        """One micro-step of the reference loops with accumulation_steps = K (cs_train.py:105-127): backward under
-        no_sync() unless i % K == 0; on those i (except i = 0) optimizer.step, zero_grad, EMA update and the learning-rate
-        schedule written into param_groups."""
-        i = micro[0]
-        micro[0] += 1
-        sync_now = i % accum == 0
-        with (contextlib.nullcontext() if sync_now else model.no_sync()):
-            loss, _ = loss_fn(net, latents, actions, just_2d=just_2d, sync=False)
-            loss.backward()
-        nimg[0] += world * B
-        if sync_now:
-            if world > 1 or force_dist:
-                model.wait()
-            if i != 0:
-                opt.step(max_norm=max_norm, ema=ema.weights(nimg[0], accum * world * B))
-                opt.zero_grad()
-                for g_ in opt.param_groups:
-                    g_["lr"] = learning_rate_schedule(i, ref_lr, sched_steps, sched_steps)
-        return loss
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    dbg = os.environ.get("ONIRIS_DEBUG_LOSS")
-    for i in range(max(args.warmup, 16 if use_graph else 0)):     # graphs: 3 eager + 1 capture call per step flavour
-        l_ = step(i)
-        if dbg:
-            print("warmup", i, float(l_.item()), file=sys.stderr)
-    fence()
-    if _host_t:
-        _host_t[0] = _host_t[1] = _host_t[2] = 0.0
-    t0 = time.perf_counter()
-    hist = []
-    for i in range(args.steps):
-        last = step(i)
-        if dbg == "2":
-            print("timed", i, float(last.item()), file=sys.stderr)
-        if dbg == "3":
-            hist.append(last.detach().clone())
-    t_enq = time.perf_counter() - t0                               # host time to ENQUEUE the K steps (before the fence)
-    fence()
-    if dbg == "3":
-        print("timed losses", [round(float(h.item()), 4) for h in hist], file=sys.stderr)
-    dt = time.perf_counter() - t0
+    out = train(args, args.net, args.steps, args.warmup, rank, world, dev, wd)
+    single = rank == 0 and world == 1 and not force_dist
+    if single and args.net == "gym" and not args.no_extra and args.accum == 1 and not os.environ.get("ONIRIS_ONLY_MODE"):
+        # BASELINE configs[2] and [4] next to the headline, so that their figures are witnessed by the same run:
+        # the Counter-Strike net at its own 32 frames (8 timed steps, ~1 s) and a 32-frame KV-cached rollout (~2 s)
+        import types
+        extra = {}
+        try:
+            extra["cs_t32"] = train(args, "cs", 8, 4, rank, world, dev, wd, light=True)
+            torch.cuda.empty_cache()
+            extra["rollout_32"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=32), quiet=True)
+            extra["rollout_32"]["note"] = ("configs[4] settings (16 Heun steps = 31 evaluations per frame) on 32 generated frames behind a "
+                                           "10-frame context; `python bench.py --mode rollout --gen-frames 256` runs the full 256")
+        except Exception as e:                                   # (never lose the headline to an extra)
+            extra["error"] = f"{type(e).__name__}: {e}"
+        out["extra"] = extra
+    if single and args.cpu_frames > 0 and args.net == "gym":
+        out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+    elif rank == 0:
+        out["cpu_baseline"] = None
     if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    loss_val = float(last.item())
-    if os.environ.get("ONIRIS_HOST_TIMING") == "2":
-        from autoregressive_diffusion_amd import _lib as _l
-        tot = sum(v[1] for v in _l.call_stats.values())
-        print(f"C-ABI calls: {sum(v[0] for v in _l.call_stats.values())} calls, {tot * 1e3:.1f} ms in total (whole process)", file=sys.stderr)
-        for k, v in sorted(_l.call_stats.items(), key=lambda kv: -kv[1][1])[:8]:
-            print(f"   {k:28s} n={v[0]:6d}  {v[1] / v[0] * 1e6:7.1f} us/call", file=sys.stderr)
-    if os.environ.get("ONIRIS_HOST_TIMING"):
-        print(f"host enqueue {t_enq / args.steps * 1e3:.2f} ms/step of {dt / args.steps * 1e3:.2f} ms/step "
-              f"(forward {_host_t[0] / args.steps * 1e3:.2f} [cpu {_host_t[2] / args.steps * 1e3:.2f}], backward {_host_t[1] / args.steps * 1e3:.2f})", file=sys.stderr)
-
-    # per-mode step times (one 3-D and one 2-D step, timed separately, not part of `value`)
-    per_mode = {}
-    for name, i in (("ms_3d_step", 1), ("ms_2d_step", 0)):
-        fence(); t1 = time.perf_counter(); step(i); fence()
-        per_mode[name] = (time.perf_counter() - t1) * 1e3
-
-    roof, kernels, roof_attn, roof_attn_bwd = None, None, None, None
-    if rank == 0 and not args.no_profile:
-        ops.KernelProfile.start()
-        for i in range(4):                                        # one full 3:1 cycle (eager), every MFMA conv launch
-            step(i, profile=True)                                 # bracketed by HIP events on its own stream
-        agg = ops.KernelProfile.stop()
-        kernels = {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
-                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)) for k, v in
-                   sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:12]}
-        attn = {k: v for k, v in agg.items() if k.startswith("attn_fwd") and "MODE=2" in k}      # VideoAttention forward
-        dom, v = max(((k, v) for k, v in agg.items() if not k.startswith("attn_")), key=lambda kv: kv[1]["ms"])
-        achieved = v["flops"] / (v["ms"] * 1e-3)
-        roof = dict(bound="mfma", kernel=dom, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
-                    flops_per_launch=v["flops"] / v["launches"], achieved=achieved / 1e12, peak=MFMA_BF16_PEAK / 1e12,
-                    unit="TFLOP/s", frac=achieved / MFMA_BF16_PEAK, traffic=_pmc_traffic(dom),
-                    # operands read once + results written once, mean over the same launches (to set `traffic` against)
-                    algorithmic_bytes=v["bytes"] / v["launches"])
-        roof_attn = None
-        if attn:                                                  # the north star's second roofline: VideoAttention forward
-            k, v = max(attn.items(), key=lambda kv: kv[1]["ms"])
-            ach = v["flops"] / (v["ms"] * 1e-3)
-            roof_attn = dict(bound="mfma", kernel=k, launches=v["launches"], avg_launch_ms=v["ms"] / v["launches"],
-                             flops_per_launch=v["flops"] / v["launches"], achieved=ach / 1e12, peak=MFMA_BF16_PEAK / 1e12,
-                             unit="TFLOP/s", frac=ach / MFMA_BF16_PEAK,
-                             note="algorithmic FLOPs = unmasked token pairs x 4 x 64 x heads x B (SURVEY 8d)")
-        # ... and its backward: dQ + dK/dV launches of a layer together, priced on the ALGORITHMIC backward FLOPs = 2.5 x the
-        # forward's (five products S, dP, dV, dK, dQ; the two kernels execute seven: each recomputes S and dP)
-        bq = {k: v for k, v in agg.items() if k.startswith("attn_bwd_dq") and "MODE=2" in k}
-        bkv = {k: v for k, v in agg.items() if k.startswith("attn_bwd_dkv") and "MODE=2" in k}
-        roof_attn_bwd = None
-        if attn and bq and bkv:
-            fwd = max(attn.values(), key=lambda v: v["ms"])
-            n = fwd["launches"]
-            ms = sum(v["ms"] for v in bq.values()) + sum(v["ms"] for v in bkv.values())
-            fl = 2.5 * fwd["flops"]
-            ach = fl / (ms * 1e-3)
-            roof_attn_bwd = dict(bound="mfma", kernels=sorted(bq) + sorted(bkv), layers=n, avg_layer_ms=ms / n,
-                                 flops_per_layer=fl / n, achieved=ach / 1e12, peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s",
-                                 frac=ach / MFMA_BF16_PEAK,
-                                 note="dQ + dK/dV launches of one VideoAttention layer; algorithmic FLOPs = 2.5 x forward")
-    elif world > 1:
-        for i in range(4):
-            step(i, profile=True)                                 # keep collectives matched across ranks
-    cpu = None
-    if rank == 0 and world == 1 and args.cpu_frames > 0 and not cs:
-        cpu = cpu_baseline(args.cpu_frames)
-    if world > 1:
+        wd.beat("final barrier")
         dist.barrier()
-
+    wd.stop()
     if rank == 0:
-        frames = world * B * T * args.steps
-        out = {"metric": "denoiser-step frames/sec at 1/2/4/8 MI355X; 64-frame Lunar-Lander seq",
-               "value": frames / dt, "unit": "latent-frames/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "rccl_world": rccl_world, "devices": sorted(set(devices)),
-               "backend": (dist.get_backend() if (world > 1 or force_dist) else None),
-               "ddp": ({"exchange": model.exchange, "grad_dtype": str(model.grad_dtype or "fp32"), "stages": len(flat.stages)}
-                       if (world > 1 or force_dist) else None),
-               "config": {"workload": (f"Counter-Strike latents {T}-frame seq, EDM2 UNet 310.0M (cs_train.py:35-45), " if cs else
-                                       f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), ") +
-                                      f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
-                                      f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
-                          "parallelism": f"dp{world}", "hip_graph": bool(use_graph),
-                          **({"accum_NOT_THE_HEADLINE": accum, "lr": opt.param_groups[0]["lr"]} if accum > 1 else {}),
-                          **({"shared_gpu_gloo_NOT_A_MEASUREMENT": True} if share else {}),
-                          **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
-                          **{k: round(v, 2) for k, v in per_mode.items()}},
-               "loss": loss_val, "roofline": roof, "cpu_baseline": cpu, "roofline_attention": roof_attn,
-               "roofline_attention_bwd": roof_attn_bwd, "kernels": kernels}
         print(json.dumps(out))
     if world > 1 or force_dist:
         dist.destroy_process_group()

@@ -514,26 +514,49 @@ def edm_t_steps(num_steps, sigma_min, sigma_max, rho):
 
 
 def edm_sample_frame(p, cfg, cache, noise, conditioning=None, num_steps=32, sigma_min=0.002, sigma_max=80.0,
-                     rho=7, sigma_data=0.5):
-    """One autoregressive frame: noise (B,1,C,H,W) ~ N(0,1).  Heun; cache updated on the last Euler eval only."""
+                     rho=7, sigma_data=0.5, guidance=1.0, S_churn=0.0, S_min=0.0, S_max=float("inf"), S_noise=1.0,
+                     churn_noise=None, target=None):
+    """One autoregressive frame (reference edm2/sampler.py:12-85): noise (B,1,C,H,W) ~ N(0,1).  Heun; cache updated on the
+    last Euler evaluation only, and not at all when `target` is given (:63).  guidance != 1 (:25-32): every evaluation is
+    lerp(D_2d, D, guidance) with D_2d an eval-mode `just_2d` evaluation WITHOUT cache.  S_churn (:52-59): churn_noise[i] is the
+    N(0,1) draw of step i.  target (:46-48, 78-83): x starts at target + noise * t0.
+    Returns (x, cache) -- or (x, cache, mse, mse_pred) when target is given."""
     B = noise.shape[0]
     t_steps = edm_t_steps(num_steps, sigma_min, sigma_max, rho)
     x_next = noise * t_steps[0]
+    if target is not None:
+        x_next = x_next + target
 
     def den(x, t, cache, upd):
-        D, cache = precond_forward(p, cfg, x, torch.ones(B, 1) * t, conditioning, cache=cache, update_cache=upd,
+        sig = torch.ones(B, 1) * t
+        D, cache = precond_forward(p, cfg, x, sig, conditioning, cache=cache, update_cache=upd,
                                    training=False, sigma_data=sigma_data)
+        if guidance != 1:
+            ref, _ = precond_forward(p, cfg, x, sig, conditioning, cache=None, update_cache=False, just_2d=True,
+                                     training=False, sigma_data=sigma_data)
+            D = ref.lerp(D, guidance)
         return D, cache
 
+    mse, mse_pred = [], []
     with torch.no_grad():
         for i in range(num_steps):
             t_cur, t_next = t_steps[i], t_steps[i + 1]
-            x_hat = x_next
-            x_pred, cache = den(x_hat, t_cur, cache, i == num_steps - 1)
-            d_cur = (x_hat - x_pred) / t_cur
-            x_next = x_hat + (t_next - t_cur) * d_cur
+            if S_churn > 0 and S_min <= t_cur <= S_max:
+                gamma = min(S_churn / num_steps, 2 ** 0.5 - 1)
+                t_hat = t_cur + gamma * t_cur
+                x_hat = x_next + (t_hat ** 2 - t_cur ** 2).sqrt() * S_noise * churn_noise[i]
+            else:
+                t_hat, x_hat = t_cur, x_next
+            x_pred, cache = den(x_hat, t_hat, cache, i == num_steps - 1 and target is None)
+            d_cur = (x_hat - x_pred) / t_hat
+            x_next = x_hat + (t_next - t_hat) * d_cur
             if i < num_steps - 1:
                 x_pred, _ = den(x_next, t_next, cache, False)
                 d_prime = (x_next - x_pred) / t_next
-                x_next = x_hat + (t_next - t_cur) * (0.5 * d_cur + 0.5 * d_prime)
+                x_next = x_hat + (t_next - t_hat) * (0.5 * d_cur + 0.5 * d_prime)
+            if target is not None:
+                mse_pred.append(torch.mean((x_pred - target) ** 2).item())
+                mse.append(torch.mean((x_next - target) ** 2).item())
+    if target is not None:
+        return x_next, cache, mse, mse_pred
     return x_next, cache

@@ -401,6 +401,55 @@ def g9():
     save("g9_sampler", **out)
 
 
+# ------------------------------------------------------------------ G9b the sampler's side branches
+def g9b():
+    """edm_sampler_with_mse beyond its default path (reference edm2/sampler.py): `guidance != 1` (:25-32: a second, eval-mode
+    `just_2d=True` evaluation without cache + lerp), `S_churn > 0` (:52-59: noise injection before every Euler evaluation) and
+    `target=` (:46-48, 78-83: start from target + noise, per-step MSE lists, cache NOT updated).  Every case starts from the
+    G9 prefill cache; all random draws are replaced by recorded tensors (torch.randn: the initial noise; torch.randn_like: the
+    churn noise of each step)."""
+    import copy
+    net, p = build_precond(SMALL_CFG, 90, 0.5)
+    net.eval()
+    g = torch.Generator().manual_seed(190)
+    B, t0 = 1, 4
+    ctx = torch.randn(B, t0, 4, 32, 32, generator=g)
+    lab = torch.randint(0, 4, (B, t0), generator=g)
+    with torch.no_grad():
+        _, cache0 = net(ctx, torch.ones(B, t0) * 0.05, lab, update_cache=True)
+    g2 = torch.Generator().manual_seed(191)
+    noise = torch.randn(B, 1, 4, 32, 32, generator=g2)
+    churn = torch.randn(4, B, 1, 4, 32, 32, generator=g2)
+    target = torch.randn(B, 1, 4, 32, 32, generator=g2) * 0.5
+    out = dict(seed=np.int64(90), ctx=ctx, ctx_labels=lab, noise=noise, churn_noise=churn, target=target)
+    real_randn, real_like = torch.randn, torch.randn_like
+    cases = dict(guid=dict(guidance=1.5, S_churn=0), churn=dict(guidance=1, S_churn=8, S_noise=1),
+                 target=dict(guidance=1, S_churn=0, target=target), all=dict(guidance=0.7, S_churn=8, target=target))
+    for tag, kw in cases.items():
+        cache = copy.deepcopy(cache0)
+        n_like = {"n": 0}
+
+        def fake_randn(*a, **k):
+            return noise.clone()
+
+        def fake_like(x, **k):
+            n_like["n"] += 1
+            return churn[n_like["n"] - 1].clone()
+        torch.randn, torch.randn_like = fake_randn, fake_like
+        try:
+            x, mse, mse_pred, cache = edm_sampler_with_mse(net, cache, conditioning=torch.full((B, 1), 2), num_steps=4,
+                                                           sigma_min=0.01, sigma_max=80, rho=2, **kw)
+        finally:
+            torch.randn, torch.randn_like = real_randn, real_like
+        assert n_like["n"] == (4 if kw["S_churn"] else 0)
+        out[tag + "_x"] = x
+        out[tag + "_mse"] = np.array(mse, dtype=np.float64)
+        out[tag + "_mse_pred"] = np.array(mse_pred, dtype=np.float64)
+        out[tag + "_cache_n_ctx"] = np.int64(cache["n_context_frames"])
+        out[tag + "_cache_attn_frames"] = np.int64(cache[("enc", "8x8_block0")]["attn"][0].shape[2])
+    save("g9b_sampler_branches", **out)
+
+
 # ------------------------------------------------------------------ G10 import of a 2-D EDM2 net (load_from_2d)
 def g10():
     """UNet.load_from_2d (networks_edm2.py:238-258): the reference net starts from parameter set A, imports the 2-D
@@ -474,6 +523,6 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g9b", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

@@ -36,3 +36,13 @@ def test_self_launch_propagates_a_failing_rank():
 def test_mismatched_launcher_is_refused():
     r = _run(["--gpus", "4", "--dry-run"], {"RANK": "0", "WORLD_SIZE": "2", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and "disagree" in (r.stderr + r.stdout)
+
+
+def test_watchdog_names_the_stage_of_a_hung_collective():
+    # rank 1 stops answering after the rendezvous: rank 0's watchdog must end it with exit code 124 and the stage name,
+    # well before any outer timeout -- the first 8-GPU run must be diagnosable from its stderr alone
+    r = _run(["--gpus", "2", "--dry-run", "--watchdog", "5"], {"ONIRIS_DRY_RUN_HANG_RANK": "1", "TORCH_DISTRIBUTED_DEBUG": "OFF"},
+             timeout=300)
+    assert r.returncode != 0
+    assert "watchdog: rank 0 made no progress" in r.stderr and "all_reduce(MAX)" in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

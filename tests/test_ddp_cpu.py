@@ -515,3 +515,18 @@ def test_mesh_mode_checkpoint_state_and_accumulation_cadence(exchange):
     for got, want in zip(esd, want_e["emas"]):
         for k, v in want.items():
             assert torch.allclose(torch.from_numpy(got[k]), v, atol=2e-6), k
+
+
+def test_ddp_guard_is_invisible_to_generic_introspection():
+    """the torch-DDP refusal must not turn hasattr / inspect.getmembers / attribute copying on a UNet into a
+    RuntimeError about DistributedDataParallel when nobody is wrapping anything."""
+    import inspect
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    from edm2.networks_edm2 import UNet
+    unet = UNet(img_resolution=16, img_channels=4, label_dim=4, model_channels=8, channel_mult=[1, 2], num_blocks=1)
+    assert not hasattr(unet, "_ddp_params_and_buffers_to_ignore")
+    assert getattr(unet, "_ddp_params_and_buffers_to_ignore", None) is None
+    names = [n for n, _ in inspect.getmembers(unet)]
+    assert "forward" in names and "_ddp_params_and_buffers_to_ignore" not in names

@@ -266,3 +266,26 @@ def test_g9_sampler():
     assert blk["conv_res0"]["n_context_frames"] == int(z["cache_conv0_n"])
     close(blk["conv_res0"]["activations"], z["cache_conv0_act"], rtol=1e-3)
     close(blk["attn"][0], z["cache_attn_k"], rtol=1e-3); close(blk["attn"][1], z["cache_attn_v"], rtol=1e-3)
+
+
+def test_g9b_sampler_branches():
+    """The sampler's side branches (guidance != 1, S_churn > 0, target=; reference edm2/sampler.py:25-32,46-59,78-83)."""
+    import copy
+    z = load("g9b_sampler_branches")
+    p = paramgen.prenormalise(paramgen.precond_params(SMALL_CFG, int(z["seed"])))
+    with torch.no_grad():
+        _, cache0 = O.precond_forward(p, SMALL_CFG, T(z["ctx"]), torch.ones(1, 4) * 0.05, T(z["ctx_labels"]),
+                                      update_cache=True, training=False, sigma_data=0.5)
+    cases = dict(guid=dict(guidance=1.5), churn=dict(S_churn=8.0), target=dict(target=T(z["target"])),
+                 all=dict(guidance=0.7, S_churn=8.0, target=T(z["target"])))
+    for tag, kw in cases.items():
+        res = O.edm_sample_frame(p, SMALL_CFG, copy.deepcopy(cache0), T(z["noise"]), torch.full((1, 1), 2), num_steps=4,
+                                 sigma_min=0.01, sigma_max=80.0, rho=2, sigma_data=0.5, churn_noise=T(z["churn_noise"]), **kw)
+        close(res[0], z[tag + "_x"], rtol=1e-3, what=f"{tag} frame")
+        assert res[1]["n_context_frames"] == int(z[tag + "_cache_n_ctx"])
+        assert res[1][("enc", "8x8_block0")]["attn"][0].shape[2] == int(z[tag + "_cache_attn_frames"])
+        if "target" in kw:
+            np.testing.assert_allclose(res[2], z[tag + "_mse"], rtol=2e-3)
+            np.testing.assert_allclose(res[3], z[tag + "_mse_pred"], rtol=2e-3)
+        else:
+            assert len(z[tag + "_mse"]) == 0
