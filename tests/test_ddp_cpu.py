@@ -530,3 +530,121 @@ def test_ddp_guard_is_invisible_to_generic_introspection():
     assert getattr(unet, "_ddp_params_and_buffers_to_ignore", None) is None
     names = [n for n, _ in inspect.getmembers(unet)]
     assert "forward" in names and "_ddp_params_and_buffers_to_ignore" not in names
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the REAL module tree (gym UNet, 449 parameters, its overlap stages and 2-D / 3-D parameter classes) under OnirisDDP with two
+# gloo ranks; the HIP ops are replaced by CPU stand-ins with the same interface and autograd topology (tests/cpu_ops_stub.py)
+
+# gym_train.py:37-47 at HALF the width (model_channels 16 instead of 32: the same 449 parameter tensors, module names, overlap
+# stages and parameter classes with a quarter of the elements -- the CPU suite has minutes, and the layout logic under test
+# counts tensors, not elements; the attention levels keep whole 64-channel heads: 64 ch at 16x16, 128 ch at 8x8)
+GYM_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=16, channel_mult=[1, 2, 4, 8],
+               channel_mult_noise=None, channel_mult_emb=None, num_blocks=2, video_attn_resolutions=[8],
+               frame_attn_resolutions=[16])
+
+
+def _build_gym_unet(seed):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import cpu_ops_stub
+    cpu_ops_stub.install()
+    from edm2.networks_edm2 import UNet
+    torch.manual_seed(seed)
+    unet = UNet(**GYM_CFG).train()
+    for m in unet.modules():
+        if hasattr(m, "emb_gain"):
+            nn.init.constant_(m.emb_gain, 0.3)
+    nn.init.constant_(unet.out_gain, 1.0)
+    return unet
+
+
+def _gym_batches():
+    g = torch.Generator().manual_seed(21)
+    # [micro-step][rank]: (x, c_noise, labels) -- B = 1 sequence of 2 frames (clean | noised: 4 slots; 2 in a 2-D step)
+    return [[(torch.randn(1, 2 if j2d else 4, 8, 64, 64, generator=g), torch.randn(1, 2 if j2d else 4, generator=g),
+              torch.randint(0, 4, (1, 2 if j2d else 4), generator=g)) for _ in range(2)] for j2d in (True, False, False, False)]
+
+
+def _real_tree_worker(rank, world, port, q, exchange, bf16, mismatch):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autoregressive_diffusion_amd.parallel import OnirisDDP, FlatAdamW, FlatParams, FlatEMA
+    torch.set_num_threads(3)                             # (two ranks share the container's 8 cores)
+    unet = _build_gym_unet(400 + rank)                   # different init per rank: construction broadcasts rank 0's
+    flat = FlatParams(unet, lazy_small=True)             # (bench.py's construction)
+    ddp = OnirisDDP(unet, flat=flat, exchange=exchange, grad_dtype=torch.bfloat16 if bf16 else None)
+    opt = FlatAdamW(flat, lr=1e-3, weight_decay=0.01)
+    ema = FlatEMA(flat, stds=(0.05,))
+    keys = [k for k, _, _ in flat.stages]
+    fired = []
+    hooks = unet.__dict__["_oniris_stage_hooks"]
+    for k in list(hooks):
+        hooks[k] = (lambda cb, k: (lambda g: (fired.append(k), cb(g))[1]))(hooks[k], k)
+    data = _gym_batches()
+    outcome = "ok"
+    try:
+        for i, j2d in enumerate((True, False, False, False)):
+            x, cn, lab = data[i][rank]
+            if mismatch and rank == 1 and i == 1:            # rank 1 runs a 2-D step where rank 0 runs a 3-D one
+                x, cn, lab, j2d = x[:, :2], cn[:, :2], lab[:, :2], True
+            opt.zero_grad()
+            del fired[:]
+            if i == 2:                                       # one accumulated micro-step under no_sync() first
+                with ddp.no_sync():
+                    out, _ = ddp(x, cn, lab, just_2d=j2d); out.float().pow(2).mean().backward()
+                assert fired == keys and not ddp._works, "stage hooks fire under no_sync() but exchange nothing"
+                del fired[:]
+            out, _ = ddp(x, cn, lab, just_2d=j2d); out.float().pow(2).mean().backward()
+            assert fired == keys, (fired, keys)              # every stage, in backward order, exactly once
+            assert not any(ddp._sent) and len(ddp._works) >= len(keys) + 1      # ... each started its exchange; + the head
+            ddp.wait()
+            opt.step(max_norm=0.5, ema=ema.weights(8 * (i + 1), 8))
+    except RuntimeError as e:
+        outcome = "raised" if "ranks disagree" in str(e) else f"error: {e}"
+    steps = {flat.names[id(p)]: s for p, s in zip(flat.params, opt.param_steps)}
+    q.put((rank, outcome, flat.flat.numpy().copy(), steps, len(flat.params), [(str(k), lo, hi) for k, lo, hi in flat.stages]))
+    if outcome == "ok":
+        dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange,bf16", [("allreduce", False), ("mesh", True)])
+def test_real_unet_module_tree_under_ddp_world2(exchange, bf16):
+    """VERDICT r03 next #6a: hook ordering, stage firing, no_sync(), the active-bitmap check and the flat layout on the
+    gym UNet's own 449 parameters (not a toy net), two gloo ranks, against ONE process that averages both ranks' gradients."""
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW, FlatEMA
+    res = _run2(_real_tree_worker, exchange, bf16, False)
+    (_, o0, p0, steps0, n0, st0), (_, o1, p1, steps1, n1, st1) = res
+    assert o0 == o1 == "ok", (o0, o1)
+    assert n0 == n1 == 449 - 5 + 5 and len(st0) >= 4 and st0 == st1        # all 449 are re-homed; >= 4 overlap stages
+    assert (p0 == p1).all(), "ranks diverged"
+    assert steps0 == steps1
+    # parameter classes: own-frame weights step on all 4 steps, context weights / gates only on the 3 3-D steps, out_res /
+    # emb_time never (networks_edm2.py:197,205-207)
+    assert steps0["enc.64x64_conv.last_frame_conv.weight.weight"] == 4 and steps0["enc.64x64_conv.weight.weight"] == 3
+    assert steps0["enc.64x64_conv.gating.mult"] == 3 and steps0["out_res.mult"] == 0 and steps0["emb_time.weight.weight"] == 0
+    # single process, same stub ops: mean of the two ranks' gradients per step (accumulated micro-step included)
+    unet = _build_gym_unet(400)
+    flat = FlatParams(unet, lazy_small=True)
+    opt = FlatAdamW(flat, lr=1e-3, weight_decay=0.01)
+    ema = FlatEMA(flat, stds=(0.05,))
+    data = _gym_batches()
+    for i, j2d in enumerate((True, False, False, False)):
+        opt.zero_grad()
+        for r in range(2):
+            x, cn, lab = data[i][r]
+            for _ in range(2 if i == 2 else 1):
+                out, _ = unet(x, cn, lab, just_2d=j2d); (out.float().pow(2).mean() / 2).backward()
+        opt.step(max_norm=0.5, ema=ema.weights(8 * (i + 1), 8))
+    tol = 3e-3 if bf16 else 1e-5
+    d = (torch.from_numpy(p0) - flat.flat).abs().max().item()
+    assert d <= tol, d
+
+
+def test_real_unet_ranks_running_different_step_kinds_are_detected():
+    res = _run2(_real_tree_worker, "allreduce", False, True)
+    assert sorted(r[1] for r in res) == ["raised", "raised"], [r[1] for r in res]
