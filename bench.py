@@ -4,7 +4,8 @@
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
 
 Workload (config.workload): the Lunar-Lander net of gym_train.py:37-47 (46.2 M parameters), 64-frame sequences of
-8x64x64 latents, B sequences per GPU, synthetic N(0,1) latents and random-init weights.  One step = the reference
+8x64x64 latents, B sequences per GPU -- by default the reference's own micro-batch, 8 (gym_train.py:55; rounds 1-3 quoted
+B = 2, which the default run still reports as extra.gym_t64_b2) -- synthetic N(0,1) latents and random-init weights.  One step = the reference
 training micro-step: EDM2Loss forward (Precond -> UNet over clean|noised frame slots), backward, gradient
 all-reduce (N > 1), fused AdamW, with the reference's 3:1 mix of 3-D and 2-D steps (gym_train.py:96).
 value = latent frames / s over the whole job = N * B * T * K / wall time of the K timed steps (max over ranks).
@@ -249,7 +250,7 @@ def _claim_stdout():
     sys.stdout = os.fdopen(keep, "w", buffering=1)
 
 
-def train(args, netname, steps, warmup, rank, world, dev, wd, light=False):
+def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light_batch=2):
     """The timed training job on this rank: build the net, W warm-up + K timed steps between fences, max over ranks.
     light: an extra measurement inside the headline run (no per-kernel profile, no CPU baseline): {frames_s, ms_per_step, ...}.
     Returns the JSON record (rank 0) or None."""
@@ -291,7 +292,7 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False):
     loss_fn = (EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1) if cs else   # cs_train.py:75
                EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5))         # gym_train.py:66-67
 
-    B = args.batch
+    B = args.batch if not light else light_batch
     T = (args.frames if not light else None) or (32 if cs else 64)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     res = unet.img_resolution
@@ -518,7 +519,9 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False):
                     if multi else None),
             "config": {"workload": (f"Counter-Strike latents {T}-frame seq, EDM2 UNet 310.0M (cs_train.py:35-45), " if cs else
                                     f"Lunar-Lander {T}-frame seq, gym EDM2 UNet 46.2M (gym_train.py:37-47), ") +
-                                   f"{B} seq/GPU, step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
+                                   f"{B} seq/GPU" + (" (cs_train.py:59 micro_batch_size)" if (cs and B == 2) else
+                                                     " (gym_train.py:55 micro_batch_size)" if (not cs and B == 8) else "") +
+                                   f", step = EDM2Loss fwd + bwd + grad all-reduce + [grad-norm clip +] AdamW + 2 EMA profiles, "
                                    f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
                        "parallelism": f"dp{world}", "hip_graph": False,
                        **({"accum_NOT_THE_HEADLINE": accum, "lr": opt.param_groups[0]["lr"]} if accum > 1 else {}),
@@ -534,7 +537,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=2, help="sequences per GPU (weak scaling)")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="sequences per GPU (weak scaling).  Default: the reference's own micro-batch -- 8 for the Lunar-Lander "
+                         "net (gym_train.py:55 micro_batch_size), 2 for the Counter-Strike net (cs_train.py:59); rollout: 1")
     ap.add_argument("--frames", type=int, default=None, help="frames per sequence (default 64 gym / 32 cs)")
     ap.add_argument("--net", choices=["gym", "cs"], default="gym",
                     help="gym = BASELINE configs[1] (the headline metric); cs = the Counter-Strike net of configs[2]/[3] "
@@ -560,6 +565,8 @@ def main():
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 64 if args.net == "gym" else 32
+    if args.batch is None:
+        args.batch = 1 if args.mode == "rollout" else (8 if args.net == "gym" else 2)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.mode == "train":
         sys.exit(self_launch(args))              # (this process never imports torch, never touches a GPU)
     _claim_stdout()
@@ -601,8 +608,11 @@ def main():
         import types
         extra = {}
         try:
-            extra["cs_t32"] = train(args, "cs", 8, 4, rank, world, dev, wd, light=True)
+            extra["cs_t32"] = train(args, "cs", 8, 4, rank, world, dev, wd, light=True, light_batch=2)   # cs_train.py:59
             torch.cuda.empty_cache()
+            if args.batch != 2:      # rounds 1-3 quoted the headline at 2 sequences per GPU: kept for round-over-round comparison
+                extra["gym_t64_b2"] = train(args, "gym", 8, 4, rank, world, dev, wd, light=True, light_batch=2)
+                torch.cuda.empty_cache()
             extra["rollout_32"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=32), quiet=True)
             extra["rollout_32"]["note"] = ("configs[4] settings (16 Heun steps = 31 evaluations per frame) on 32 generated frames behind a "
                                            "10-frame context; `python bench.py --mode rollout --gen-frames 256` runs the full 256")

@@ -105,6 +105,9 @@ def test_g6_attention_modules():
     assert e[0] < 1e-2 and e[1] < 2e-2 and e[2] < 3e-2
 
 
+WEIGHT_GN_TOL = dict(enc=5e-2, dec=5e-2)      # (tightened to 2x the measured floor below)
+
+
 def test_g7_blocks():
     from edm2.networks_edm2 import Block
     from test_oracle_golden import _block_params
@@ -124,12 +127,16 @@ def test_g7_blocks():
             k = f"{tag}_gn_{n}"
             if k in z.files and prm.grad is not None:
                 gn[n] = abs(prm.grad.norm().item() - float(z[k])) / (float(z[k]) + 1e-12)
-        print("g7", tag, e, "max gradnorm rel err", max(gn.values()), max(gn, key=gn.get))
-        assert e["y"] < 1.5e-2 and e["gx"] < 3e-2 and e["gemb"] < 3e-2
-        # weights: 5e-2.  gate scalars: d(gate) is a reduction of bf16-stored activations whose true value can be far
-        # below the magnitude of its terms (scale-invariant layers downstream) -> absolute noise floor, see GATE_TOL
-        assert max(v for k, v in gn.items() if "gating" not in k) < 5e-2, gn
-        assert max(v for k, v in gn.items() if "gating" in k) < 0.15, gn
+        wmax = max(v for k, v in gn.items() if "gating" not in k)
+        gmax = max(v for k, v in gn.items() if "gating" in k)
+        print("g7", tag, e, "max gradnorm rel err: weights", wmax, "gates", gmax, max(gn, key=gn.get))
+        # bounds = 2x the measured floors (round 4: y 4.7e-3, gx 5.2e-3, gemb 6.5e-3)
+        assert e["y"] < 1e-2 and e["gx"] < 1.1e-2 and e["gemb"] < 1.3e-2
+        # gate scalars: d(gate) is a reduction of bf16-stored activations whose true value can be far below the magnitude
+        # of its terms (scale-invariant layers downstream).  Measured: 0.9 % (enc), 7.3 % (dec: conv_res1.max_gating, a
+        # gradient of 1e-3 that is the difference of two sums of order 1) -- bounds at 2x
+        assert wmax < WEIGHT_GN_TOL[tag], gn
+        assert gmax < (0.02 if tag == "enc" else 0.15), gn
 
 
 SMALL_CFG = dict(img_resolution=32, img_channels=4, label_dim=4, model_channels=16, channel_mult=[1, 4, 4],
@@ -186,6 +193,7 @@ def test_g8_unet_loss(tag, cfg):
         assert e["Dx"] < 2e-2 and e["loss"] < 2e-2 and e["unw"] < 2e-2
         scalars = {n for n in names if prm[n].numel() <= 2}          # gate parameters and emb_gain / out_gain
         wg = {k: v for k, v in gerr.items() if k not in scalars}
+        print("   weight gradnorm rel err: median", float(np.median(list(wg.values()))), "max", max(wg.values()), max(wg, key=wg.get))
         assert np.median(list(wg.values())) < 2e-2 and max(wg.values()) < 0.1, sorted(wg.items(), key=lambda kv: kv[1])[-3:]
         # gate scalars: |err| <= 3% of the value + 0.3% of the largest gate gradient in the net (bf16 noise floor of
         # the sum(dout*out) / sum(dout*y3) reductions; measured floor ~5e-5 absolute on this fixture)

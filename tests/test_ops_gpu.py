@@ -134,7 +134,11 @@ def test_conv_plain(N, H, cin, cout, k):
                                             # several tiles per frame / per workgroup, 1..4 channel chunks, ragged Cout
                                             (2, 5, 32, 32, 96), (1, 3, 16, 128, 64), (3, 7, 16, 32, 32),
                                             # 8x8 images: two frames per workgroup tile (odd T: a ragged last tile)
-                                            (2, 3, 8, 64, 128), (1, 5, 8, 32, 64)])
+                                            (2, 3, 8, 64, 128), (1, 5, 8, 32, 64),
+                                            # BASELINE configs[1]'s own 64x64 level (B = 2 x 64 frames x 2 slots, C = 32): the
+                                            # weight gradients are summed from the MAXIMUM number of bf16 split-K slabs here
+                                            # (the rounding of every partial sum must not show against the fp32 oracle)
+                                            (2, 64, 64, 32, 32)])
 def test_gated_conv_train(B, T, H, cin, cout):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(3)
@@ -169,7 +173,9 @@ def test_gated_conv_train(B, T, H, cin, cout):
     e = dict(y=rel(nchw(y), yr), dx=rel(nchw(x.grad), xr.grad), dw2=rel(p2.grad, w2r.grad), dw3=rel(p3.grad, w3r.grad),
              dg=rel(g.grad, gr.grad))
     print("gated_conv", (B, T, H, cin, cout), e)
-    assert e["y"] < 1e-2 and e["dx"] < 1e-2 and e["dw2"] < 2e-2 and e["dw3"] < 2e-2 and e["dg"] < 3e-2
+    # 2x the measured floors (round 4, all eleven shapes: y / dx / dw 2.0-2.5e-3 = the bf16 rounding of inputs and outputs,
+    # including the 64x64-level shape with the maximum number of bf16 split-K slabs; dg 1.9-5.7e-3)
+    assert e["y"] < 5e-3 and e["dx"] < 5e-3 and e["dw2"] < 5e-3 and e["dw3"] < 5e-3 and e["dg"] < 1.2e-2
 
 
 def test_gated_conv_eval_matches_oracle():
