@@ -32,6 +32,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base0, const unsi
 }
 
 #include "conv_wgrad_glds.h"
+#include "conv_wgrad_stream.h"
 #include "wgrad1x1_glds.h"
 
 template <int TAPS, int PW, int CT, int IT>
@@ -328,6 +329,10 @@ extern "C" int oniris_conv_wgrad_group(const OnirisWgradArgs* args, int ngroups,
     return wgrad_pick_tile<1, 16>(args, ngroups, stream);
   }
   const int W = a.W, H = a.H;
+  if (wgrad_stream_ok(args, ngroups)) {              // a gated conv's three groups on 32-channel weight blocks: one streaming pass
+    const int rc = launch_wgrad_stream(args, stream);
+    if (rc != 1) return rc;
+  }
   if (W >= 16 && W % 16 == 0 && H % 8 == 0) return wgrad_pick_tile<9, 16>(args, ngroups, stream);
   if (W == 8 && H % 8 == 0) return wgrad_pick_tile<9, 8>(args, ngroups, stream);
   if (W == 4 && H % 4 == 0) return wgrad_pick_tile<9, 4>(args, ngroups, stream);

@@ -143,6 +143,8 @@ def _nsplit_cap(cin, cout, taps):
     tile = 2 if (cin > 32 and cout > 32) else 1
     gy = -(-roundup(cin, 16) // (32 * tile)) * -(-roundup(cout, 8) // (32 * tile))
     cap = max(1, (256 if tile == 2 else 512) // gy)
+    if tile == 1 and taps >= 9:
+        cap = 512       # launch_wgrad_stream() (csrc/conv_wgrad_stream.h): one slab per (sequence, 8x16-pixel tile, segment)
     if taps == 1 and cin >= 64 and cout >= 64:
         cap = max(cap, 256 // (-(-cin // 128) * -(-cout // 128)))
     return cap
@@ -543,7 +545,10 @@ def _wgrad_launch_group(arglist):
     if KernelProfile.enabled:
         a0 = arglist[0]
         tile = 2 if (a0.Cin > 32 and a0.Cout > 32) else 1
-        if WGRAD_VARIANT >= 0 and all(a.taps == 9 and ((a.W % 16 == 0 and a.H % 8 == 0) or (a.W == 8 and a.H == 8))
+        if (WGRAD_VARIANT >= 0 and not (WGRAD_VARIANT & 2) and len(arglist) == 3 and tile == 1 and a0.taps == 9 and a0.W % 16 == 0
+                and a0.H % 8 == 0 and arglist[1].B * (a0.W // 16) * (a0.H // 8) <= min(a0.nsplit_cap, arglist[1].nsplit_cap)):
+            key = "conv_wgrad_stream_kernel"                                      # mirrors wgrad_stream_ok() / launch_wgrad_stream()
+        elif WGRAD_VARIANT >= 0 and all(a.taps == 9 and ((a.W % 16 == 0 and a.H % 8 == 0) or (a.W == 8 and a.H == 8))
                                       and a.fill in (0.0, 1.0) for a in arglist):     # mirrors wgrad_glds_ok() in csrc
             key = f"conv_wgrad_glds_kernel<CT={tile},IT={tile},NG=2,PW={_patch_w(a0.W)}>"
         elif (WGRAD_VARIANT >= 0 and len(arglist) == 1 and a0.taps == 1 and a0.Cin >= 64 and a0.Cout >= 64 and not a0.scale
