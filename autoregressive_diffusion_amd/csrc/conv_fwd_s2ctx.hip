@@ -1,5 +1,6 @@
 #include "conv_fwd_common.h"
 #include "conv_glds.h"
+#include "conv_stream.h"
 
 // DART training layout.  big_tile: 0/1/2 = register-staged kernels (conv_kernels.h), >= 3 = persistent LDS-DMA kernel
 // (conv_glds.h: 8 waves, 16x16-pixel workgroup tiles) wherever the shape allows it.
@@ -11,6 +12,8 @@ static int glds_pick(const OnirisConvArgs& a, hipStream_t st) {
 }
 
 int conv_dispatch_s2ctx(const OnirisConvArgs& a, hipStream_t st) {
+  // 32 -> <= 32 channels (the 64x64 level): frames streamed through an LDS ring, weights in registers (conv_stream.h)
+  if (a.big_tile >= 4 && conv_stream_ok(a)) return launch_conv_stream(a, st);
   if (a.big_tile >= 3 && conv_glds_ok(a, 16, 16, (a.CoutP % 64 == 0) ? 64 : 32))
     return (a.CoutP % 64 == 0) ? glds_pick<2>(a, st) : glds_pick<1>(a, st);
   // 8x8 images: two whole frames per workgroup, 4 position waves x 2 channel waves (32 channels each)

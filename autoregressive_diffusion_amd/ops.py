@@ -463,7 +463,10 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         if ctx is not None:
             flops += 2.0 * B * T * H * W * Cout * Cin * 2 * taps
         nt = 2 if CoutP % 64 == 0 else 1
-        if (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H % 16 == 0 and W % 16 == 0
+        if (BIG_TILE >= 4 and S == 2 and ctx is not None and taps == 9 and Cin == 32 and CinP == 64 and CoutP == 32 and W % 16 == 0
+                and H % 4 == 0 and ctx_fill in (0.0, 1.0) and ctx_T == T and tuple(coff) in ((-2, -1), (2, 1))):
+            key = f"conv_stream_kernel<ALIAS={int(ctx.data_ptr() == x.data_ptr() and ctx_bstride == 2 * T and coff[0] < 0)}>"   # conv_stream_ok()
+        elif (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H % 16 == 0 and W % 16 == 0
                 and ctx_fill in (0.0, 1.0)):          # mirrors conv_glds_ok() in csrc/conv_glds.h
             key = f"conv_glds_kernel<NT={nt},PW=16,NW=8,MT=1,WC=1,CTX=1>"
         elif (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H == 8 and W == 8

@@ -138,7 +138,10 @@ def test_conv_plain(N, H, cin, cout, k):
                                             # BASELINE configs[1]'s own 64x64 level (B = 2 x 64 frames x 2 slots, C = 32): the
                                             # weight gradients are summed from the MAXIMUM number of bf16 split-K slabs here
                                             # (the rounding of every partial sum must not show against the fp32 oracle)
-                                            (2, 64, 64, 32, 32)])
+                                            (2, 64, 64, 32, 32),
+                                            # the streaming kernels of the 32-channel level (conv_stream.h / conv_wgrad_stream.h):
+                                            # ragged Cout, several segments per sequence with a ragged last one, one frame
+                                            (2, 5, 32, 32, 8), (1, 19, 16, 32, 32), (4, 1, 16, 32, 24), (1, 64, 32, 32, 32)])
 def test_gated_conv_train(B, T, H, cin, cout):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(3)
