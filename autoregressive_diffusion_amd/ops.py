@@ -560,12 +560,20 @@ def _wgrad_launch_group(arglist):
         else:
             key = f"conv_wgrad_kernel<TAPS={a0.taps},PW={_patch_w(a0.W)},CT={tile},IT={tile}>"
         flops = sum(2.0 * a.B * a.T * a.H * a.W * a.Cout * a.Cin * a.taps for a in arglist)
+        # algorithmic HBM bytes: every distinct operand read once (the context groups of a gated conv read frames of the own
+        # group's x again: counted once), + one slab set written
+        seen, nbytes = set(), 0.0
+        for a in arglist:
+            for ptr, n in ((a.x, a.B * a.xb_stride * a.H * a.W * a.Cin), (a.dy, a.B * a.T * a.H * a.W * a.Cout)):
+                if ptr not in seen:
+                    seen.add(ptr)
+                    nbytes += 2.0 * n
         KernelProfile.enabled = False
         try:
             e0, e1 = _timed_launch(lambda: _wgrad_launch_group(arglist))
         finally:
             KernelProfile.enabled = True
-        KernelProfile.records.append((key, flops, e0, e1))
+        KernelProfile.records.append((key, flops, e0, e1, nbytes))
         return
     arr = (_lib.WgradArgs * len(arglist))(*arglist)
     check(lib.oniris_conv_wgrad_group(arr, len(arglist), _stream()), "conv_wgrad")

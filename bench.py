@@ -445,9 +445,15 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
                     a = tgt.setdefault(k, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0, t_min=0.0))
                     for f_ in ("launches", "flops", "ms", "bytes", "t_min"):
                         a[f_] += v[f_]
+        # per kernel: frac = algorithmic FLOPs / time / bf16 MFMA peak; roof = sum of the launches' roofline times max(FLOPs / 2.5 PF,
+        # algorithmic bytes / 6.3 TB/s) / measured time, bound = which term makes up most of that sum (the 32-channel level and the
+        # 1x1 convs are HBM-bound: their `frac` of the MFMA peak says little, `roof` is the figure to read)
         kernels = {k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
-                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), frac=round(v["flops"] / (v["ms"] * 1e-3) / MFMA_BF16_PEAK, 3))
-                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:14]}
+                           tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1), frac=round(v["flops"] / (v["ms"] * 1e-3) / MFMA_BF16_PEAK, 3),
+                           roof=round(v["t_min"] / (v["ms"] * 1e-3), 3),
+                           bound=("hbm" if v["bytes"] / HBM_ACHIEVABLE > v["flops"] / MFMA_BF16_PEAK else "mfma"),
+                           gbytes_s=(round(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None))
+                   for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:16]}
         attn = {k: v for k, v in agg.items() if k.startswith("attn_fwd") and "MODE=2" in k}      # VideoAttention forward
         dom, v = max(((k, v) for k, v in agg.items() if not k.startswith("attn_")), key=lambda kv: kv[1]["ms"])
         achieved = v["flops"] / (v["ms"] * 1e-3)

@@ -41,5 +41,5 @@ def run(B, T, H, C, Cout, dgrad=False):
     for w in (0, 3, 4, 7):
         tot = int(s[w].sum())
         print(f"  wave {w}: total {tot:7d} | " + " ".join(f"{n} {int(c)}" for n, c in zip(names, s[w]) if n != "-"))
-for shp in [(2, 64, 32, 64, 64), (2, 64, 16, 128, 128)]:
+for shp in [(int(os.environ.get("SB", "2")), 64, 32, 64, 64), (int(os.environ.get("SB", "2")), 64, 16, 128, 128)]:
     run(*shp)
