@@ -1,0 +1,27 @@
+#!/bin/bash
+# end-of-round measurements (run through gpurun from the repo root); everything lands in gpurun_out/
+set -x
+O=gpurun_out
+python -m pytest tests -m gpu -q > $O/r04_gputests_final.log 2>&1; echo rc=$? >> $O/r04_gputests_final.log
+python bench.py --steps 20 --warmup 5 > $O/r04_bench.json 2> $O/r04_bench.err
+python bench.py --batch 2 --steps 20 --warmup 5 --cpu-frames 0 --no-extra > $O/r04_bench_b2.json 2> $O/r04_bench_b2.err
+python bench.py --net cs --steps 8 --warmup 4 --no-profile > $O/r04_bench_cs.json 2> $O/r04_bench_cs.err
+python bench.py --net cs --steps 16 --warmup 8 --accum 4 --no-profile > $O/r04_bench_cs_accum4.json 2> $O/r04_bench_cs_accum4.err
+python bench.py --mode rollout --gen-frames 16 --batch 1 > $O/r04_rollout.json 2> $O/r04_rollout.err
+python bench.py --mode rollout --gen-frames 256 --batch 1 > $O/r04_rollout_256.json 2> $O/r04_rollout_256.err
+ONIRIS_FORCE_DIST=1 python bench.py --steps 8 --warmup 4 --cpu-frames 0 --no-extra --no-profile > $O/r04_rccl_1rank.json 2> $O/r04_rccl_1rank.err
+ONIRIS_DDP_EXCHANGE=mesh ONIRIS_DDP_BF16=1 ONIRIS_FORCE_DIST=1 python bench.py --steps 8 --warmup 4 --cpu-frames 0 --no-extra --no-profile > $O/r04_rccl_1rank_mesh_bf16.json 2> $O/r04_rccl_1rank_mesh_bf16.err
+ONIRIS_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 4 --warmup 2 --cpu-frames 0 --no-profile --batch 2 > $O/r04_selflaunch2.json 2> $O/r04_selflaunch2.err
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ks -o ks -- python3 bench.py --steps 4 --warmup 2 --cpu-frames 0 --no-extra > $O/r04_prof_ks.log 2>&1
+cp "$(find $O/prof_ks -name '*kernel_stats.csv' | head -1)" $O/r04_kernel_stats.csv; rm -rf $O/prof_ks
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_f -o f -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile --no-extra > $O/r04_prof_f.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_w -o w -- python3 bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-profile --no-extra > $O/r04_prof_w.log 2>&1
+python scratch/pmc_traffic.py $O/prof_f $O/prof_w $O/r04_pmc_traffic > /dev/null 2>&1
+rm -rf $O/prof_f $O/prof_w
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ro -o ro -- python3 bench.py --mode rollout --gen-frames 4 --batch 1 > $O/r04_prof_ro.log 2>&1
+cp "$(find $O/prof_ro -name '*kernel_stats.csv' | head -1)" $O/r04_rollout_kernel_stats.csv; rm -rf $O/prof_ro
+ONIRIS_LIB_NAME=liboniris_hip_stamp.so python scratch/stream_stamp.py 8 > $O/r04_stream_stamps.txt 2>&1
+python scratch/c32_bench.py 8 > $O/r04_c32_bench_b8.txt 2>&1
+ONIRIS_BIG_TILE=3 ONIRIS_WGRAD=2 python scratch/c32_bench.py 8 > $O/r04_c32_bench_b8_tilekernels.txt 2>&1
+tail -3 $O/r04_gputests_final.log
