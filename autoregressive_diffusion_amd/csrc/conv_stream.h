@@ -189,12 +189,6 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const ConvStreamDev
   const int n_dma = (ALIAS ? 2 : 3) * per_halo + ((emb && uw == 0) ? 1 : 0);
   const int n_st = (a.ctx_out ? 1 : 0) + 2 * (mps ? ((a.out2 ? 1 : 0) + 1) : emb ? 2 : 1);
   if (nfr <= 0) return;
-  // two workgroups share a CU and run the same phases in the same time: started together they compete for the matrix pipe,
-  // then for the vector ALU.  The second half of the grid (the workgroups that land beside a resident one) starts half a
-  // step late, so that one workgroup's epilogue runs under the other's MFMA section.
-  if ((a.big_tile & 16) && blockIdx.x >= (gridDim.x >> 1)) {
-    __builtin_amdgcn_s_sleep(40);
-  }
   // ---- prologue copies: the two context frames of the first step, then its own frames
   issue_ctx(ts + a.coff0);
   issue_ctx(ts + a.coff1);
