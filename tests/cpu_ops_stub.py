@@ -48,8 +48,26 @@ def _mix(x, cout, pws, extra=()):
     return _Owned.apply((y * ramp).to(BF16), tuple(pws))
 
 
+_saved = {}
+
+
+def uninstall():
+    """Put the product's entry points back (the parent process of the DDP tests runs other tests afterwards)."""
+    from autoregressive_diffusion_amd import ops
+    for (obj, name), val in _saved.items():
+        setattr(obj, name, val)
+    _saved.clear()
+    ops.prelude_reference = None
+
+
 def install():
     from autoregressive_diffusion_amd import ops
+    if _saved:
+        return
+    for obj, names in ((ops.WeightBank, ("prepare", "backward")),
+                       (ops, ("conv", "gated_conv_train", "act", "resample", "attention_train", "FUSED_PRELUDE", "GRAD_SLOTS"))):
+        for n in names:
+            _saved[(obj, n)] = getattr(obj, n)
 
     def prepare(self, training):
         ops.GradSlot.live = []

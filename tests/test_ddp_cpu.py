@@ -628,6 +628,15 @@ def test_real_unet_module_tree_under_ddp_world2(exchange, bf16):
     assert steps0["enc.64x64_conv.last_frame_conv.weight.weight"] == 4 and steps0["enc.64x64_conv.weight.weight"] == 3
     assert steps0["enc.64x64_conv.gating.mult"] == 3 and steps0["out_res.mult"] == 0 and steps0["emb_time.weight.weight"] == 0
     # single process, same stub ops: mean of the two ranks' gradients per step (accumulated micro-step included)
+    import cpu_ops_stub
+    try:
+        _real_tree_reference(p0, bf16)
+    finally:
+        cpu_ops_stub.uninstall()                         # (this process runs other test files afterwards)
+
+
+def _real_tree_reference(p0, bf16):
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW, FlatEMA
     unet = _build_gym_unet(400)
     flat = FlatParams(unet, lazy_small=True)
     opt = FlatAdamW(flat, lr=1e-3, weight_decay=0.01)
