@@ -38,7 +38,7 @@ class ConvArgs(C.Structure):
                 ("res", c_void_p), ("escale", c_void_p), ("emb_gain", c_void_p), ("out2", c_void_p),
                 ("ta", c_float), ("tb", c_float), ("clip", c_float), ("ctx_out", c_void_p),
                 ("big_tile", c_int32), ("escale_pitch", c_int32),
-                ("splitk_ws", c_void_p), ("splitk_ws_bytes", C.c_size_t)]
+                ("splitk_ws", c_void_p), ("splitk_ws_bytes", C.c_size_t), ("clip_flag", c_void_p)]
 
 
 class WgradArgs(C.Structure):
@@ -100,7 +100,7 @@ _SIGS = {
                                       c_int, c_int, c_int, c_int64, c_void_p]),
     "oniris_gconv_bwd_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
-                                       c_float, c_float, c_float, c_int, c_void_p]),
+                                       c_float, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "oniris_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
                                c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,

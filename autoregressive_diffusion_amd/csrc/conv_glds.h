@@ -383,6 +383,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     // -- epilogue: lane-local math (lane = position), bf16 results transposed through a wave-private LDS tile so that
     // global stores are 16 B per lane over whole channel rows
     bf16* og = (bf16*)a.out;
+    bool clip_hit = false;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
       const int ptile = (wp + NWP * m) * 32;              // first position of this tile inside the workgroup tile
@@ -442,7 +443,10 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
 #pragma unroll
               for (int k = 0; k < 4; ++k) {
                 float o = a.ta * bf2f(rv[k]) + a.tb * v[4 * g + k];
-                if (a.clip > 0.f) o = fminf(fmaxf(o, -a.clip), a.clip);
+                if (a.clip > 0.f) {
+                  o = fminf(fmaxf(o, -a.clip), a.clip);
+                  clip_hit |= !(fabsf(bf2f(f2bf(o))) < a.clip);     // (what the backward's mask tests: the STORED value)
+                }
                 v[4 * g + k] = o;
               }
             }
@@ -482,6 +486,9 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
           flush((bf16*)a.ctx_out, (size_t)cur.b * T * HWp);
         }
       }
+    }
+    if (a.clip_flag && __builtin_amdgcn_ballot_w64(clip_hit) != 0ull) {      // (practically never: OnirisConvArgs.clip_flag)
+      if (lane == 0) atomicOr(a.clip_flag, 1);
     }
     CSTAMP(6)
     if (!more) break;

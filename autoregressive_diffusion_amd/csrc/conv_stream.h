@@ -317,13 +317,17 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const ConvStreamDev
 #pragma unroll
       for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(resq[g]));
       float o[16];
+      bool clip_hit = false;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const bf16x4 rv = __builtin_bit_cast(bf16x4, resq[g]);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           float q = a.ta * bf2f(rv[k]) + a.tb * v[4 * g + k];
-          if (a.clip > 0.f) q = fminf(fmaxf(q, -a.clip), a.clip);
+          if (a.clip > 0.f) {
+            q = fminf(fmaxf(q, -a.clip), a.clip);
+            clip_hit |= !(fabsf(bf2f(f2bf(q))) < a.clip);         // (what the backward's mask tests: the STORED value)
+          }
           o[4 * g + k] = q;
         }
       }
@@ -331,6 +335,10 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const ConvStreamDev
       if (a.out2) { put(v); flush((bf16*)a.out2, blk); }
       put(o);
       flush((bf16*)a.out, blk);
+      if (a.clip_flag && __builtin_amdgcn_ballot_w64(clip_hit) != 0ull) {    // (practically never: OnirisConvArgs.clip_flag)
+        if (lane == 0) atomicOr(a.clip_flag, 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // one more op in the vmcnt stream than the counted waits know
+      }
       SSTAMP(6)
       continue;
     }

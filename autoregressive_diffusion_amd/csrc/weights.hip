@@ -458,14 +458,19 @@ __global__ __launch_bounds__(256) void gconv_bwd_prep_kernel(const bf16* __restr
 //   mode 2 (EPI_MPSUM):    g = d out, out = clip(ta*res + tb*v) -> dres = ta*g*mask ; dout = tb*g*mask
 // then S1/S2/dy3 exactly as gconv_bwd_prep_kernel.  raw = y (mode 1) or v (mode 2).
 template <int MODE>
-__global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* __restrict__ g, const bf16* __restrict__ raw,
+__global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* g, const bf16* __restrict__ raw,
                                                               const bf16* __restrict__ y3, const float* __restrict__ ca,
                                                               const float* __restrict__ cb, const float* __restrict__ cs,
-                                                              const bf16* __restrict__ xo, bf16* __restrict__ dout,
+                                                              const bf16* __restrict__ xo, bf16* dout,
                                                               bf16* __restrict__ dres, bf16* __restrict__ dy3,
                                                               float* __restrict__ dca, float* __restrict__ dcb,
                                                               float* __restrict__ dcs, int T, int P, int C, float ta,
-                                                              float tb, float clip, int pix_per_block, int cs_pitch) {
+                                                              float tb, float clip, int pix_per_block, int cs_pitch,
+                                                              const int* __restrict__ clip_flag, float* __restrict__ ca_scaled) {
+  // mode 2, aliasing protocol (include/oniris.h): dgrad / wgrad read g itself with tb folded into the own-frame coefficient;
+  // only a forward that really clipped something makes this pass read xo and write the masked gradient (in place)
+  const bool alias = MODE == 2 && clip_flag != nullptr;
+  const bool masked = MODE == 2 && clip > 0.f && (!alias || *clip_flag != 0);
   __shared__ float red[16];
   __shared__ float accs[2][512];
   const int bt = blockIdx.x, b = bt / T, t = bt % T;
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* __res
         const bf16x8 rv = *(const bf16x8*)(raw + o);
         bf16x8 dv, drv;
         bf16x8 xv;
-        if (MODE == 2 && clip > 0.f) xv = *(const bf16x8*)(xo + o);
+        if (masked) xv = *(const bf16x8*)(xo + o);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float r_ = bf2f(rv[i]);
@@ -524,16 +529,17 @@ __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* __res
             d = dz * cv[s][i];
           } else {
             float gg = bf2f(gv[i]);
-            if (clip > 0.f && !(fabsf(bf2f(xv[i])) < clip)) gg = 0.f;
+            if (masked && !(fabsf(bf2f(xv[i])) < clip)) gg = 0.f;
             drv[i] = f2bf(gg * ta);
             d = gg * tb;
+            if (alias) dv[i] = f2bf(gg);                // (what dgrad / wgrad read: the gradient itself, masked if need be)
           }
-          dv[i] = f2bf(d);
-          const float dr = bf2f(dv[i]);                 // the rounded value is what dgrad / wgrad will consume
+          float dr = d;                                 // aliasing: tb * (bf16 gradient), exact in fp32
+          if (!alias) { dv[i] = f2bf(d); dr = bf2f(dv[i]); }      // else: the rounded value is what dgrad / wgrad will consume
           s1[s] += dr * r_; s2[s] += dr * bf2f(yv3[i]); acc3[i] += cbv[s] * dr;
         }
-        *(bf16x8*)(dout + o) = dv;
-        if (MODE == 2) *(bf16x8*)(dres + o) = drv;
+        if (!alias || masked) *(bf16x8*)(dout + o) = dv;       // (aliasing + masked: dout IS g -- every element is read
+        if (MODE == 2) *(bf16x8*)(dres + o) = drv;             //  and rewritten by the same lane)
       }
       bf16x8 o3;
 #pragma unroll
@@ -562,7 +568,10 @@ __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* __res
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
     const float a_ = block_sum(s1[s], red), b_ = block_sum(s2[s], red);
-    if (threadIdx.x == 0) { atomicAdd(dca + nn[s], (a_ - cbv[s] * b_) / ca[nn[s]]); atomicAdd(dcb + nn[s], b_); }
+    if (threadIdx.x == 0) {
+      atomicAdd(dca + nn[s], (a_ - cbv[s] * b_) / ca[nn[s]]); atomicAdd(dcb + nn[s], b_);
+      if (alias && blockIdx.y == 0) ca_scaled[nn[s]] = tb * ca[nn[s]];
+    }
   }
   if (MODE == 1) {
     __syncthreads();
@@ -576,12 +585,15 @@ extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, 
                                       const float* coef_ctx, const float* cscale, const void* xo, void* dout, void* dres,
                                       void* dy3, float* d_coef_own, float* d_coef_ctx, float* d_cscale, int B, int T,
                                       int P, int C, float ta, float tb, float clip, int cscale_pitch,
-                                      oniris_stream_t stream_) {
+                                      const int32_t* clip_flag, float* coef_own_scaled, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG((mode == 1 || mode == 2) && g && raw && y3 && coef_own && coef_ctx && dout && dy3 && d_coef_own &&
                    d_coef_ctx && B > 0 && T > 0 && P > 0 && C % 8 == 0 && C <= 512, "gconv_bwd_fused: bad arguments");
   ONIRIS_CHECK_ARG(mode != 1 || (cscale && d_cscale), "gconv_bwd_fused: mode 1 needs cscale / d_cscale");
   ONIRIS_CHECK_ARG(mode != 2 || (dres && (clip <= 0.f || xo)), "gconv_bwd_fused: mode 2 needs dres (and xo when clipping)");
+  ONIRIS_CHECK_ARG((clip_flag == nullptr) == (coef_own_scaled == nullptr) && (mode == 2 || !clip_flag),
+                   "gconv_bwd_fused: clip_flag and coef_own_scaled come together, in mode 2");
+  ONIRIS_CHECK_ARG(!clip_flag || dout == g, "gconv_bwd_fused: the aliasing protocol masks g in place (pass dout = g)");
   // pixel slices so that the launch covers the chip (B*T alone is ~128 blocks); partial sums meet through atomics,
   // so d_coef_own / d_coef_ctx / d_cscale must be ZERO on entry.
   int slices = 1;
@@ -602,11 +614,12 @@ extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, 
   if (mode == 1)
     hipLaunchKernelGGL(gconv_bwd_fused_kernel<1>, dim3(B * T, slices), dim3(nth), 0, stream, (const bf16*)g,
                        (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
-                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp);
+                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp, nullptr, nullptr);
   else
     hipLaunchKernelGGL(gconv_bwd_fused_kernel<2>, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)g,
                        (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
-                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp);
+                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp,
+                       (const int*)clip_flag, coef_own_scaled);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -455,9 +455,26 @@ def _patch_w(W):
     return 16 if W >= 16 else W
 
 
+def _s2ctx_family(T, H, W, Cin, CinP, CoutP, ctx_T, coff, ctx_fill):
+    """Which kernel family conv_dispatch_s2ctx() (csrc/conv_fwd_s2ctx.hip) picks for a gated conv in the DART training layout:
+    'stream' (conv_stream.h), 'glds16' / 'glds8' (conv_glds.h) or 'staged' (conv_kernels.h).  Mirrors the C side."""
+    ok = ctx_fill in (0.0, 1.0)
+    if (BIG_TILE >= 4 and ok and Cin == 32 and CinP == 64 and CoutP == 32 and W % 16 == 0 and H % 4 == 0 and ctx_T == T
+            and tuple(coff) in ((-2, -1), (2, 1))):
+        return "stream"
+    if BIG_TILE >= 3 and ok and Cin % 32 == 0 and H % 16 == 0 and W % 16 == 0:
+        return "glds16"
+    if BIG_TILE >= 3 and ok and Cin % 32 == 0 and H == 8 and W == 8 and CoutP % 64 == 0:
+        return "glds8"
+    return "staged"
+
+
+CLIP_FLAG = int(_os.environ.get("ONIRIS_CLIP_FLAG", "1"))    # 0: the mp_sum backward always reads the clipped output and writes a masked gradient copy (A/B, tests)
+
+
 def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP, Cout, CoutP, taps,
                  ctx_bstride=0, ctx_T=0, coff=(0, 0), ctx_fill=0.0, epi=0, res=None, escale=None, emb_gain=None,
-                 out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None):
+                 out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None, clip_flag=None):
     if KernelProfile.enabled:
         flops = 2.0 * B * S * T * H * W * Cout * Cin * taps
         if ctx is not None:
@@ -485,7 +502,7 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         try:
             e0, e1 = _timed_launch(lambda: _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP,
                                                         Cout, CoutP, taps, ctx_bstride, ctx_T, coff, ctx_fill, epi, res, escale,
-                                                        emb_gain, out2, ta, tb, clip, ctx_out))
+                                                        emb_gain, out2, ta, tb, clip, ctx_out, clip_flag))
         finally:
             KernelProfile.enabled = True
         # algorithmic HBM bytes of the launch (every operand read once, every result written once; the context
@@ -508,6 +525,7 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     if escale is not None:
         a.escale_pitch = escale.stride(0)
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
+    a.clip_flag = _p(clip_flag)
     a.big_tile = BIG_TILE
     if SPLITK and B * S * T * H * W <= 64 * 256:      # few tiles (one rollout frame): lend the split-K workspace
         ws = _splitk_workspace(x.device)
@@ -629,6 +647,7 @@ class _ConvOp(torch.autograd.Function):
         kw = {}
         raw = torch.empty((N, H, W, Co), dtype=BF16, device=dev)
         ret = raw
+        clip_flag = None
         if cfg.epi == "emb_silu":
             cs = _rows_f32(cscale)
             assert tuple(cs.shape) == (N, Co), (cs.shape, N, Co)
@@ -640,7 +659,14 @@ class _ConvOp(torch.autograd.Function):
             kw = dict(epi=_lib.EPI_MPSUM, res=res, ta=cfg.ta, tb=cfg.tb, clip=cfg.clip, out2=raw if keep_raw else None)
             if not keep_raw:
                 raw = None
+            # "did the clip change anything?" -- one int of the step's pre-zeroed arena, set by the forward launch (the kernel
+            # families that support it), read by the backward pre-pass: see OnirisConvArgs.clip_flag
+            if (CLIP_FLAG and keep_raw and Co <= 512 and cfg.clip > 0 and
+                    _s2ctx_family(cfg.T, H, W, Cin, pw2.CinP, pw2.CoutP, cfg.T, (-2, -1), 1.0) != "staged"):
+                clip_flag = pw2.bank.zero_arena.take(1, dev).view(torch.int32)
+                kw["clip_flag"] = clip_flag
         y3 = ca32 = cb32 = None
+        ctx.clip_flag = kw.get("clip_flag")
         first_out = ret if cfg.epi == "mpsum" else (raw if raw is not None else ret)
         if gated:
             B, T = cfg.B, cfg.T
@@ -670,9 +696,19 @@ class _ConvOp(torch.autograd.Function):
         dcs = dres = None
         dx = dca = dcb = None
         fused = gated and cfg.epi in ("emb_silu", "mpsum") and Co <= 512
+        ca_own = ca                                 # the own-frame coefficient dgrad / wgrad apply to `dout`
         if fused:                                   # epilogue adjoint + gate/context pre-pass in ONE pass over g
             B, T = cfg.B, cfg.T
-            dout = torch.empty_like(g)
+            flag = getattr(ctx, "clip_flag", None) if cfg.epi == "mpsum" else None
+            if flag is not None:
+                # aliasing protocol (include/oniris.h): dout = tb * g * mask is not written -- dgrad and wgrad read g with
+                # the coefficient vector tb * ca; the mask exists (and is applied to g in place) only if the forward clipped
+                # (g is the gradient of this conv's output alone -- produced by the one kernel that joined all of its
+                # consumers' gradients -- and nothing reads it after this backward)
+                dout = g
+                ca_own = torch.empty_like(ca)
+            else:
+                dout = torch.empty_like(g)
             dy3 = torch.empty_like(y3)
             acc = pw2.bank.zero_arena.take(N * (2 + (Co if cfg.epi == "emb_silu" else 0)), dev)
             dca, dcb = acc[:N], acc[N:2 * N]
@@ -683,7 +719,7 @@ class _ConvOp(torch.autograd.Function):
             check(lib.oniris_gconv_bwd_fused(1 if cfg.epi == "emb_silu" else 2, _p(g), _p(raw), _p(y3), _p(ca), _p(cb),
                                              _p(cs), _p(xo), _p(dout), _p(dres), _p(dy3), _p(dca), _p(dcb), _p(dcs), B, T,
                                              H * W, Co, cfg.ta, cfg.tb, cfg.clip, cs.stride(0) if cs is not None else 0,
-                                             _stream()), "gconv_bwd_fused")
+                                             _p(flag), _p(ca_own) if flag is not None else None, _stream()), "gconv_bwd_fused")
         elif cfg.epi == "emb_silu":
             dout = torch.empty_like(g)
             dcs = pw2.bank.zero_arena.take(N * Co, dev)[:N * Co].view(N, Co)     # (zero-filled once per step with all the others)
@@ -706,11 +742,11 @@ class _ConvOp(torch.autograd.Function):
             if ctx.needs_input_grad[0]:
                 dx = torch.empty_like(x)
                 sel = _clean_selector(B, T, dev)               # the context gradient only reaches the clean slot
-                _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca, sel, B, 2, T, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb, 9,
+                _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca_own, sel, B, 2, T, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb, 9,
                              ctx_bstride=T, ctx_T=T, coff=(2, 1), ctx_fill=0.0)
             grp = []                                 # own-frame weight + the two context taps: ONE split-K launch
             if pw2.param.requires_grad:
-                grp.append(_wgrad_args(x, dout, pw2, ca, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0))
+                grp.append(_wgrad_args(x, dout, pw2, ca_own, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0))
             if pw3.param.requires_grad:
                 for j, coff in enumerate((-2, -1)):
                     grp.append(_wgrad_args(x, dy3, pw3, None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T, coff,

@@ -225,6 +225,12 @@ typedef struct OnirisConvArgs {
    * a second launch adds them in slice order and runs the epilogue.                                               */
   float* splitk_ws;
   size_t splitk_ws_bytes;
+  /* Optional (EPI_MPSUM with clip > 0, ABI 10): device int that the launch ORs 1 into when the clip changed at least one
+   * element.  Zero it before the launch; kernels that do not support it leave it alone (the caller knows which ones do:
+   * csrc/conv_glds.h, csrc/conv_stream.h).  The backward pre-pass reads it: activations of a magnitude-preserving net
+   * practically never reach the clip, and then the gradient needs no mask -- no read of the clipped output, no masked copy
+   * of the incoming gradient (oniris_gconv_bwd_fused, mode 2).                                                      */
+  int32_t* clip_flag;
 } OnirisConvArgs;
 
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);
@@ -275,7 +281,13 @@ int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void*
                            const float* coef_ctx, const float* cscale, const void* xo, void* dout, void* dres, void* dy3,
                            float* d_coef_own, float* d_coef_ctx, float* d_cscale, int B, int T, int P, int C, float ta,
                            float tb, float clip,
-                           int cscale_pitch /* floats between rows of cscale; 0 = C */, oniris_stream_t stream);
+                           int cscale_pitch /* floats between rows of cscale; 0 = C */,
+                           const int32_t* clip_flag, float* coef_own_scaled, oniris_stream_t stream);
+/* clip_flag / coef_own_scaled (mode 2 only, both or neither; ABI 10): the ALIASING protocol.  dout = tb * g * mask is a scaled
+ * copy of the incoming gradient, so the launch does not write it: dgrad and weight gradient read g itself with the
+ * coefficient vector coef_own_scaled[n] = tb * coef_own[n] (written here, [B*2*T]); `dout` is ignored (pass g).  When
+ * *clip_flag != 0 (the forward clipped something: OnirisConvArgs.clip_flag) the mask is applied to g IN PLACE -- g must then
+ * be a buffer this backward owns -- and xo is read; otherwise xo is not touched: 4 instead of 6 tensor passes.       */
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Fused magnitude-preserving glue (HBM-bound, one pass each) -- the elementwise chains of Block.forward
