@@ -39,3 +39,9 @@ stamp: build/attention_stamp.o build/conv_fwd_s2ctx_stamp.o $(OBJS)
 
 clean:
 	rm -rf build $(OUT)
+
+# experiment builds of the gated-conv translation unit with other -D settings (VNAME / VDEF), e.g.
+#   make variant VNAME=m816 VDEF="-DGLDS_MID_OWN=8 -DGLDS_MID_CTX=16"   -> autoregressive_diffusion_amd/liboniris_hip_m816.so
+variant: $(OBJS)
+	$(HIPCC) $(HIPFLAGS) $(VDEF) -c $(CSRC)/conv_fwd_s2ctx.hip -o build/conv_fwd_s2ctx_$(VNAME).o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o autoregressive_diffusion_amd/liboniris_hip_$(VNAME).so build/conv_fwd_s2ctx_$(VNAME).o $(filter-out build/conv_fwd_s2ctx.hip.o,$(OBJS))
