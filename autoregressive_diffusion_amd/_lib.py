@@ -93,6 +93,12 @@ _SIGS = {
                                      c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
     "oniris_loss_tail": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
                                  c_int, c_int, c_int, c_int, c_int, c_float, c_void_p]),
+    "oniris_qkv_norm_hd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                   c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oniris_qkv_norm_hd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                       c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oniris_rope_hd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_int, c_void_p]),
     "oniris_conv_fwd": (c_int, [C.POINTER(ConvArgs), c_void_p]),
     "oniris_conv_wgrad": (c_int, [C.POINTER(WgradArgs), c_void_p]),
     "oniris_conv_wgrad_group": (c_int, [C.POINTER(WgradArgs), c_int, c_void_p]),

@@ -17,10 +17,10 @@ class _AttentionBase(nn.Module):
         self.channels, self.num_heads, self.attn_balance = channels, num_heads, attn_balance
         if num_heads == 0:
             return
-        if channels != 64 * num_heads:
-            # every configuration of the reference builds its attention with channels_per_head = 64
-            # (networks_edm2.py:28,39); the kernels are written for that head dimension and nothing else
-            raise NotImplementedError(f"attention kernels: head dimension 64 only (got {channels} channels / {num_heads} heads)")
+        # every configuration of the reference builds its attention with channels_per_head = 64 (networks_edm2.py:28,39) and
+        # the attention kernels are written for that; heads of 8 / 16 / 32 channels (the reference's own consistency tests
+        # use 16) run through the same kernels zero-padded to 64 (ops._AttentionHdFn, csrc/attention_hd.hip)
+        ops._head_dim(channels, num_heads)
         self.attn_qkv = MPConv(channels, channels * 3, kernel=[1, 1])
         self.attn_qkv.weight.perm3 = True          # packed rows (m c s) -> (s m c): q | k | v contiguous
         self.attn_proj = MPConv(channels, channels, kernel=[1, 1])

@@ -326,6 +326,8 @@ class UNet(BetterModule):
                 kv = (cache.get((side, name)) or {}).get("attn") if isinstance(block, Block) else None
                 if att is None or kv is None or not hasattr(att, "rope") or "_tokens_per_frame" not in att.__dict__:
                     continue
+                if att.channels != 64 * att.num_heads:            # (padded small heads: no KV ring, ops._attention_eval_hd)
+                    continue
                 P = att.__dict__["_tokens_per_frame"]
                 nk = kv[0].shape[1] // P + 1
                 ops.rope_tables(att.rope.inv_freq, att.rope.scale, nk, dev)

@@ -1255,7 +1255,9 @@ def rope_tables(inv_freq, scale_vec, n_pos, device, scale_base=64):
     only -- so a rollout, whose key count grows by one per generated frame, uploads nothing per frame (a host->device
     copy from pageable memory waits for everything queued on the stream: it used to stall the host once per frame and
     layer, with the previous frame's 31 evaluations still in the queue)."""
-    key = (str(device), inv_freq.data_ptr(), scale_vec.data_ptr(), scale_base)
+    # (numel: a freed module's buffer address is recycled by the allocator -- a module with another head dimension must not
+    # find the tables of a dead one; equal head dimensions have equal tables, RoPe.py:10-16)
+    key = (str(device), inv_freq.data_ptr(), scale_vec.data_ptr(), scale_base, inv_freq.numel())
     m = _rope_cache.get(key)
     if m is None or m[0] < n_pos:
         cap = max(64, 2 * n_pos, 2 * (m[0] if m is not None else 0))
@@ -1305,6 +1307,82 @@ def _train_sched(T, P, n_pairs, dev, which):
     return attn_schedule(w, n_pairs, dev)
 
 
+def _attn_core_fwd(qr, kr, v, kind, B, T, heads, P):
+    """The attention launch of a training step on prepared q (rotated, carrying the softmax scale), k, v (N, P, heads*64):
+    'video' = DART training table over B sequences of 2T frames, 'frame' = dense per frame.  Returns (out, lse, tabs, meta)."""
+    N, _, C = qr.shape
+    dev = qr.device
+    if kind == "video":
+        frames = N // B
+        Bq, L = B, frames * P
+        mask_mode = 2
+        tabs = device_tables("train", T, P, dev)
+        if tabs is None:
+            raise RuntimeError(f"make_train_mask returns None for T={T}, P={P} (T*P must be a multiple of 128)")
+    else:
+        frames, Bq, L = 1, N, P
+        mask_mode, tabs = 0, None
+    out = torch.empty((N, P, C), dtype=BF16, device=dev)
+    lse = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
+    a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
+    fl = _attn_flops(kind, Bq, T, heads, L, P)
+    ks = 2 if (mask_mode != 0 and L >= 2048) else 1
+    name = f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>"
+    if mask_mode == 2 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64 and L % 128 == 0 and Bq * heads < 32768:
+        # persistent kernel: query blocks of 128 rows, cost = key blocks of its table row + 1 (fixed per-item work)
+        sched = _train_sched(T, P, Bq * heads, dev, "fwd")
+        a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+        name = f"attn_fwd_ws_kernel<MODE={mask_mode}>"
+    _profiled(name, fl, lambda: check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd"))
+    return out, lse, tabs, (kind, B, T, heads, Bq, L, frames, P, C, mask_mode)
+
+
+def _attn_core_bwd(qr, kr, v, out, lse, dout, tabs, meta):
+    """dq (w.r.t. the unscaled q), dk, dv of _attn_core_fwd."""
+    kind, B, T, heads, Bq, L, frames, P, C, mask_mode = meta
+    dev = qr.device
+    delta = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
+    dkv_ws = (mask_mode == 2 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and tabs[3].shape[1] <= 64 and L % 128 == 0
+              and Bq * heads < 32768)
+    neg = torch.empty((2, Bq, heads, L), dtype=torch.float32, device=dev) if dkv_ws else None     # -lse | -delta
+    check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), None, _p(lse) if dkv_ws else None, _p(neg), Bq, heads, L, C,
+                                   _stream()), "attn_bwd_prep")
+    dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
+    a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
+    a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
+    fl = _attn_flops(kind, Bq, T, heads, L, P)
+    ks = 2 if (mask_mode != 0 and L >= 2048) else 1
+    if dkv_ws and ATTN_DQ_PERSISTENT and tabs[1].shape[1] <= 64:
+        # persistent dQ kernel on the forward's work list (query blocks, longest first); reads the NEGATED row constants
+        sched = _train_sched(T, P, Bq * heads, dev, "fwd")
+        a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+        a.lse, a.delta = _p(neg[0]), _p(neg[1])
+        _profiled(f"attn_bwd_dq_ws_kernel<MODE={mask_mode}>", 1.5 * fl,
+                  lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
+        a.sched, a.sched_wgs, a.sched_slots = None, 0, 0
+        a.lse, a.delta = _p(lse), _p(delta)
+    else:
+        _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
+                  lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
+    if dkv_ws:
+        # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
+        # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch); it reads the NEGATED row constants
+        sched = _train_sched(T, P, Bq * heads, dev, "dkv")
+        a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+        a.lse, a.delta = _p(neg[0]), _p(neg[1])
+        _profiled(f"attn_bwd_dkv_ws_kernel<MODE={mask_mode}>", 2.0 * fl,
+                  lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))
+    else:
+        # causal tables: split every key block's query list so that no workgroup walks more than ~32 sub-tiles
+        nch = max(1, min(ATTN_DKV_CHUNKS, L // ATTN_DKV_MIN_L)) if mask_mode == 2 else 1
+        if nch > 1:
+            part = torch.empty((2, nch, Bq, L, C), dtype=torch.float32, device=dev)
+            a.dkv_part, a.dkv_chunks = _p(part), nch
+        _profiled(f"attn_bwd_dkv_kernel<MODE={mask_mode}>", 2.0 * fl,
+                  lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))     # (+ the partial-sum reduce)
+    return dq, dk, dv
+
+
 class _AttentionFn(torch.autograd.Function):
     """qkv (N, P, 3C) bf16 (channel = s*C + head*64 + c)  ->  attention output (N, P, C).
     kind: 'video' (DART training mask + RoPE over frames, B sequences of 2T frames) or 'frame' (dense per frame)."""
@@ -1315,49 +1393,28 @@ class _AttentionFn(torch.autograd.Function):
         N, P, C3 = qkv.shape
         C = C3 // 3
         if C != 64 * heads:
-            raise NotImplementedError(f"attention kernels: head dimension 64 only (got {C} channels / {heads} heads)")
+            raise NotImplementedError(f"_AttentionFn: 64-channel heads (got {C} channels / {heads} heads: _AttentionHdFn)")
         dev = qkv.device
         q = torch.empty((N, P, C), dtype=BF16, device=dev)
         k, v = torch.empty_like(q), torch.empty_like(q)
         fused_rope = kind == "video" and FUSED_ROPE
         if not fused_rope:
             check(lib.oniris_qkv_norm(_p(qkv), _p(q), _p(k), _p(v), N * P, C, 0, 0, 0, _stream()), "qkv_norm")
-        if kind == "video":
-            frames = N // B
-            Bq, L = B, frames * P
-            tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], T, dev)
-            mask_mode = 2
-            tabs = device_tables("train", T, P, dev)
-            if tabs is None:
-                raise RuntimeError(f"make_train_mask returns None for T={T}, P={P} (T*P must be a multiple of 128)")
-        else:
-            frames, Bq, L = 1, N, P
-            tabs_r, mask_mode, tabs = None, 0, None
+        tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], T, dev) if kind == "video" else None
         if fused_rope:              # normalisation + rotation in one pass over qkv (frames = 2T: position = frame mod T)
             cs_, sn_, sc_ = tabs_r
             check(lib.oniris_qkv_norm_rope(_p(qkv), _p(q), _p(k), _p(v), _p(cs_), _p(sn_), _p(sc_), N * P, C, P, T, _stream()),
                   "qkv_norm_rope")
             qr, kr = q, k
         elif kind == "video":
+            frames = N // B
             qr, kr = torch.empty_like(q), torch.empty_like(k)
-            _rope(q, qr, None, tabs_r, 1, Bq, frames, P, C, 0, T)
-            _rope(k, kr, None, tabs_r, 2, Bq, frames, P, C, 0, T)
+            _rope(q, qr, None, tabs_r, 1, B, frames, P, C, 0, T)
+            _rope(k, kr, None, tabs_r, 2, B, frames, P, C, 0, T)
         else:
             qr, kr = q, k
-        out = torch.empty((N, P, C), dtype=BF16, device=dev)
-        lse = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
-        a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
-        fl = _attn_flops(kind, Bq, T, heads, L, P)
-        ks = 2 if (mask_mode != 0 and L >= 2048) else 1
-        name = f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>"
-        sched = None
-        if mask_mode == 2 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64 and L % 128 == 0 and Bq * heads < 32768:
-            # persistent kernel: query blocks of 128 rows, cost = key blocks of its table row + 1 (fixed per-item work)
-            sched = _train_sched(T, P, Bq * heads, dev, "fwd")
-            a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
-            name = f"attn_fwd_ws_kernel<MODE={mask_mode}>"
-        _profiled(name, fl, lambda: check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd"))
-        ctx.meta = (kind, B, T, heads, Bq, L, frames, P, C, mask_mode)
+        out, lse, tabs, meta = _attn_core_fwd(qr, kr, v, kind, B, T, heads, P)
+        ctx.meta = meta
         ctx.tabs, ctx.tabs_r = tabs, tabs_r
         ctx.save_for_backward(qkv, qr, kr, v, out, lse)
         return out
@@ -1366,47 +1423,8 @@ class _AttentionFn(torch.autograd.Function):
     def backward(ctx, dout):
         qkv, qr, kr, v, out, lse = ctx.saved_tensors
         kind, B, T, heads, Bq, L, frames, P, C, mask_mode = ctx.meta
-        dev = qkv.device
         dout = dout.contiguous()
-        delta = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
-        dkv_ws = (mask_mode == 2 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and ctx.tabs[3].shape[1] <= 64 and L % 128 == 0
-                  and Bq * heads < 32768)
-        neg = torch.empty((2, Bq, heads, L), dtype=torch.float32, device=dev) if dkv_ws else None     # -lse | -delta
-        check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), None, _p(lse) if dkv_ws else None, _p(neg), Bq, heads, L, C,
-                                       _stream()), "attn_bwd_prep")
-        dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
-        a = _attn_args(qr, kr, v, None, None, None, out, lse, ctx.tabs, Bq, heads, L, L, C, mask_mode, P, T)
-        a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
-        fl = _attn_flops(kind, Bq, T, heads, L, P)
-        ks = 2 if (mask_mode != 0 and L >= 2048) else 1
-        if dkv_ws and ATTN_DQ_PERSISTENT and ctx.tabs[1].shape[1] <= 64:
-            # persistent dQ kernel on the forward's work list (query blocks, longest first); reads the NEGATED row constants
-            sched = _train_sched(T, P, Bq * heads, dev, "fwd")
-            a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
-            a.lse, a.delta = _p(neg[0]), _p(neg[1])
-            _profiled(f"attn_bwd_dq_ws_kernel<MODE={mask_mode}>", 1.5 * fl,
-                      lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
-            a.sched, a.sched_wgs, a.sched_slots = None, 0, 0
-            a.lse, a.delta = _p(lse), _p(delta)
-        else:
-            _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
-                      lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
-        if dkv_ws:
-            # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
-            # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch); it reads the NEGATED row constants
-            sched = _train_sched(T, P, Bq * heads, dev, "dkv")
-            a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
-            a.lse, a.delta = _p(neg[0]), _p(neg[1])
-            _profiled(f"attn_bwd_dkv_ws_kernel<MODE={mask_mode}>", 2.0 * fl,
-                      lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))
-        else:
-            # causal tables: split every key block's query list so that no workgroup walks more than ~32 sub-tiles
-            nch = max(1, min(ATTN_DKV_CHUNKS, L // ATTN_DKV_MIN_L)) if mask_mode == 2 else 1
-            if nch > 1:
-                part = torch.empty((2, nch, Bq, L, C), dtype=torch.float32, device=dev)
-                a.dkv_part, a.dkv_chunks = _p(part), nch
-            _profiled(f"attn_bwd_dkv_kernel<MODE={mask_mode}>", 2.0 * fl,
-                      lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))     # (+ the partial-sum reduce)
+        dq, dk, dv = _attn_core_bwd(qr, kr, v, out, lse, dout, ctx.tabs, ctx.meta)
         dqkv = torch.empty_like(qkv)
         N = qkv.shape[0]
         if kind == "video" and FUSED_ROPE:
@@ -1424,8 +1442,69 @@ class _AttentionFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None
 
 
+HEAD_DIMS_PADDED = (8, 16, 32)        # served through the 64-channel kernels on zero-padded heads (csrc/attention_hd.hip)
+
+
+def _head_dim(C, heads):
+    d = C // max(heads, 1)
+    if heads <= 0 or C != heads * d or (d != 64 and d not in HEAD_DIMS_PADDED):
+        raise NotImplementedError(f"attention head dimension {C}/{heads}: 64, or 8 / 16 / 32 through the padded path")
+    return d
+
+
+def _pad_heads(t, heads, d):
+    """(N, P, heads*d) -> (N, P, heads*64) with zeros in channels d..63 of every head."""
+    N, P, _ = t.shape
+    out = torch.zeros((N, P, heads, 64), dtype=t.dtype, device=t.device)
+    out[..., :d] = t.reshape(N, P, heads, d)
+    return out.view(N, P, heads * 64)
+
+
+def _unpad_heads(t, heads, d):
+    N, P, _ = t.shape
+    return t.view(N, P, heads, 64)[..., :d].reshape(N, P, heads * d)
+
+
+class _AttentionHdFn(torch.autograd.Function):
+    """_AttentionFn for heads of 8 / 16 / 32 channels: per-head norm (+ rotary embedding) into zero-padded 64-channel heads
+    (oniris_qkv_norm_hd), the SAME attention launches, the padding dropped from the result."""
+
+    @staticmethod
+    def forward(ctx, qkv, kind, B, T, heads, rope_bufs, need_grad):
+        _need_gpu(qkv)
+        N, P, C3 = qkv.shape
+        d = _head_dim(C3 // 3, heads)
+        dev = qkv.device
+        qkv = qkv.contiguous()
+        q = torch.empty((N, P, heads * 64), dtype=BF16, device=dev)
+        k, v = torch.empty_like(q), torch.empty_like(q)
+        tabs_r = rope_tables(rope_bufs[0], rope_bufs[1], T, dev) if kind == "video" else (None, None, None)
+        rope = 3 if kind == "video" else 0
+        check(lib.oniris_qkv_norm_hd(_p(qkv), _p(q), _p(k), _p(v), _p(tabs_r[0]), _p(tabs_r[1]), _p(tabs_r[2]), N * P, heads, d, P,
+                                     T if kind == "video" else 1, 0, rope, T if kind == "video" else 1, _stream()), "qkv_norm_hd")
+        out, lse, tabs, meta = _attn_core_fwd(q, k, v, kind, B, T, heads, P)
+        ctx.meta, ctx.tabs, ctx.tabs_r, ctx.hd = meta, tabs, tabs_r, (d, rope)
+        ctx.save_for_backward(qkv, q, k, v, out, lse)
+        return _unpad_heads(out, heads, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, q, k, v, out, lse = ctx.saved_tensors
+        kind, B, T, heads, Bq, L, frames, P, C, mask_mode = ctx.meta
+        d, rope = ctx.hd
+        dq, dk, dv = _attn_core_bwd(q, k, v, out, lse, _pad_heads(dout.contiguous(), heads, d), ctx.tabs, ctx.meta)
+        dqkv = torch.empty_like(qkv)
+        N = qkv.shape[0]
+        cs_, sn_, sc_ = ctx.tabs_r
+        check(lib.oniris_qkv_norm_hd_bwd(_p(qkv), _p(dq), _p(dk), _p(dv), _p(dqkv), _p(cs_), _p(sn_), _p(sc_), N * P, heads, d, P,
+                                         T if kind == "video" else 1, 0, rope, T if kind == "video" else 1, _stream()),
+              "qkv_norm_hd_bwd")
+        return dqkv, None, None, None, None, None, None
+
+
 def attention_train(qkv, kind, B, T, heads, rope_bufs=None):
-    return _AttentionFn.apply(qkv, kind, B, T, heads, rope_bufs, torch.is_grad_enabled())
+    fn = _AttentionFn if _head_dim(qkv.shape[-1] // 3, heads) == 64 else _AttentionHdFn
+    return fn.apply(qkv, kind, B, T, heads, rope_bufs, torch.is_grad_enabled())
 
 
 class KVRing:
@@ -1559,11 +1638,54 @@ def frame_attention_eval(x, pw, heads):
 
 
 @torch.no_grad()
+def _attention_eval_hd(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
+    """attention_eval for heads of 8 / 16 / 32 channels (zero-padded into the 64-channel kernels, csrc/attention_hd.hip).  The
+    cache is the reference's: normalised, UN-rotated k and v of all frames so far -- here (B, frames*P, heads*64) padded --
+    and every call re-rotates all keys for the grown key count (RoPe.py:55-57); no KV ring on this path."""
+    N, _, C3 = qkv.shape
+    d = _head_dim(C3 // 3, heads)
+    dev = qkv.device
+    t = N // B
+    Cp = heads * 64
+    n = 0 if kv_cache is None else kv_cache[0].shape[1] // P
+    nk = n + t
+    cs_, sn_, sc_ = rope_tables(rope_bufs[0], rope_bufs[1], nk, dev)
+    q = torch.empty((N, P, Cp), dtype=BF16, device=dev)
+    knew, vnew = torch.empty_like(q), torch.empty_like(q)
+    # q: normalised, scaled and rotated at positions n .. nk-1; k, v of the new frames: normalised only
+    check(lib.oniris_qkv_norm_hd(_p(qkv.contiguous()), _p(q), _p(knew), _p(vnew), _p(cs_), _p(sn_), _p(sc_), N * P, heads, d, P, nk, n,
+                                 1, t, _stream()), "qkv_norm_hd")
+    knew, vnew = knew.view(B, t * P, Cp), vnew.view(B, t * P, Cp)
+    if kv_cache is not None:
+        K = torch.cat([kv_cache[0][:, :n * P], knew], dim=1)
+        V = torch.cat([kv_cache[1][:, :n * P], vnew], dim=1)
+    else:
+        K, V = knew, vnew
+    K, V = K.contiguous(), V.contiguous()
+    new_cache = (K, V) if update_cache else kv_cache
+    kr = torch.empty_like(K)
+    check(lib.oniris_rope_hd(_p(K), _p(kr), _p(cs_), _p(sn_), _p(sc_), B * nk * P, heads, d, P, nk, 0, 2, nk, _stream()), "rope_hd")
+    Lq, Lk = t * P, nk * P
+    out = torch.empty((N, P, Cp), dtype=BF16, device=dev)
+    if t == 1:
+        mask_mode, tabs = 0, None                               # one new frame: dense SDPA over all keys (:69-70)
+    elif Lq == Lk:
+        mask_mode, tabs = 1, device_tables("infer", t, P, dev)  # causal prefill (:72-75)
+    else:
+        raise NotImplementedError("The inference mask is not implemented for this case")
+    a = _attn_args(q, kr, V, None, None, None, out, None, tabs, B, heads, Lq, Lk, Cp, mask_mode, P, 0)
+    if t == 1:
+        _decode_splits(a, B, heads, Lq, Lk, dev)
+    check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd")
+    return _unpad_heads(out, heads, d), new_cache
+
+
+@torch.no_grad()
 def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     """Eval-mode VideoAttention core (attention_modules.py:51-77): qkv (B*t, P, 3C) of the NEW frames.
     kv_cache: (K, V) normalised, un-rotated, (B, t_cached*P, C) or None.  Returns out (B*t,P,C), new cache."""
-    if qkv.shape[-1] != 3 * 64 * heads:
-        raise NotImplementedError(f"attention kernels: head dimension 64 only (got {qkv.shape[-1] // 3} channels / {heads} heads)")
+    if _head_dim(qkv.shape[-1] // 3, heads) != 64:
+        return _attention_eval_hd(qkv, B, heads, rope_bufs, kv_cache, update_cache, P)
     N, P_, C3 = qkv.shape
     C = C3 // 3
     dev = qkv.device

@@ -348,6 +348,24 @@ int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t, const flo
                 int mode, int B, int frames, int P, int C, int pos_offset, int pos_mod,
                 int64_t x_batch_stride /* elements between the sequences of x (KV ring); 0 = frames*P*C */,
                 int64_t xr_batch_stride /* the same for xr */, oniris_stream_t stream);
+/* Heads of 8, 16 or 32 channels (Block(channels_per_head=...), networks_edm2.py:28,39; the reference's own tests use 16,
+ * consistency_test.py:39,61).  The attention entry points below are written for 64-channel heads; other sizes run through
+ * them PADDED: q, k, v [tokens][heads*64] with channels head_dim..63 of every head zero (q.k and P.V are unchanged by
+ * zeros), the softmax scale log2(e)/sqrt(head_dim) on q.  These three do what depends on head_dim: the per-head pixel
+ * norm (attention_modules.py:48-49), the rotary embedding with its partner head_dim/2 channels away (RoPe.py:34-57; tables
+ * [pos][head_dim] fp32, position of a token = ((token / P) % seq_frames + pos_off) % pos_mod with seq_frames = frames per
+ * sequence of the tensor; rope bit 0: rotate q, bit 1: rotate k) and the
+ * adjoint (dq as the attention backward returns it for the 64-channel model, dk, dv padded -> dqkv).
+ * qkv / dqkv [tokens][3*heads*head_dim], channel = (s*heads + head)*head_dim + c.  oniris_rope_hd: mode 1 = q (* scale),
+ * 2 = k (/ scale) on a padded tensor (eval: all cached keys are re-rotated per call, RoPe.py:55-57).               */
+int oniris_qkv_norm_hd(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,
+                       const float* scale_t, int64_t n_tokens, int heads, int head_dim, int P, int pos_mod, int pos_off,
+                       int rope, int seq_frames, oniris_stream_t stream);
+int oniris_qkv_norm_hd_bwd(const void* qkv, const void* dq, const void* dk, const void* dv, void* dqkv, const float* cos_t,
+                           const float* sin_t, const float* scale_t, int64_t n_tokens, int heads, int head_dim, int P,
+                           int pos_mod, int pos_off, int rope, int seq_frames, oniris_stream_t stream);
+int oniris_rope_hd(const void* x, void* out, const float* cos_t, const float* sin_t, const float* scale_t, int64_t n_tokens,
+                   int heads, int head_dim, int P, int pos_mod, int pos_off, int mode, int seq_frames, oniris_stream_t stream);
 /* One new frame per sequence in the KV-cached sampler (edm2/sampler.py:12-85; attention_modules.py:51-70): oniris_qkv_norm
  * + the rotation of the frame's q and k at table row `pos` (= number of keys - 1) in one pass.  k (un-rotated) and v go
  * into the KV ring as in oniris_qkv_norm; kr receives the ROTATED k at the same ring position: the ring's rotated image,

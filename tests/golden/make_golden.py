@@ -251,6 +251,60 @@ def g6():
     save("g6_attention", **out)
 
 
+# ------------------------------------------------------------------ G6b attention modules with 16- / 32-channel heads
+def g6b():
+    """VideoAttention / FrameAttention with heads of 16 and 32 channels (Block(channels_per_head=...), networks_edm2.py:28;
+    the reference's own tests use 16: consistency_test.py:39,61): training forward + backward, just_2d, and -- for the
+    16-channel case -- causal prefill and two cached one-frame steps."""
+    out = {}
+    g = torch.Generator().manual_seed(66)
+
+    def params(C, d, video=True):
+        p = {"attn_qkv.weight.weight": torch.randn(3 * C, C, 1, 1, generator=g),
+             "attn_proj.weight.weight": torch.randn(C, C, 1, 1, generator=g)}
+        p = {k: paramgen.O.normalize(paramgen.O.normalize(v)) for k, v in p.items()}
+        if video:
+            p["rope.inv_freq"] = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+            p["rope.scale"] = (torch.arange(0, d, 2) + 0.4 * d) / (1.4 * d)
+        return p
+    for tag, T, H, C, m, B in [("h16", 4, 8, 64, 4, 2), ("h32", 2, 8, 64, 2, 1)]:
+        att = VideoAttention(C, m)
+        p = params(C, C // m)
+        att.load_state_dict(p, strict=True)
+        out.update({f"{tag}_p_{k}": v for k, v in p.items()})
+        x = torch.randn(B * 2 * T, C, H, H, generator=g, requires_grad=True)
+        att.train()
+        y, _ = att(x, B)
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        out.update({f"{tag}_x": x, f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_gx": x.grad,
+                    f"{tag}_g_qkv": att.attn_qkv.weight.weight.grad, f"{tag}_g_proj": att.attn_proj.weight.weight.grad})
+        y2d, _ = att(x.detach(), B, just_2d=True)
+        out[f"{tag}_y_just2d"] = y2d
+        if tag == "h16":
+            att.eval()
+            t_all = 6
+            xe = torch.randn(B * t_all, C, H, H, generator=g)
+            xs = xe.reshape(B, t_all, C, H, H)
+            with torch.no_grad():
+                ye, _ = att(xe, B)
+                y4, cache = att(xs[:, :4].reshape(-1, C, H, H), B, None, update_cache=True)
+                y5, cache = att(xs[:, 4:5].reshape(-1, C, H, H), B, cache, update_cache=True)
+                y6, _ = att(xs[:, 5:6].reshape(-1, C, H, H), B, cache, update_cache=False)
+            out.update(h16_eval_x=xe, h16_eval_y=ye, h16_eval_y4=y4, h16_eval_y5=y5, h16_eval_y6=y6)
+    fa = FrameAttention(32, 2)
+    p = params(32, 16, video=False)
+    fa.load_state_dict(p, strict=True)
+    x = torch.randn(6, 32, 8, 8, generator=g, requires_grad=True)
+    fa.train()
+    y, _ = fa(x)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out.update({"f_p_" + k: v for k, v in p.items()})
+    out.update(f_x=x, f_y=y, f_gy=gy, f_gx=x.grad, f_g_qkv=fa.attn_qkv.weight.weight.grad)
+    save("g6b_attention_heads", **out)
+
+
 # ------------------------------------------------------------------ G7 blocks
 def g7():
     out = {}
@@ -523,6 +577,6 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g7", "g8", "g9", "g9b", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g6b", "g7", "g8", "g9", "g9b", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

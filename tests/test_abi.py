@@ -99,17 +99,20 @@ def test_attn_schedule_is_a_balanced_partition():
                                          tab.ctypes.data_as(ctypes.c_void_p), 1) < 0
 
 
-def test_attention_modules_refuse_other_head_dimensions():
-    """The reference's unit tests build 4 heads of 16 channels (consistency_test.py:39,61); the kernels serve head
-    dimension 64 (every shipped configuration, networks_edm2.py:28,39) and must say so instead of computing garbage."""
+def test_attention_modules_head_dimensions():
+    """64-channel heads (every shipped configuration, networks_edm2.py:28,39) and -- through the padded path -- 8 / 16 / 32
+    (the reference's unit tests build 4 heads of 16 channels, consistency_test.py:39,61); anything else must be refused
+    instead of computing garbage."""
     import pytest
     import autoregressive_diffusion_amd  # noqa: F401
     from edm2.attention import VideoAttention, FrameAttention
     for cls in (VideoAttention, FrameAttention):
-        with pytest.raises(NotImplementedError):
-            cls(channels=64, num_heads=4)
+        cls(channels=64, num_heads=4)          # 16-channel heads
         cls(channels=128, num_heads=2)
         cls(channels=64, num_heads=0)
+        for channels, heads in ((96, 2), (64, 3), (256, 2)):      # 48, not a divisor, 128
+            with pytest.raises(NotImplementedError):
+                cls(channels=channels, num_heads=heads)
 
 
 def test_attention_flop_count_is_the_unmasked_pair_count():

@@ -3,7 +3,8 @@ for the HIP modules behind the same `edm2.*` API.  Same constants where the ship
 tokens per frame, 8 frames, cut at frame 3); what differs and why:
 
   * head dimension: the reference's test modules use 4 heads of 16 channels; every BASELINE configuration has
-    channels_per_head = 64 (networks_edm2.py:28,39) and so do the kernels -- the attention modules here are 4 x 64;
+    channels_per_head = 64 (networks_edm2.py:28,39).  Every attention test here runs at both: 4 x 16 (the reference's own
+    constants, through the zero-padded-head path) and 4 x 64 (the shipped kernels' native width);
   * the UNet of the reference's test (resolution 16 -> a 2x2 bottom level) is run at resolution 32 (4x4 bottom level, the
     smallest image the conv kernels tile);
   * tolerance: bf16 operands.  Where both sides run the SAME arithmetic (cached vs non-cached: per-token results do not
@@ -28,11 +29,14 @@ def _bt(x, b):
     return x.reshape(b, -1, *x.shape[1:])
 
 
-@pytest.fixture(scope="module")
-def video_attention():
+HEAD_CHANNELS = (16, 64)          # consistency_test.py:39,61 (4 * IMG_CHANNELS over 4 heads); networks_edm2.py:28
+
+
+@pytest.fixture(scope="module", params=HEAD_CHANNELS, ids=lambda c: f"head{c}")
+def video_attention(request):
     from edm2.attention import VideoAttention
     torch.manual_seed(SEED)
-    return VideoAttention(channels=4 * 64, num_heads=4).to(DEV)
+    return VideoAttention(channels=4 * request.param, num_heads=4).to(DEV)
 
 
 def _qkv_split(att, x, b):
@@ -44,13 +48,14 @@ def _qkv_split(att, x, b):
     return normalize(y, dim=-1).unbind(0)
 
 
-def test_frame_attention_matches_manual_softmax():
+@pytest.mark.parametrize("hc", HEAD_CHANNELS)
+def test_frame_attention_matches_manual_softmax(hc):
     """consistency_test.py:41-55"""
     from edm2.attention import FrameAttention
     from edm2.utils import mp_sum
     torch.manual_seed(SEED)
-    att = FrameAttention(channels=4 * 64, num_heads=4).to(DEV)
-    x = torch.randn(B * 2 * T_, 4 * 64, RES, RES, device=DEV)
+    att = FrameAttention(channels=4 * hc, num_heads=4).to(DEV)
+    x = torch.randn(B * 2 * T_, 4 * hc, RES, RES, device=DEV)
     with torch.no_grad():
         y_frame, _ = att(x.clone())
         q, k, v = _qkv_split(att, x, x.shape[0])                       # every image its own "sequence" of one frame
@@ -65,7 +70,7 @@ def test_video_vs_frame_attention_first_frame(video_attention):
     """consistency_test.py:63-74: with just_2d every frame attends to itself only -- so does frame 0 of each sequence under
     the training mask; later frames must differ."""
     att = video_attention.train()
-    x = torch.randn(B * 2 * T_, 4 * 64, RES, RES, device=DEV)
+    x = torch.randn(B * 2 * T_, att.channels, RES, RES, device=DEV)
     with torch.no_grad():
         yv, _ = att(x.clone(), B, just_2d=False)
         yf, _ = att(x.clone(), B, just_2d=True)
@@ -80,15 +85,16 @@ def test_video_attention_matches_masked_sdpa(video_attention):
     from oracle import oniris_oracle as O
     from edm2.utils import mp_sum
     att = video_attention.train()
-    x = torch.randn(B * 2 * T_, 4 * 64, RES, RES, device=DEV)
+    x = torch.randn(B * 2 * T_, att.channels, RES, RES, device=DEV)
     with torch.no_grad():
         yv, _ = att(x.clone(), B, just_2d=False)
         q, k, v = _qkv_split(att, x, B)                                # b m 2T hw c
         q, k = O.rope_apply(q.cpu(), k.cpu(), att.rope.inv_freq.float().cpu(), att.rope.scale.float().cpu(), True)
-        q, k, v = (z.reshape(B, att.num_heads, -1, 64).to(DEV) for z in (q, k, v.cpu()))
+        hc = att.channels // att.num_heads
+        q, k, v = (z.reshape(B, att.num_heads, -1, hc).to(DEV) for z in (q, k, v.cpu()))
         allowed = torch.from_numpy(O.train_allowed_tokens(T_, RES * RES)).to(DEV)
         y = torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
-        y = y.reshape(B, att.num_heads, 2 * T_, RES, RES, 64).permute(0, 2, 1, 5, 3, 4).reshape(x.shape)
+        y = y.reshape(B, att.num_heads, 2 * T_, RES, RES, hc).permute(0, 2, 1, 5, 3, 4).reshape(x.shape)
         y = mp_sum(x, att.attn_proj(y), t=att.attn_balance)
     assert _std(y, yv) <= 1e-2 * y.std().item()
 
@@ -97,7 +103,7 @@ def test_video_attention_train_vs_eval(video_attention):
     """consistency_test.py:108-125: clean frames 0..CUT-1 and the noised frame CUT of a training pass equal an eval pass
     over [clean 0..CUT-1, noised CUT]."""
     att = video_attention
-    x = torch.randn(B * 2 * T_, 4 * 64, RES, RES, device=DEV)
+    x = torch.randn(B * 2 * T_, att.channels, RES, RES, device=DEV)
     with torch.no_grad():
         y_train, _ = att.train()(x, B)
         xs = _bt(x, B)
@@ -112,7 +118,7 @@ def test_video_attention_train_vs_eval(video_attention):
 def test_video_attention_cached_vs_non_cached(video_attention):
     """consistency_test.py:129-146"""
     att = video_attention.eval()
-    x = torch.randn(B, T_, 4 * 64, RES, RES, device=DEV)
+    x = torch.randn(B, T_, att.channels, RES, RES, device=DEV)
     flat = lambda z: z.reshape(-1, *z.shape[2:])
     with torch.no_grad():
         y_full, _ = att(flat(x), B)
@@ -129,7 +135,7 @@ def test_video_attention_cached_vs_non_cached_multistep(video_attention):
     """consistency_test.py:148-172"""
     att = video_attention.eval()
     b = 1
-    x = torch.randn(b, T_, 4 * 64, RES, RES, device=DEV)
+    x = torch.randn(b, T_, att.channels, RES, RES, device=DEV)
     flat = lambda z: z.reshape(-1, *z.shape[2:])
     with torch.no_grad():
         y_full, _ = att(flat(x), b)

@@ -105,6 +105,47 @@ def test_g6_attention_modules():
     assert e[0] < 1e-2 and e[1] < 2e-2 and e[2] < 3e-2
 
 
+def test_g6b_attention_small_heads():
+    """Heads of 16 / 32 channels (the reference's own tests build 4 heads of 16, consistency_test.py:39,61) through the padded
+    path (ops._AttentionHdFn / _attention_eval_hd, csrc/attention_hd.hip) against fixture G6b from the reference: training
+    forward + backward, just_2d, causal prefill and cached one-frame steps."""
+    from edm2.attention import VideoAttention, FrameAttention
+    z = load("g6b_attention_heads")
+    for tag, C, m, B in [("h16", 64, 4, 2), ("h32", 64, 2, 1)]:
+        att = load_params(VideoAttention(C, m), {k[len(tag) + 3:]: T(z[k]) for k in z.files if k.startswith(tag + "_p_")})
+        att.train()
+        x = T(z[tag + "_x"]).to(DEV).requires_grad_(True)
+        y, _ = att(x, B)
+        y.backward(T(z[tag + "_gy"]).to(DEV))
+        e = dict(y=rel(y, z[tag + "_y"]), gx=rel(x.grad, z[tag + "_gx"]),
+                 g_qkv=rel(att.attn_qkv.weight.weight.grad, z[tag + "_g_qkv"]),
+                 g_proj=rel(att.attn_proj.weight.weight.grad, z[tag + "_g_proj"]))
+        print("g6b", tag, e)
+        assert e["y"] < 1e-2 and e["gx"] < 2e-2 and e["g_qkv"] < 3e-2 and e["g_proj"] < 3e-2
+        y2, _ = att(x.detach(), B, just_2d=True)
+        assert rel(y2, z[tag + "_y_just2d"]) < 1e-2
+        if tag == "h16":
+            att.eval()
+            with torch.no_grad():
+                xe = T(z["h16_eval_x"]).to(DEV)
+                ye, _ = att(xe, B)
+                xs = xe.reshape(B, 6, *xe.shape[1:])
+                y4, c = att(xs[:, :4].reshape(-1, *xe.shape[1:]), B, None, update_cache=True)
+                y5, c = att(xs[:, 4:5].reshape(-1, *xe.shape[1:]), B, c, update_cache=True)
+                y6, _ = att(xs[:, 5:6].reshape(-1, *xe.shape[1:]), B, c, update_cache=False)
+            e = (rel(ye, z["h16_eval_y"]), rel(y4, z["h16_eval_y4"]), rel(y5, z["h16_eval_y5"]), rel(y6, z["h16_eval_y6"]))
+            print("g6b eval", e)
+            assert max(e) < 1e-2
+    fa = load_params(FrameAttention(32, 2), {k[4:]: T(z[k]) for k in z.files if k.startswith("f_p_")})
+    fa.train()
+    x = T(z["f_x"]).to(DEV).requires_grad_(True)
+    y, _ = fa(x)
+    y.backward(T(z["f_gy"]).to(DEV))
+    e = (rel(y, z["f_y"]), rel(x.grad, z["f_gx"]), rel(fa.attn_qkv.weight.weight.grad, z["f_g_qkv"]))
+    print("g6b frame", e)
+    assert e[0] < 1e-2 and e[1] < 2e-2 and e[2] < 3e-2
+
+
 WEIGHT_GN_TOL = dict(enc=5e-2, dec=5e-2)      # (tightened to 2x the measured floor below)
 
 

@@ -289,3 +289,34 @@ def test_g9b_sampler_branches():
             np.testing.assert_allclose(res[3], z[tag + "_mse_pred"], rtol=2e-3)
         else:
             assert len(z[tag + "_mse"]) == 0
+
+
+def test_g6b_attention_small_heads():
+    """Heads of 16 / 32 channels (fixture from the reference): the oracle is generic in the head dimension."""
+    z = load("g6b_attention_heads")
+    for tag, m, B in [("h16", 4, 2), ("h32", 2, 1)]:
+        p = {"a." + k[len(tag) + 3:]: T(z[k]).requires_grad_(k.endswith("weight")) for k in z.files if k.startswith(tag + "_p_")}
+        x = T(z[tag + "_x"]).requires_grad_(True)
+        y, _ = O.video_attention(p, "a.", x, B, m, None, False, False, True)
+        close(y, z[tag + "_y"], rtol=5e-5, what=tag + " y")
+        (y * T(z[tag + "_gy"])).sum().backward()
+        close(x.grad, z[tag + "_gx"], rtol=1e-4, what=tag + " gx")
+        close(p["a.attn_qkv.weight.weight"].grad, z[tag + "_g_qkv"], rtol=2e-4, what=tag + " g_qkv")
+        y2, _ = O.video_attention(p, "a.", x.detach(), B, m, None, False, True, True)
+        close(y2, z[tag + "_y_just2d"], rtol=5e-5)
+    p = {"a." + k[6:]: T(z[k]) for k in z.files if k.startswith("h16_p_")}
+    with torch.no_grad():
+        xe = T(z["h16_eval_x"]); B = 2
+        ye, _ = O.video_attention(p, "a.", xe, B, 4, None, False, False, False)
+        close(ye, z["h16_eval_y"], rtol=5e-5, what="prefill")
+        xs = xe.reshape(B, 6, *xe.shape[1:])
+        y4, c = O.video_attention(p, "a.", xs[:, :4].reshape(-1, *xe.shape[1:]), B, 4, None, True, False, False)
+        y5, c = O.video_attention(p, "a.", xs[:, 4:5].reshape(-1, *xe.shape[1:]), B, 4, c, True, False, False)
+        y6, _ = O.video_attention(p, "a.", xs[:, 5:6].reshape(-1, *xe.shape[1:]), B, 4, c, False, False, False)
+        close(y4, z["h16_eval_y4"], rtol=5e-5); close(y5, z["h16_eval_y5"], rtol=5e-5); close(y6, z["h16_eval_y6"], rtol=5e-5)
+    p = {"f." + k[4:]: T(z[k]).requires_grad_(True) for k in z.files if k.startswith("f_p_")}
+    x = T(z["f_x"]).requires_grad_(True)
+    y = O.frame_attention(p, "f.", x, 2, True)
+    close(y, z["f_y"], rtol=5e-5)
+    (y * T(z["f_gy"])).sum().backward()
+    close(x.grad, z["f_gx"], rtol=1e-4); close(p["f.attn_qkv.weight.weight"].grad, z["f_g_qkv"], rtol=2e-4)
