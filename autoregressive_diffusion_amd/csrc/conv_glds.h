@@ -25,13 +25,16 @@
 #include "lds_dma.h"
 
 // Diagnostic build only (make stamp: -DCONV_STAMP): per-phase cycle sums of every wave of workgroup 0, written to the
-// buffer passed in OnirisConvArgs.splitk_ws (unused by this kernel): [wave][8] uint64.
+// buffer passed in OnirisConvArgs.splitk_ws (unused by this kernel): [wave][12] uint64 (slots 7 .. 10: the context phases' share of
+// slots 2 .. 5).
 #ifdef CONV_STAMP
-#define CSTAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define CSTAMP_DECL unsigned long long st_t = __builtin_amdgcn_s_memtime(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #define CSTAMP(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); st_acc[i] += n_ - st_t; st_t = n_; }
+#define CSTAMP2(c, i, j) { if (c) CSTAMP(i) else CSTAMP(j) }      // (static indices: st_acc stays in registers)
 #else
 #define CSTAMP_DECL
 #define CSTAMP(i)
+#define CSTAMP2(c, i, j)
 #endif
 
 // NT: 32-channel tiles per wave; WC: channel groups of waves (a workgroup covers 32*NT*WC channels and
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
     ld(0, 0);
 #pragma unroll
     for (int st = 0; st < NSTEP; ++st) {
-      if (st == MID_STEP) mid();
+      mid(st);
       if (st + 1 < NSTEP) ld((st + 1) & 1, st + 1);
 #pragma unroll
       for (int m = 0; m < MT; ++m)
@@ -275,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
       __builtin_amdgcn_sched_group_barrier(0x008, NX * MT * NT, 0);
     }
   };
-  auto no_mid = []() __attribute__((always_inline)) {};
+  auto no_mid = [](int) __attribute__((always_inline)) {};
 
   constexpr int EROW = Cfg::EROW;
   constexpr int ESC = 2 * FT * BN * 4;                  // emb-scale vectors [slot][frame][BN], in front of the staging tiles
@@ -325,22 +328,23 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
         // pipe of every SIMD sat idle for the ~1000 cycles its two waves spent on their ~10 pieces each (stamped: 30 %
         // of the kernel).  Now one wave of a SIMD feeds the matrix pipe while the other one issues.
         const bool have_next = itp + 1 < nphase;
+        // (Which half goes first, and `s_setprio` on either half for part or all of a phase, measured nothing: round 4.)
         const bool early = __builtin_amdgcn_readfirstlane(wave) < NW / 2 || (a.big_tile & 32);      // (bit 5: A/B knob, all waves issue at the phase top)
         if (have_next && early) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);
-        auto mid = [&]() __attribute__((always_inline)) {
-          if (have_next && !early) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);
+        auto mid = [&](int st) __attribute__((always_inline)) {
+          if (st == MID_STEP && have_next && !early) issue(cur, (itp + 1) / NPH, (itp + 1) % NPH, bsel ^ 1);
         };
-        CSTAMP(2)
+        CSTAMP2(ph == 0, 2, 7)
         if (!CTX || ph == 0) mfma_steps(std::true_type{}, bsel * BUF, AROWS * 64, mid);
         else mfma_steps(std::false_type{}, bsel * BUF, AROWS * 64, mid);
 #ifdef CONV_STAMP
         asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[1][0][0]), "v"(accc[0][0]), "v"(acc[0][0][NT - 1]), "v"(acc[1][0][NT - 1]), "v"(accc[0][NT - 1]));
 #endif
-        CSTAMP(3)
+        CSTAMP2(ph == 0, 3, 8)
         dma_wait();                        // this wave's share of the next phase has landed ...
-        CSTAMP(4)
+        CSTAMP2(ph == 0, 4, 9)
         __syncthreads();                   // ... everybody's has; and everybody is done reading buffer bsel
-        CSTAMP(5)
+        CSTAMP2(ph == 0, 5, 10)
         bsel ^= 1;
       }
     }
@@ -497,8 +501,8 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
   }
 #ifdef CONV_STAMP
   if (blockIdx.x == 0 && lane == 0 && a.splitk_ws) {
-    unsigned long long* dst = (unsigned long long*)a.splitk_ws + wave * 8;
-    for (int i = 0; i < 8; ++i) dst[i] = st_acc[i];
+    unsigned long long* dst = (unsigned long long*)a.splitk_ws + wave * 12;
+    for (int i = 0; i < 12; ++i) dst[i] = st_acc[i];
   }
 #endif
 #endif

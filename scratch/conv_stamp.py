@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from autoregressive_diffusion_amd import ops, _lib
 from autoregressive_diffusion_amd._lib import lib, check
-names = ["tile-top wait", "prologue", "dma issue", "mfma", "dma wait", "barrier", "epilogue", "-"]
+names = ["tile-top wait", "prologue", "own: dma issue", "mfma", "dma wait", "barrier", "epilogue", "ctx: dma issue", "mfma", "dma wait", "barrier", "-"]
 def run(B, T, H, C, Cout, dgrad=False):
     dev = "cuda"
     torch.manual_seed(0)
@@ -15,7 +15,7 @@ def run(B, T, H, C, Cout, dgrad=False):
     c3 = torch.randn(B * T, H, H, C, device=dev).to(torch.bfloat16)
     ca = torch.rand(N, device=dev) + 0.5; cb = torch.rand(N, device=dev) * 0.3
     out = torch.zeros(N, H, H, Cout, device=dev, dtype=torch.bfloat16); y3 = torch.zeros(B * T, H, H, Cout, device=dev, dtype=torch.bfloat16)
-    stamps = torch.zeros(64, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(96, dtype=torch.int64, device=dev)
     a = _lib.ConvArgs()
     a.x, a.ctx, a.w_own, a.w_ctx, a.out = x.data_ptr(), (c3 if dgrad else x).data_ptr(), pw2.wf.data_ptr(), pw3.wf.data_ptr(), out.data_ptr()
     a.coef_own, a.coef_ctx = ca.data_ptr(), cb.data_ptr()
@@ -37,7 +37,7 @@ def run(B, T, H, C, Cout, dgrad=False):
     us = e0.elapsed_time(e1) * 100
     fl = 2.0 * N * H * H * Cout * C * 9 * 2
     print(f"{'dgrad' if dgrad else 'fwd'} B={B} T={T} H={H} {C}->{Cout}: {us:.1f} us (stamped build) {fl / us / 1e6:.0f} TFLOP/s")
-    s = stamps.view(8, 8).cpu()
+    s = stamps.view(8, 12).cpu()
     for w in (0, 3, 4, 7):
         tot = int(s[w].sum())
         print(f"  wave {w}: total {tot:7d} | " + " ".join(f"{n} {int(c)}" for n, c in zip(names, s[w]) if n != "-"))
