@@ -98,7 +98,7 @@ def test_weight_perm3():
 
 
 @pytest.mark.parametrize("N,H,cin,cout,k", [(6, 16, 32, 64, 3), (5, 8, 96, 32, 3), (16, 4, 64, 64, 3), (3, 32, 16, 40, 3),
-                                            (7, 8, 64, 192, 1), (3, 16, 48, 32, 1), (130, 1, 64, 96, 1),
+                                            (7, 8, 64, 192, 1), (3, 16, 48, 32, 1), (130, 1, 64, 96, 1), (6, 32, 32, 96, 1),
                                             # 1x1 with >= 8192 positions and Cin % 64 == 0: the LDS-DMA GEMM (conv1x1_glds.h);
                                             # ragged last position tile, Cout not a multiple of the 128-channel tile
                                             (15, 24, 64, 192, 1), (9, 32, 128, 136, 1), (8, 32, 192, 64, 1), (2, 64, 256, 768, 1),
