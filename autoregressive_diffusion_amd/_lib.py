@@ -38,7 +38,8 @@ class ConvArgs(C.Structure):
                 ("res", c_void_p), ("escale", c_void_p), ("emb_gain", c_void_p), ("out2", c_void_p),
                 ("ta", c_float), ("tb", c_float), ("clip", c_float), ("ctx_out", c_void_p),
                 ("big_tile", c_int32), ("escale_pitch", c_int32),
-                ("splitk_ws", c_void_p), ("splitk_ws_bytes", C.c_size_t), ("clip_flag", c_void_p)]
+                ("splitk_ws", c_void_p), ("splitk_ws_bytes", C.c_size_t), ("clip_flag", c_void_p),
+                ("ctx_prod", c_void_p), ("ctx_prod_mode", c_int32)]
 
 
 class WgradArgs(C.Structure):

@@ -3,8 +3,12 @@
 
 extern "C" int oniris_conv_fwd(const OnirisConvArgs* args, oniris_stream_t stream_) {
   hipStream_t st = (hipStream_t)stream_;
-  ONIRIS_CHECK_ARG(args && args->x && args->w_own && args->out, "conv_fwd: null pointer");
+  ONIRIS_CHECK_ARG(args && args->w_own && ((args->x && args->out) || args->ctx_prod_mode == 3), "conv_fwd: null pointer");
   const OnirisConvArgs& a = *args;
+  if (a.ctx_prod_mode != 0 && !(a.S == 1 && a.ctx && a.taps == 9 && a.ctx_prod)) {
+    oniris_set_error("conv_fwd: ctx_prod_mode %d is for the one-frame cached evaluation (S == 1, context path, ctx_prod given)", a.ctx_prod_mode);
+    return ONIRIS_EUNSUPPORTED;
+  }
   ONIRIS_CHECK_ARG(a.taps == 9 || a.taps == 1, "conv_fwd: taps must be 1 or 9 (got %d)", a.taps);
   ONIRIS_CHECK_ARG(a.B > 0 && a.T > 0 && a.H > 0 && a.W > 0 && (a.S == 1 || a.S == 2), "conv_fwd: bad sizes");
   ONIRIS_CHECK_ARG(a.Cin % 8 == 0 && a.Cout % 8 == 0, "conv_fwd: Cin, Cout must be multiples of 8 (%d,%d)", a.Cin, a.Cout);

@@ -17,6 +17,11 @@
 //     gate combine, emb-scale + SiLU or mp_sum + clip, 8-byte coalesced bf16 stores.
 // LDS images as in conv_glds.h: 64-byte rows (32 channels), the four 16-byte parts XOR-swizzled with row bits 2..3 on the
 // source side, 12-entry halo rows (2 unused) so that the 16-lane groups of a ds_read_b128 take 16 consecutive rows.
+// Context product kept between evaluations (OnirisConvArgs.ctx_prod, ABI 11): the 31 evaluations of one generated frame
+// convolve the SAME cached pair with the same context weights -- only the gate coefficient in front of that product
+// changes.  Mode 3 computes the product once per frame (context phases only, fp32 store), mode 2 reads it back and walks the
+// own phases only: a third of the phases and of the weight stream per evaluation.  The stored value is the fp32 sum the
+// epilogue would have formed itself, so mode 2 is bit-identical to the all-phases launch.
 // Requirements (conv_eval1_ok): S == 1, T == 1, context = the cached pair (ctx_T == 2, coff = 0 / 1), taps == 9,
 // Cin % 32 == 0, H % 8 == 0, W % 8 == 0.  Same results as the split-K path up to fp32 summation order.
 #pragma once
@@ -49,7 +54,19 @@ __global__ __launch_bounds__(512, 2) void conv_eval1_kernel(const ConvDev d) {
   const int x0 = (bid % d.ntx) * 8; bid /= d.ntx;
   const int y0 = (bid % d.nty) * 8; bid /= d.nty;
   const int b = bid;
-  const int NP = (Cin / 32) * 3;
+  // phases per 32-channel chunk: own | cached frame 0 | cached frame 1, or (ctx_prod_mode 2) the own one only, or (3) the two
+  // context ones only
+  const int mode = a.ctx_prod_mode;
+  const int phs = (mode == 2) ? 1 : (mode == 3) ? 2 : 3, ph0 = (mode == 3) ? 1 : 0;
+  const int NP = (Cin / 32) * phs;
+  // (mode 2) this thread's four context sums, requested now: nothing else of this wave is in flight yet, and the loader waves'
+  // counted waits only ever leave YOUNGER requests outstanding
+  float4 y3v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (mode == 2) {
+    const int pos = tid >> 3, cq = (tid & 7) * 4;
+    if (co0 + cq < a.Cout)
+      y3v = *(const float4*)(a.ctx_prod + ((size_t)b * HWp + (size_t)(y0 + (pos >> 3)) * W + (x0 + (pos & 7))) * a.Cout + co0 + cq);
+  }
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
 
   if (wave >= 4) {
@@ -80,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv_eval1_kernel(const ConvDev d) {
     const i32x4 rs_c = make_rsrc((const bf16*)a.ctx + (size_t)b * a.ctx_bstride * HWp * Cin, 2 * frame_bytes);
     const i32x4 rs_wo = make_rsrc(a.w_own, wbytes), rs_wc = make_rsrc(a.w_ctx, 2 * wbytes);
     auto issue = [&](int p) __attribute__((always_inline)) {
-      const int ch = p / 3, ph = p - 3 * ch, c0 = ch * 32;
+      const int ch = p / phs, ph = ph0 + p - phs * ch, c0 = ch * 32;
       const unsigned dst = lds0 + (p & 3) * SLOTB + lw * 1024;
       if (ph == 0) {
 #pragma unroll
@@ -161,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_eval1_kernel(const ConvDev d) {
     for (int p = 0; p < NP; ++p) {
       if (p > 0) __syncthreads();                  // barrier_p
       const unsigned char* base = smem + (p & 3) * SLOTB;
-      if (p % 3 == 0) phase(std::true_type{}, base);
+      if (ph0 + p % phs == 0) phase(std::true_type{}, base);
       else phase(std::false_type{}, base);
     }
     // partial tiles -> LDS as [wave][own | ctx][position][co] fp32 (after E1: every wave is done with the ring)
@@ -195,8 +212,11 @@ __global__ __launch_bounds__(512, 2) void conv_eval1_kernel(const ConvDev d) {
     const int co = co0 + cq;
     if (co < a.Cout) {
       const int n = b;                             // frame-slot index (S == 1, T == 1)
-      const float cown = a.coef_own ? a.coef_own[n] : 1.f, cctx = a.coef_ctx ? a.coef_ctx[n] : 1.f;
       const size_t o = ((size_t)n * HWp + (size_t)(y0 + py) * W + (x0 + px)) * a.Cout + co;
+      if (mode == 2) { ctx[0] = y3v.x; ctx[1] = y3v.y; ctx[2] = y3v.z; ctx[3] = y3v.w; }
+      else if (mode != 0) *(float4*)(a.ctx_prod + o) = make_float4(ctx[0], ctx[1], ctx[2], ctx[3]);
+      if (mode == 3) return;
+      const float cown = a.coef_own ? a.coef_own[n] : 1.f, cctx = a.coef_ctx ? a.coef_ctx[n] : 1.f;
       float v[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) v[i] = __builtin_fmaf(cctx, ctx[i], cown * own[i]);
@@ -245,6 +265,7 @@ __global__ __launch_bounds__(512, 2) void conv_eval1_kernel(const ConvDev d) {
 static inline bool conv_eval1_ok(const OnirisConvArgs& a) {
   return a.S == 1 && a.T == 1 && a.ctx && a.w_ctx && a.taps == 9 && a.ctx_T == 2 && a.coff0 == 0 && a.coff1 == 1 &&
          a.Cin % 32 == 0 && a.Cin >= 32 && a.H % 8 == 0 && a.W % 8 == 0 && a.Cout % 8 == 0 &&
+         a.ctx_prod_mode >= 0 && a.ctx_prod_mode <= 3 && (a.ctx_prod_mode == 0 || a.ctx_prod != nullptr) &&
          2LL * a.H * a.W * a.Cin * 2 < (1LL << 31) && 18LL * a.CoutP * a.CinP * 2 < (1LL << 31) &&
          (a.escale_pitch == 0 || a.escale_pitch % 4 == 0);
 }

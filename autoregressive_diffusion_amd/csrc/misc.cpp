@@ -31,7 +31,7 @@ extern "C" int oniris_profile_disarm(void) {          // 1: the pair was still a
   oniris_prof_ev[0] = oniris_prof_ev[1] = nullptr;
   return armed;
 }
-extern "C" int oniris_abi_version(void) { return 10; }
+extern "C" int oniris_abi_version(void) { return 11; }
 
 // ---- mask tables (reference: edm2/attention/attention_masking.py:27-53, 64-90); 128 = flex default block
 static const int kFlexBlock = 128;

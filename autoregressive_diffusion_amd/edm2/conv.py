@@ -234,6 +234,7 @@ class MPCausal3DGatedConv(nn.Module):
             return ops.gated_conv_train(x, gate, pw2, pw3, batch_size, T, coefs, **epi), cache
         t = N // batch_size
         pad = cache.get("activations")
+        had_pair = pad is not None
         if pad is None:
             pad = torch.ones(batch_size, 2, H, W, C, dtype=BF16, device=x.device)
         if t == 1:              # one generated frame (the sampler's 31 evaluations): its context IS the cached pair
@@ -244,11 +245,37 @@ class MPCausal3DGatedConv(nn.Module):
                 cache["_pending_frame"] = x.reshape(batch_size, 1, H, W, C)
             elif update_cache:
                 cache["activations"] = torch.cat([pad[:, 1:], x.reshape(batch_size, 1, H, W, C)], dim=1)
+            # The context product of the cached pair is the same in every evaluation against that pair (the sampler runs 31
+            # per generated frame, sampler.py:50-76; the reference's F.conv3d recomputes it each time, conv.py:84-86): kept
+            # in the cache entry beside the pair it belongs to -- computed by UNet.prewarm_eval or by the first evaluation,
+            # read by all later ones, dropped (by identity of the pair) as soon as the cache moves on.
+            kept = cache.get("_ctx_product") if had_pair else None
+            if kept is not None and kept[1] is pad:
+                epi = dict(epi, ctx_prod=kept[0], ctx_prod_mode=2)
+            elif had_pair and pad.is_contiguous() and ops.ctx_product_ok(H, W, C, pw2.cout) and not torch.cuda.is_current_stream_capturing():
+                y3 = torch.empty((batch_size, H, W, ops.roundup(pw2.cout, 8)), dtype=torch.float32, device=x.device)
+                cache["_ctx_product"] = (y3, pad)
+                epi = dict(epi, ctx_prod=y3, ctx_prod_mode=1)
             return ops.gated_conv_eval(x, gate, pw2, pw3, batch_size, 1, pad.contiguous(), coefs, ctx_T=2, **epi), cache
         ctx = torch.cat([pad, x.reshape(batch_size, t, H, W, C)], dim=1).contiguous()
         if update_cache:
             cache["activations"] = ctx[:, -2:].clone()
         return ops.gated_conv_eval(x, gate, pw2, pw3, batch_size, t, ctx, coefs, **epi), cache
+
+    def keep_ctx_product(self, cache):
+        """Compute the context product of `cache`'s pair now (one context-phases-only launch), so that the evaluations that
+        follow -- captured into a hipGraph or not -- only walk their own phases.  No-op when it is already there."""
+        pad = cache.get("activations") if cache else None
+        if pad is None or not pad.is_contiguous() or pad.dtype != BF16:
+            return
+        kept = cache.get("_ctx_product")
+        if kept is not None and kept[1] is pad:
+            return
+        pw2, pw3 = self.last_frame_conv.weight.pw, self.weight.pw
+        B, _, H, W, C = pad.shape
+        if not ops.ctx_product_ok(H, W, C, pw2.cout):
+            return
+        cache["_ctx_product"] = (ops.gated_conv_ctx_product(pad, pw2, pw3, B), pad)
 
     def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
         with weights_ready(self):

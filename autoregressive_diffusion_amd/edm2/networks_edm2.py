@@ -317,6 +317,14 @@ class UNet(BetterModule):
             nctx_tensor(n_ctx, dev)
             _nctx_i32(n_ctx, dev)
         _packed_gate_params(convs, dev)
+        # context products of the cached pairs, once per frame (conv.MPCausal3DGatedConv.keep_ctx_product) -- only while the
+        # packed eval weights of the last evaluation are still the parameters' (otherwise the next evaluation computes them)
+        pw = convs[0].weight.pw if convs else None
+        bank = getattr(pw, "bank", None)
+        if not self.training and bank is not None and bank.packed_valid():
+            for conv, c in zip(convs, caches):
+                if c:
+                    conv.keep_ctx_product(c)
         eb, groups = self.__dict__.get("_oniris_emb_blocks"), self.__dict__.get("_oniris_groups")
         if eb is not None and groups:
             ops.eval_gain_vector(groups[0], eb[1])                 # (cached outside the capture, see there)

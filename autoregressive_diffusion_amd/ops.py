@@ -345,6 +345,11 @@ class WeightBank:
               "weight_prep")
         self._packed_sig = None if training else (_weights_epoch, tuple(w.param._version for w, _ in self.items))
 
+    def packed_valid(self):
+        """True while the packed EVAL weights of the last `prepare(False)` still match the parameters."""
+        sig = getattr(self, "_packed_sig", None)
+        return sig is not None and sig == (_weights_epoch, tuple(w.param._version for w, _ in self.items))
+
     def backward(self):
         """Packed fp32 weight gradients (from the wgrad kernels) -> parameter .grad (accumulated); one launch."""
         # re-validated on every call (~150 us of host time): between forward and backward the gradients may have been
@@ -474,7 +479,7 @@ CLIP_FLAG = int(_os.environ.get("ONIRIS_CLIP_FLAG", "1"))    # 0: the mp_sum bac
 
 def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP, Cout, CoutP, taps,
                  ctx_bstride=0, ctx_T=0, coff=(0, 0), ctx_fill=0.0, epi=0, res=None, escale=None, emb_gain=None,
-                 out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None, clip_flag=None):
+                 out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None, clip_flag=None, ctx_prod=None, ctx_prod_mode=0):
     if KernelProfile.enabled:
         flops = 2.0 * B * S * T * H * W * Cout * Cin * taps
         if ctx is not None:
@@ -502,7 +507,7 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         try:
             e0, e1 = _timed_launch(lambda: _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP,
                                                         Cout, CoutP, taps, ctx_bstride, ctx_T, coff, ctx_fill, epi, res, escale,
-                                                        emb_gain, out2, ta, tb, clip, ctx_out, clip_flag))
+                                                        emb_gain, out2, ta, tb, clip, ctx_out, clip_flag, ctx_prod, ctx_prod_mode))
         finally:
             KernelProfile.enabled = True
         # algorithmic HBM bytes of the launch (every operand read once, every result written once; the context
@@ -526,8 +531,9 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         a.escale_pitch = escale.stride(0)
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
     a.clip_flag = _p(clip_flag)
+    a.ctx_prod, a.ctx_prod_mode = _p(ctx_prod), ctx_prod_mode
     a.big_tile = BIG_TILE
-    if SPLITK and B * S * T * H * W <= 64 * 256:      # few tiles (one rollout frame): lend the split-K workspace
+    if SPLITK and B * S * T * H * W <= 64 * 256 and ctx_prod_mode == 0:      # few tiles (one rollout frame): lend the split-K workspace
         ws = _splitk_workspace(x.device)
         a.splitk_ws, a.splitk_ws_bytes = _p(ws), ws.numel() * 4
     check(lib.oniris_conv_fwd(ctypes.byref(a), _stream()), "conv_fwd")
@@ -808,11 +814,35 @@ def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0
     return _ConvOp.apply(x, pw2.param, pw3.param, ca, cb, cscale, res, cfg)
 
 
+KEEP_CTX_PRODUCT = int(_os.environ.get("ONIRIS_KEEP_CTX_PRODUCT", "1"))     # A/B knob: 0 = every evaluation recomputes y3
+
+
+def ctx_product_ok(H, W, Cin, Cout):
+    """True when the one-frame kernel (csrc/conv_eval1.h, conv_eval1_ok) serves this layer, i.e. when the context product
+    of a cached pair can be kept between the evaluations of a frame (OnirisConvArgs.ctx_prod)."""
+    return bool(KEEP_CTX_PRODUCT and BIG_TILE >= 3 and not (BIG_TILE & 16) and Cin % 32 == 0 and Cin >= 32 and H % 8 == 0
+                and W % 8 == 0 and Cout % 8 == 0 and 2 * H * W * Cin * 2 < (1 << 31))
+
+
+@torch.no_grad()
+def gated_conv_ctx_product(pair, pw2, pw3, B, out=None):
+    """y3 (B, H, W, Cout) fp32 = the un-gated context product of the cached pair (B, 2, H, W, C) with pw3 -- what every
+    one-frame evaluation against this pair adds, times its gate coefficient (OnirisConvArgs.ctx_prod_mode 3)."""
+    _, two, H, W, Cin = pair.shape
+    assert two == 2 and pair.is_contiguous() and pair.dtype == BF16
+    Co = roundup(pw2.cout, 8)
+    y3 = out if out is not None else torch.empty((B, H, W, Co), dtype=torch.float32, device=pair.device)
+    _conv_launch(None, pair, pw2.wf, pw3.wf, None, None, None, B, 1, 1, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
+                 ctx_bstride=2, ctx_T=2, coff=(0, 1), ctx_fill=0.0, ctx_prod=y3, ctx_prod_mode=3)
+    return y3
+
+
 @torch.no_grad()
 def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None,
-                    ctx_T=None):
+                    ctx_T=None, ctx_prod=None, ctx_prod_mode=0):
     """Eval-mode gated conv: x (B*t,H,W,C); ctx_frames (B, ctx_T, H, W, C) = [2 cached frames, x frames] (ctx_T = t+2),
-    or just the 2 cached frames when t == 1 (output frame 0 reads context frames 0 and 1 only)."""
+    or just the 2 cached frames when t == 1 (output frame 0 reads context frames 0 and 1 only).  ctx_prod (t == 1 only):
+    the kept context product of that pair, written (mode 1) or read instead of being recomputed (mode 2)."""
     ctx_T = t + 2 if ctx_T is None else ctx_T
     assert ctx_frames.shape[1] == ctx_T and (ctx_T == t + 2 or t == 1)
     N, H, W, Cin = x.shape
@@ -826,6 +856,9 @@ def gated_conv_eval(x, gate, pw2, pw3, B, t, ctx_frames, coefs=None, res=None, t
     elif cscale is not None:
         ret = torch.empty_like(out)
         kw = dict(epi=_lib.EPI_EMB_SILU, escale=_rows_f32(cscale), out2=ret)
+    if ctx_prod_mode:
+        assert t == 1 and ctx_prod.dtype == torch.float32 and tuple(ctx_prod.shape) == (B, H, W, Co) and ctx_prod.is_contiguous()
+        kw.update(ctx_prod=ctx_prod, ctx_prod_mode=ctx_prod_mode)
     _conv_launch(x, ctx_frames, pw2.wf, pw3.wf, out, ca, cb, B, 1, t, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9,
                  ctx_bstride=ctx_T, ctx_T=ctx_T, coff=(0, 1), ctx_fill=0.0, **kw)
     return ret

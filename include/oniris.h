@@ -231,6 +231,19 @@ typedef struct OnirisConvArgs {
    * practically never reach the clip, and then the gradient needs no mask -- no read of the clipped output, no masked copy
    * of the incoming gradient (oniris_gconv_bwd_fused, mode 2).                                                      */
   int32_t* clip_flag;
+  /* Optional (ABI 11; the one-frame cached evaluation only: S == 1, T == 1, ctx = the cached pair, csrc/conv_eval1.h): the
+   * un-gated context product  y3[n][p][co] = sum_j conv(ctxframe(b, coff[j]), w_ctx[j])  in fp32, [B][H][W][Cout].  The sampler
+   * evaluates the net 31 times per generated frame against the SAME cached pair (edm2/sampler.py:50-76 inside one frame of
+   * :36-85; the reference recomputes F.conv3d over the cached frames every time, edm2/conv.py:84-86): y3 does not change
+   * between those evaluations, only the gate coefficient that scales it does.
+   *   ctx_prod_mode 0: ctx_prod unused.
+   *                 1: all phases as usual, and y3 is ALSO stored to ctx_prod.
+   *                 2: y3 is READ from ctx_prod; the context phases (two thirds of the weight stream) are skipped.  Bit-identical
+   *                    to mode 0 / 1 on the same inputs (the fp32 sum is stored before the gate touches it).
+   *                 3: ONLY y3 is computed and stored; out / out2 / res / x are not touched (x and out may be NULL).
+   * A launch with ctx_prod_mode != 0 that the one-frame kernel cannot serve fails with ONIRIS_EUNSUPPORTED.        */
+  float* ctx_prod;
+  int32_t ctx_prod_mode;
 } OnirisConvArgs;
 
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);

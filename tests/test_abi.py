@@ -16,7 +16,7 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(_lib.EXPORTED), (declared ^ set(_lib.EXPORTED))
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.oniris_abi_version() == 10
+    assert _lib.lib.oniris_abi_version() == 11
 
 
 def test_mask_tables_against_golden():

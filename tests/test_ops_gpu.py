@@ -252,6 +252,58 @@ def test_gated_conv_eval_one_frame_splitk(B, H, cin, cout, epi, monkeypatch):
     assert d <= 2.0 ** -6 * max(1.0, float(outs[0].abs().max()))          # one bf16 ulp of the largest value
 
 
+@pytest.mark.parametrize("B,H,cin,cout,epi", [(1, 8, 256, 256, "silu"), (2, 16, 128, 128, "mpsum"), (3, 32, 64, 64, "none"),
+                                              (1, 8, 96, 160, "mpsum"), (2, 64, 32, 32, "silu"), (1, 16, 512, 24, "none")])
+def test_one_frame_conv_kept_context_product(B, H, cin, cout, epi):
+    """OnirisConvArgs.ctx_prod (ABI 11): the context product of the cached pair stored by an all-phases launch (mode 1) or by
+    the context-phases-only launch (mode 3), and read back by own-phases-only launches (mode 2) -- all BIT-identical to the
+    plain launch, for every epilogue, and with other gate coefficients than the ones the product was stored under (the
+    sampler's 31 evaluations per frame differ in exactly that).  y3 itself against the fp32 reference."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(cin + H + 1)
+    w2, w3 = torch.randn(cout, cin, 3, 3), torch.randn(cout, cin, 2, 3, 3)
+    p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=False)
+    cache0 = bfr(torch.randn(B, cin, 2, H, H))
+    pad = cache0.permute(0, 2, 3, 4, 1).to(DEV, torch.bfloat16).contiguous()          # (B, 2, H, H, C)
+    assert ops.ctx_product_ok(H, H, cin, cout)
+    Co = ops.roundup(cout, 8)
+    F = torch.nn.functional
+    kept = None
+    for it in range(3):                                                               # three "evaluations": new x, new gates
+        x = nhwc(bfr(torch.randn(B, cin, H, H)))
+        g = (torch.rand(B) * 0.6 + 0.05).to(DEV)
+        kw = {}
+        if epi == "silu":
+            kw = dict(cscale=(torch.rand(B, cout) + 0.5).to(DEV))
+        elif epi == "mpsum":
+            kw = dict(res=nhwc(bfr(torch.randn(B, cout, H, H))), ta=0.7, tb=0.5, clip=2.0)
+        plain = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, **kw)
+        if kept is None:
+            kept = torch.full((B, H, H, Co), float("nan"), device=DEV)
+            stored = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, ctx_prod=kept, ctx_prod_mode=1, **kw)
+            assert torch.equal(plain, stored)
+            only = ops.gated_conv_ctx_product(pad, pw2, pw3, B)
+            assert torch.equal(only, kept) and bool(torch.isfinite(kept).all())
+            e3, _ = O.weight_effective(w3, 1.0, False)
+            y3 = F.conv2d(cache0[:, :, 0], e3[:, :, 0], padding=1) + F.conv2d(cache0[:, :, 1], e3[:, :, 1], padding=1)
+            e = rel(kept.cpu().permute(0, 3, 1, 2)[:, :cout], y3)
+            print("kept context product", (B, H, cin, cout), "rel", e)
+            assert e < 6e-3                                                           # bf16 operands, fp32 sum, fp32 store
+        before = kept.clone()
+        read = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, ctx_prod=kept, ctx_prod_mode=2, **kw)
+        assert torch.equal(plain, read), (it, (plain.float() - read.float()).abs().max().item())
+        assert torch.equal(before, kept)                                              # mode 2 only reads
+    # a launch the one-frame kernel cannot serve must refuse the mode instead of ignoring it
+    x2 = nhwc(bfr(torch.randn(2 * B, cin, H, H)))
+    ctx2 = torch.cat([pad, x2.reshape(B, 2, H, H, cin)], 1).contiguous()
+    with pytest.raises(RuntimeError):
+        ops._conv_launch(x2, ctx2, pw2.wf, pw3.wf, torch.empty(2 * B, H, H, Co, dtype=torch.bfloat16, device=DEV),
+                         torch.ones(2 * B, device=DEV), torch.ones(2 * B, device=DEV), B, 1, 2, H, H, cin, pw2.CinP, Co, pw2.CoutP, 9,
+                         ctx_bstride=4, ctx_T=4, coff=(0, 1), ctx_prod=kept, ctx_prod_mode=2)
+
+
 @pytest.mark.parametrize("N,H,cin,cout,clip", [(9, 32, 128, 128, 2.0), (15, 24, 64, 200, 0.0), (33, 16, 256, 256, 3.0)])
 def test_conv1x1_mpsum_large(N, H, cin, cout, clip):
     """attn_proj-shaped op on the LDS-DMA GEMM: out = clip(ta*res + tb*(W x)) with >= 8192 positions, + gradients."""
