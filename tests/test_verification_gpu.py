@@ -114,7 +114,7 @@ def test_gated_conv_one_frame_bf16_faithful(B, H, cin, cout):
     assert e3 <= 2e-6 and e <= TIGHT
 
 
-@pytest.mark.parametrize("kind,B,T,H,m", [("video", 2, 4, 8, 2), ("video", 1, 8, 16, 1), ("frame", 6, 1, 16, 2)])
+@pytest.mark.parametrize("kind,B,T,H,m", [("video", 2, 4, 8, 2), ("video", 1, 8, 16, 1), ("frame", 6, 1, 16, 2), ("video", 1, 16, 8, 4)])
 def test_attention_core_bf16_faithful(kind, B, T, H, m):
     """The flash kernels on prepared q, k, v (what the qkv kernels hand them: unit-RMS vectors, q carrying 1/8 log2 e): dense
     masked softmax(q k) v in fp64 on the same bf16 values.  The kernels round P to bf16 in front of the P V product (relative
@@ -163,3 +163,84 @@ def test_act_bf16_faithful(N, H, C):
     e = (sd(nchw(xn), rn), sd(nchw(a), ra))
     print("act bf16-faithful (pixel norm, silu)", (N, H, C), e)
     assert e[0] <= TIGHT and e[1] <= 2 * TIGHT        # (silu of the ROUNDED norm or of the fp32 one: whichever the kernel does, within a flip)
+
+
+@pytest.mark.parametrize("B,T,H,cin,cout", [(2, 4, 16, 64, 64), (1, 6, 32, 32, 32), (2, 3, 8, 128, 256), (1, 5, 16, 128, 64)])
+def test_gated_conv_train_backward_bf16_faithful(B, T, H, cin, cout):
+    """Data gradient and gate-coefficient gradients of the gated conv (autograd of edm2/conv.py:74-95), replayed on what the
+    backward kernels read: the bf16 incoming gradient, the bf16 raw output and context product the forward stored, and the
+    bf16 context gradient dy3 = cb0 g[clean] + cb1 g[noised] the pre-pass writes (oniris_gconv_bwd_prep).  The weight gradient
+    is not replayed here (its split-K slabs are rounded to bf16 one by one: test_gated_conv_train states its bound)."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(8 + cin)
+    p2 = torch.nn.Parameter(torch.randn(cout, cin, 3, 3).to(DEV)); p3 = torch.nn.Parameter(torch.randn(cout, cin, 2, 3, 3).to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=True)
+    w2, w3 = packed_weight(pw2, cout, cin, (3, 3)).double(), packed_weight(pw3, cout, cin, (2, 3, 3)).double()
+    N = B * 2 * T
+    x0, g0 = bfr(torch.randn(N, cin, H, H)), bfr(torch.randn(N, cout, H, H))
+    ca0, cb0 = torch.rand(N) * 0.5 + 0.5, torch.rand(N) * 0.5
+    x = nhwc(x0).requires_grad_(True)
+    ca, cb = ca0.to(DEV).requires_grad_(True), cb0.to(DEV).requires_grad_(True)
+    y = ops.gated_conv_train(x, None, pw2, pw3, B, T, coefs=(ca, cb))
+    y.backward(nhwc(g0))
+    # forward quantities as stored
+    xs = x0.double().reshape(B, 2, T, cin, H, H)
+    clean = torch.cat([torch.ones(B, 2, cin, H, H, dtype=torch.float64), xs[:, 0]], dim=1)
+    y3 = (F.conv2d(clean[:, 0:T].reshape(B * T, cin, H, H), w3[:, :, 0], padding=1) +
+          F.conv2d(clean[:, 1:T + 1].reshape(B * T, cin, H, H), w3[:, :, 1], padding=1)).reshape(B, 1, T, cout, H, H)
+    y2 = F.conv2d(x0.double(), w2, padding=1).reshape(B, 2, T, cout, H, H)
+    cav, cbv = ca0.double().reshape(B, 2, T, 1, 1, 1), cb0.double().reshape(B, 2, T, 1, 1, 1)
+    raw_s, y3_s = bfr((cav * y2 + cbv * y3).float()).double(), bfr(y3.float()).double()       # what the forward wrote (bf16)
+    g = g0.double().reshape(B, 2, T, cout, H, H)
+    # gate-coefficient gradients: d ca = <g, y2>, d cb = <g, y3> with y2 recovered from the stored pair
+    dca_ref = (g * ((raw_s - cbv * y3_s) / cav)).sum(dim=(3, 4, 5)).reshape(N)
+    dcb_ref = (g * y3_s).sum(dim=(3, 4, 5)).reshape(N)
+    # context gradient as stored (bf16), then the data gradient
+    dy3 = bfr((cb0.reshape(B, 2, T, 1, 1, 1) * g0.reshape(B, 2, T, cout, H, H)).sum(dim=1)).double()      # (B, T, cout, H, W)
+    own = F.conv_transpose2d((cav * g).reshape(N, cout, H, H), w2, padding=1).reshape(B, 2, T, cin, H, H)
+    dpad = torch.cat([dy3, torch.zeros(B, 2, cout, H, H, dtype=torch.float64)], dim=1)                      # frames T, T+1: nothing
+    dctx = (F.conv_transpose2d(dpad[:, 2:T + 2].reshape(B * T, cout, H, H), w3[:, :, 0], padding=1) +
+            F.conv_transpose2d(dpad[:, 1:T + 1].reshape(B * T, cout, H, H), w3[:, :, 1], padding=1)).reshape(B, T, cin, H, H)
+    own[:, 0] += dctx
+    dx_ref = bfr(own.reshape(N, cin, H, H).float())
+    e = (sd(nchw(x.grad), dx_ref), sd(ca.grad, dca_ref), sd(cb.grad, dcb_ref))
+    print("gated_conv_train backward bf16-faithful", (B, T, H, cin, cout), "dx, dca, dcb", e)
+    assert max(e) <= TIGHT
+
+
+@pytest.mark.parametrize("kind,B,T,H,m", [("video", 2, 4, 8, 2), ("video", 1, 8, 16, 1), ("frame", 6, 1, 16, 2), ("video", 1, 16, 8, 4)])
+def test_attention_core_backward_bf16_faithful(kind, B, T, H, m):
+    """dQ, dK, dV of the flash backward (persistent dQ and dK/dV kernels for the training table, grid kernels per frame) replayed on
+    their own operands: P = 2^(s - lse) from the forward's stored row constants, delta = <dO, O> from the forward's bf16 output,
+    P and dS rounded to bf16 in front of their products (csrc/attention.hip:519-534, 708-731), the 1/8 of the score scale where
+    each kernel applies it."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(9)
+    P = H * H
+    frames = 2 * T if kind == "video" else 1
+    N, C = B * frames, 64 * m
+    c = 0.125 * 1.4426950408889634
+    unit = lambda: O.normalize(torch.randn(N, P, m, 64), dim=-1)
+    q0, k0, v0, g0 = bfr(unit() * c), bfr(unit()), bfr(unit()), bfr(torch.randn(N, P, m, 64))
+    dev = lambda z: z.reshape(N, P, C).to(DEV, torch.bfloat16).contiguous()
+    qd, kd, vd, gd = dev(q0), dev(k0), dev(v0), dev(g0)
+    out, lse, tabs, meta = ops._attn_core_fwd(qd, kd, vd, kind, B, T, m, P)
+    dq, dk, dv = ops._attn_core_bwd(qd, kd, vd, out, lse, gd, tabs, meta)
+    Bq = B if kind == "video" else N
+    seq = lambda z: z.double().reshape(Bq, frames * P, m, 64).permute(0, 2, 1, 3)               # (b, m, L, 64)
+    q, k, v, g, o = seq(q0), seq(k0), seq(v0), seq(g0), seq(out.float().cpu().reshape(N, P, m, 64))
+    s = (q.float() @ k.float().transpose(-1, -2)).double()
+    p = torch.exp2(s - lse.double().cpu().unsqueeze(-1))
+    if kind == "video":
+        p = p.masked_fill(~torch.from_numpy(O.train_allowed_tokens(T, P)), 0.0)
+    delta = (g * o).sum(-1, keepdim=True)
+    ds = p * (g @ v.transpose(-1, -2) - delta)
+    r = lambda z: bfr(z.float()).double()
+    back = lambda z: bfr(z.permute(0, 2, 1, 3).reshape(N, P, C).float())
+    dv_ref = back(r(p).transpose(-1, -2) @ g)
+    dq_ref = back((r(ds) @ k) * 0.125)
+    dk_ref = back((r(ds * 0.125).transpose(-1, -2) @ q) / c)
+    e = (sd(dq, dq_ref), sd(dk, dk_ref), sd(dv, dv_ref))
+    print("attention backward bf16-faithful", (kind, B, T, H, m), "dq, dk, dv", e)
+    assert max(e) <= TIGHT
