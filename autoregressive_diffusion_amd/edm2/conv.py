@@ -249,12 +249,16 @@ class MPCausal3DGatedConv(nn.Module):
             # per generated frame, sampler.py:50-76; the reference's F.conv3d recomputes it each time, conv.py:84-86): kept
             # in the cache entry beside the pair it belongs to -- computed by UNet.prewarm_eval or by the first evaluation,
             # read by all later ones, dropped (by identity of the pair) as soon as the cache moves on.
+            # (... or the weights do: the third entry is the packed-weight signature object of the bank, replaced by every
+            # re-packing -- WeightBank.prepare)
             kept = cache.get("_ctx_product") if had_pair else None
-            if kept is not None and kept[1] is pad:
+            wsig = getattr(pw3.bank, "_packed_sig", None)
+            if kept is not None and kept[1] is pad and kept[2] is wsig and wsig is not None:
                 epi = dict(epi, ctx_prod=kept[0], ctx_prod_mode=2)
-            elif had_pair and pad.is_contiguous() and ops.ctx_product_ok(H, W, C, pw2.cout) and not torch.cuda.is_current_stream_capturing():
+            elif (had_pair and wsig is not None and pad.is_contiguous() and ops.ctx_product_ok(H, W, C, pw2.cout)
+                  and not torch.cuda.is_current_stream_capturing()):
                 y3 = torch.empty((batch_size, H, W, ops.roundup(pw2.cout, 8)), dtype=torch.float32, device=x.device)
-                cache["_ctx_product"] = (y3, pad)
+                cache["_ctx_product"] = (y3, pad, wsig)
                 epi = dict(epi, ctx_prod=y3, ctx_prod_mode=1)
             return ops.gated_conv_eval(x, gate, pw2, pw3, batch_size, 1, pad.contiguous(), coefs, ctx_T=2, **epi), cache
         ctx = torch.cat([pad, x.reshape(batch_size, t, H, W, C)], dim=1).contiguous()
@@ -268,14 +272,17 @@ class MPCausal3DGatedConv(nn.Module):
         pad = cache.get("activations") if cache else None
         if pad is None or not pad.is_contiguous() or pad.dtype != BF16:
             return
-        kept = cache.get("_ctx_product")
-        if kept is not None and kept[1] is pad:
-            return
         pw2, pw3 = self.last_frame_conv.weight.pw, self.weight.pw
+        wsig = getattr(getattr(pw3, "bank", None), "_packed_sig", None)
+        if wsig is None:
+            return
+        kept = cache.get("_ctx_product")
+        if kept is not None and kept[1] is pad and kept[2] is wsig:
+            return
         B, _, H, W, C = pad.shape
         if not ops.ctx_product_ok(H, W, C, pw2.cout):
             return
-        cache["_ctx_product"] = (ops.gated_conv_ctx_product(pad, pw2, pw3, B), pad)
+        cache["_ctx_product"] = (ops.gated_conv_ctx_product(pad, pw2, pw3, B), pad, wsig)
 
     def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
         with weights_ready(self):

@@ -777,3 +777,44 @@ def test_zero_grad_set_to_none_between_forward_and_backward():
     assert k in got and set(want) == set(got)
     # (the first step's forced weight normalisation moved the weights by < 1e-4, so the gradients agree closely)
     assert rel(got[k], want[k]) < 2e-2 and rel(got["unet.dec.8x8_in0.conv_res1.weight.weight"], want["unet.dec.8x8_in0.conv_res1.weight.weight"]) < 2e-2
+
+
+def test_kept_context_product_follows_cache_and_weights():
+    """The context product a gated conv keeps beside its cached pair (OnirisConvArgs.ctx_prod, conv.py `_cl`) must be used while
+    pair AND weights are the ones it was computed from, and only then: repeated one-frame evaluations against one cache are
+    bit-identical to evaluations that never kept anything; a changed weight, or a cache that moved on, drops it."""
+    from autoregressive_diffusion_amd import ops
+    from edm2.conv import MPCausal3DGatedConv
+    torch.manual_seed(91)
+    net = build_precond(C1_CFG, 5, 0.5).eval()
+    ctx = torch.randn(1, 4, 8, 64, 64, device=DEV)
+    lab = torch.randint(0, 4, (1, 4), device=DEV)
+    fork = lambda c: {k: fork(v) for k, v in c.items() if k != "_ctx_product"} if isinstance(c, dict) else c
+    kept_entries = lambda c: sum(kept_entries(v) for v in c.values()) + ("_ctx_product" in c) if isinstance(c, dict) else 0
+    with torch.no_grad():
+        _, cache0 = net(ctx, torch.full((1, 4), 0.05, device=DEV), lab, update_cache=True)
+        x1, x2 = torch.randn(1, 1, 8, 64, 64, device=DEV), torch.randn(1, 1, 8, 64, 64, device=DEV)
+        s1, s2, l1 = torch.full((1, 1), 3.0, device=DEV), torch.full((1, 1), 0.4, device=DEV), lab[:, :1]
+        old = ops.KEEP_CTX_PRODUCT
+        try:
+            ops.KEEP_CTX_PRODUCT = 0
+            plain = [net(x, s, l1, cache=fork(cache0))[0] for x, s in ((x1, s1), (x2, s2))]
+        finally:
+            ops.KEEP_CTX_PRODUCT = old
+        c = fork(cache0)
+        a1 = net(x1, s1, l1, cache=c)[0]                   # stores the products (mode 1)
+        n_kept = kept_entries(c)
+        a2 = net(x2, s2, l1, cache=c)[0]                   # reads them (mode 2): other input, other sigma, other gates
+        assert n_kept >= 8, n_kept
+        assert torch.equal(a1, plain[0]) and torch.equal(a2, plain[1])
+        # the weights change under the same cache: the stale products must not be used
+        conv = next(m for m in net.modules() if isinstance(m, MPCausal3DGatedConv) and m.in_channels >= 32)
+        conv.weight.weight.add_(torch.randn_like(conv.weight.weight) * 0.5)
+        b_kept = net(x2, s2, l1, cache=c)[0]
+        b_fresh = net(x2, s2, l1, cache=fork(cache0))[0]
+        assert torch.equal(b_kept, b_fresh) and not torch.equal(b_kept, a2)
+        # the cache moves on: new pairs, new products
+        _, c2 = net(x1, s2, l1, cache=c, update_cache=True)
+        d_kept = net(x2, s2, l1, cache=c2)[0]
+        d_fresh = net(x2, s2, l1, cache=fork(c2))[0]
+        assert torch.equal(d_kept, d_fresh)
