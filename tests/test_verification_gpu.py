@@ -51,7 +51,10 @@ def test_conv_plain_bf16_faithful(N, H, cin, cout, k):
 
 
 @pytest.mark.parametrize("B,T,H,cin,cout,epi", [(2, 4, 16, 64, 64, "none"), (1, 6, 32, 32, 32, "mpsum"), (2, 3, 8, 128, 128, "silu"),
-                                                (1, 4, 16, 256, 128, "mpsum"), (1, 5, 32, 96, 32, "none")])
+                                                (1, 4, 16, 256, 128, "mpsum"), (1, 5, 32, 96, 32, "none"),
+                                                # several tiles per persistent workgroup (1024 tiles on 256 CUs) / the streaming kernel
+                                                # over whole 16-frame segments
+                                                (6, 16, 16, 128, 128, "mpsum"), (2, 16, 64, 32, 32, "silu")])
 def test_gated_conv_train_forward_bf16_faithful(B, T, H, cin, cout, epi):
     """DART training layout (edm2/conv.py:59-95): own 3x3 product + the two context taps over the CLEAN frames t-2, t-1 (padding
     frames of ones, :68), gated sum in fp32, fused epilogue -- every output the launch writes."""
