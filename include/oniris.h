@@ -23,7 +23,8 @@ extern "C" {
 typedef void* oniris_stream_t;
 
 const char* oniris_last_error(void);
-int oniris_abi_version(void);
+int oniris_abi_version(void);   /* 11.  10 -> 11: OnirisConvArgs.ctx_prod / ctx_prod_mode (appended fields); 9 -> 10: OnirisConvArgs.clip_flag,
+                                 * oniris_gconv_bwd_fused(+ clip_flag, coef_own_scaled), oniris_qkv_norm_hd / _hd_bwd / oniris_rope_hd       */
 /* Measurement aid: arm a pair of HIP events (hipEvent_t created with timing); the next MFMA conv / weight-gradient /
  * scheduled attention-forward kernel this THREAD launches records its own begin and end into them (hipExtLaunchKernel:
  * the dispatch's timestamps, as rocprofv3 reports them; events recorded around a launch also time the kernel boundary).
