@@ -247,3 +247,72 @@ def test_attention_core_backward_bf16_faithful(kind, B, T, H, m):
     e = (sd(dq, dq_ref), sd(dk, dk_ref), sd(dv, dv_ref))
     print("attention backward bf16-faithful", (kind, B, T, H, m), "dq, dk, dv", e)
     assert max(e) <= TIGHT
+
+
+@pytest.mark.parametrize("B,T,H,cin,cout,epi", [(2, 4, 16, 64, 64, "silu"), (1, 6, 32, 32, 32, "silu"), (2, 3, 8, 128, 128, "mpsum"),
+                                                (1, 5, 16, 128, 64, "mpsum_clipped"), (1, 6, 32, 32, 32, "mpsum_clipped"), (1, 6, 32, 32, 32, "mpsum")])
+def test_gated_conv_train_backward_epilogues_bf16_faithful(B, T, H, cin, cout, epi):
+    """The backward of the two fused epilogues (oniris_gconv_bwd_fused modes 1 and 2 + dgrad): emb-scale + mp_silu
+    (networks_edm2.py:78-79) and mp_sum + clip (:87-93), the latter with the clip never reached (aliasing protocol: no dout is
+    written, dgrad reads g with tb * ca) and reached (g masked in place).  Replayed on the stored bf16 tensors: raw conv output,
+    context product, clipped output; dout and dy3 rounded to bf16 where the pre-pass stores them."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(10 + cin + len(epi))
+    p2 = torch.nn.Parameter(torch.randn(cout, cin, 3, 3).to(DEV)); p3 = torch.nn.Parameter(torch.randn(cout, cin, 2, 3, 3).to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=True)
+    w2, w3 = packed_weight(pw2, cout, cin, (3, 3)).double(), packed_weight(pw3, cout, cin, (2, 3, 3)).double()
+    N = B * 2 * T
+    x0, g0 = bfr(torch.randn(N, cin, H, H)), bfr(torch.randn(N, cout, H, H))
+    ca0, cb0 = torch.rand(N) * 0.5 + 0.5, torch.rand(N) * 0.5
+    x = nhwc(x0).requires_grad_(True)
+    ca, cb = ca0.to(DEV).requires_grad_(True), cb0.to(DEV).requires_grad_(True)
+    ta, tb, clip = 0.7, 0.5, (1.0 if epi == "mpsum_clipped" else 30.0)
+    if epi == "silu":
+        cs0 = torch.rand(N, cout) + 0.5
+        cs = cs0.to(DEV).requires_grad_(True)
+        y = ops.gated_conv_train(x, None, pw2, pw3, B, T, coefs=(ca, cb), cscale=cs)
+    else:
+        r0 = bfr(torch.randn(N, cout, H, H))
+        res = nhwc(r0).requires_grad_(True)
+        y = ops.gated_conv_train(x, None, pw2, pw3, B, T, coefs=(ca, cb), res=res, ta=ta, tb=tb, clip=clip)
+    y.backward(nhwc(g0).clone())
+    # forward quantities as stored
+    xs = x0.double().reshape(B, 2, T, cin, H, H)
+    clean = torch.cat([torch.ones(B, 2, cin, H, H, dtype=torch.float64), xs[:, 0]], dim=1)
+    y3 = (F.conv2d(clean[:, 0:T].reshape(B * T, cin, H, H), w3[:, :, 0], padding=1) +
+          F.conv2d(clean[:, 1:T + 1].reshape(B * T, cin, H, H), w3[:, :, 1], padding=1)).reshape(B, 1, T, cout, H, H)
+    y2 = F.conv2d(x0.double(), w2, padding=1).reshape(B, 2, T, cout, H, H)
+    cav, cbv = ca0.double().reshape(B, 2, T, 1, 1, 1), cb0.double().reshape(B, 2, T, 1, 1, 1)
+    v = cav * y2 + cbv * y3
+    raw_s, y3_s = bfr(v.float()).double(), bfr(y3.float()).double()
+    g = g0.double().reshape(B, 2, T, cout, H, H)
+    extra = {}
+    if epi == "silu":
+        c6 = cs0.double().reshape(B, 2, T, cout, 1, 1)
+        z = raw_s * c6
+        sig = torch.sigmoid(z)
+        dz = g * sig * (1 + z * (1 - sig)) / 0.596
+        extra["dcs"] = (sd(cs.grad, (dz * raw_s).sum(dim=(4, 5)).reshape(N, cout)))
+        dv = bfr((dz * c6).float()).double()         # dout is stored in bf16, and the ROUNDED value is what the sums below see
+    else:
+        out_s = bfr((ta * r0.double().reshape(v.shape) + tb * v).clamp(-clip, clip).float()).double()
+        mask = (out_s.abs() < clip).double()
+        assert (mask.mean().item() < 0.98) == (epi == "mpsum_clipped")
+        dv = tb * g * mask
+        extra["dres"] = sd(nchw(res.grad), bfr((ta * g * mask).reshape(N, cout, H, H).float()))
+    dca_ref = (dv * ((raw_s - cbv * y3_s) / cav)).sum(dim=(3, 4, 5)).reshape(N)
+    dcb_ref = (dv * y3_s).sum(dim=(3, 4, 5)).reshape(N)
+    dy3 = bfr((cbv * dv).sum(dim=1).float()).double()                                                        # (B, T, cout, H, W)
+    if epi == "silu" or epi == "mpsum_clipped":
+        # dout is a stored bf16 tensor (silu: written by the pre-pass; clipped: g masked in place, scaled by the coefficient)
+        dsrc = dv if epi == "silu" else g * mask * tb
+    else:
+        dsrc = g * tb                                                                                         # read as g with tb * ca
+    own = F.conv_transpose2d((cav * dsrc).reshape(N, cout, H, H), w2, padding=1).reshape(B, 2, T, cin, H, H)
+    dpad = torch.cat([dy3, torch.zeros(B, 2, cout, H, H, dtype=torch.float64)], dim=1)
+    own[:, 0] += (F.conv_transpose2d(dpad[:, 2:T + 2].reshape(B * T, cout, H, H), w3[:, :, 0], padding=1) +
+                  F.conv_transpose2d(dpad[:, 1:T + 1].reshape(B * T, cout, H, H), w3[:, :, 1], padding=1)).reshape(B, T, cin, H, H)
+    e = dict(dx=sd(nchw(x.grad), bfr(own.reshape(N, cin, H, H).float())), dca=sd(ca.grad, dca_ref), dcb=sd(cb.grad, dcb_ref), **extra)
+    print("gated_conv_train backward epilogue bf16-faithful", (B, T, H, cin, cout, epi), e)
+    assert max(e.values()) <= TIGHT
