@@ -316,3 +316,48 @@ def test_gated_conv_train_backward_epilogues_bf16_faithful(B, T, H, cin, cout, e
     e = dict(dx=sd(nchw(x.grad), bfr(own.reshape(N, cin, H, H).float())), dca=sd(ca.grad, dca_ref), dcb=sd(cb.grad, dcb_ref), **extra)
     print("gated_conv_train backward epilogue bf16-faithful", (B, T, H, cin, cout, epi), e)
     assert max(e.values()) <= TIGHT
+
+
+@pytest.mark.parametrize("form,N,H,C,Cs", [("enc", 6, 16, 64, 0), ("enc", 3, 32, 32, 0), ("dec", 4, 16, 64, 32), ("dec", 2, 32, 32, 64)])
+def test_act_backward_bf16_faithful(form, N, H, C, Cs):
+    """Backward of the fused activation pass: pixel norm + mp_silu (encoder blocks, networks_edm2.py:70-77) and mp_cat + mp_silu
+    (decoder blocks, :72-77 with utils.py mp_cat): fp64 autograd of the formulas on the bf16 inputs, result rounded to bf16."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(11 + C)
+    x0 = bfr(torch.randn(N, C, H, H) * 1.3)
+    x = nhwc(x0).requires_grad_(True)
+    xr = x0.double().requires_grad_(True)
+    if form == "enc":
+        o1, o2 = ops.act(x, norm=True)
+        r1 = O.normalize(xr, dim=1)
+        rq = r1 + (bfr(r1.detach().float()).double() - r1.detach())       # the activation sees the STORED (bf16) first output
+        r2 = rq * torch.sigmoid(rq) / 0.596
+        ins, rins = [x], [xr]
+    else:
+        s0 = bfr(torch.randn(N, Cs, H, H))
+        sk = nhwc(s0).requires_grad_(True)
+        sr = s0.double().requires_grad_(True)
+        t = 0.5
+        cc = math.sqrt((C + Cs) / ((1 - t) ** 2 + t ** 2))
+        w1, w2 = cc / math.sqrt(C) * (1 - t), cc / math.sqrt(Cs) * t                      # utils.py mp_cat
+        o1, o2 = ops.act(x, sk, w1, w2, want_xo=True)
+        r1 = torch.cat([w1 * xr, w2 * sr], dim=1)
+        rq = r1 + (bfr(r1.detach().float()).double() - r1.detach())
+        r2 = rq * torch.sigmoid(rq) / 0.596
+        ins, rins = [x, sk], [xr, sr]
+    g1, g2 = bfr(torch.randn(*r1.shape)), bfr(torch.randn(*r2.shape))
+    got = torch.autograd.grad([o1, o2], ins, [nhwc(g1), nhwc(g2)])
+    if form == "enc":
+        # the kernel differentiates the norm at the STORED normalised tensor and the saved fp32 denominator (elementwise.hip
+        # act_bwd_kernel): dx = (g - xn (g . xn) s / (C (s - eps))) / s with xn = bf16(x / s), s = eps + |x| / sqrt(C)
+        xq = rq.detach()
+        sg = torch.sigmoid(xq)
+        gt = g2.double() * sg * (1 + xq * (1 - sg)) / 0.596 + g1.double()
+        sden = 1e-4 + x0.double().norm(dim=1, keepdim=True) / math.sqrt(C)
+        ref = [(gt - xq * (gt * xq).sum(dim=1, keepdim=True) * sden / (C * (sden - 1e-4))) / sden]
+    else:
+        ref = torch.autograd.grad([r1, r2], rins, [g1.double(), g2.double()])
+    e = [sd(nchw(a), bfr(b.float())) for a, b in zip(got, ref)]
+    fe = (sd(nchw(o1), bfr(r1.detach().float())), sd(nchw(o2), bfr(r2.detach().float())))
+    print("act backward bf16-faithful", (form, N, H, C, Cs), "forward outputs", fe, "input gradients", e)
+    assert max(fe) <= TIGHT and max(e) <= TIGHT
