@@ -361,3 +361,78 @@ def test_act_backward_bf16_faithful(form, N, H, C, Cs):
     fe = (sd(nchw(o1), bfr(r1.detach().float())), sd(nchw(o2), bfr(r2.detach().float())))
     print("act backward bf16-faithful", (form, N, H, C, Cs), "forward outputs", fe, "input gradients", e)
     assert max(fe) <= TIGHT and max(e) <= TIGHT
+
+
+def _ternary(shape, density, gen):
+    """Sparse tensor of -1 / 0 / +1: every product and every partial sum of a weight gradient built from two of them is a small
+    integer, exactly representable in the bf16 split-K slabs and in the fp32 accumulators -- the kernels must be EXACT."""
+    return (torch.randint(0, 2, shape, generator=gen) * 2 - 1).float() * (torch.rand(shape, generator=gen) < density).float()
+
+
+@pytest.mark.parametrize("B,T,H,cin,cout,dens", [(1, 2, 8, 32, 32, 0.25), (2, 8, 64, 32, 32, 0.05), (2, 4, 16, 128, 128, 0.12),
+                                                 (2, 4, 8, 256, 256, 0.2), (1, 6, 32, 64, 64, 0.08), (1, 3, 16, 96, 160, 0.15),
+                                                 (2, 16, 64, 32, 32, 0.04)])
+def test_gated_conv_weight_gradient_integer_exact(B, T, H, cin, cout, dens):
+    """Weight gradient of the gated conv -- own 3x3 weight over both slots, the two context taps over the clean frames, split-K
+    slabs in bf16, slab reduction + normalisation backward in weight_bwd -- on sparse ternary activations and gradients with
+    power-of-two gate coefficients: every slab entry is a small integer, so any lost, doubled or misplaced position, a wrong
+    coefficient or a slab rounding shows up at full size.  Compared with fp64 autograd through the reference's forced weight
+    normalisation (conv.py:14-21); the bound is fp32 rounding of the normalisation backward alone.  Shapes: the streaming kernel of
+    the 32-channel level (several segments), the LDS-DMA kernels for 16x16 and 8x8 tiles, ragged channel counts."""
+    from autoregressive_diffusion_amd import ops
+    gen = torch.Generator().manual_seed(12 + cin + H)
+    w2, w3 = torch.randn(cout, cin, 3, 3, generator=gen), torch.randn(cout, cin, 2, 3, 3, generator=gen)
+    p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=True)
+    N = B * 2 * T
+    x0, g0 = _ternary((N, cin, H, H), dens, gen), _ternary((N, cout, H, H), dens, gen)
+    ca0 = torch.tensor([1.0, 2.0, 0.5])[torch.randint(0, 3, (N,), generator=gen)]
+    cb0 = torch.tensor([1.0, 0.5])[torch.randint(0, 2, (N,), generator=gen)]
+    x = nhwc(x0).requires_grad_(True)
+    y = ops.gated_conv_train(x, None, pw2, pw3, B, T, coefs=(ca0.to(DEV), cb0.to(DEV)))
+    y.backward(nhwc(g0))
+    bank.backward()
+    # fp64 reference through the forced normalisation
+    r2, r3 = w2.double().requires_grad_(True), w3.double().requires_grad_(True)
+    e2, _ = O.weight_effective(r2, 1.0, training=True)
+    e3, _ = O.weight_effective(r3, 1.0, training=True)
+    xs = x0.double().reshape(B, 2, T, cin, H, H)
+    clean = torch.cat([torch.ones(B, 2, cin, H, H, dtype=torch.float64), xs[:, 0]], dim=1)
+    y3 = (F.conv2d(clean[:, 0:T].reshape(B * T, cin, H, H), e3[:, :, 0], padding=1) +
+          F.conv2d(clean[:, 1:T + 1].reshape(B * T, cin, H, H), e3[:, :, 1], padding=1)).reshape(B, 1, T, cout, H, H)
+    y2 = F.conv2d(x0.double(), e2, padding=1).reshape(B, 2, T, cout, H, H)
+    v = ca0.double().reshape(B, 2, T, 1, 1, 1) * y2 + cb0.double().reshape(B, 2, T, 1, 1, 1) * y3
+    (v * g0.double().reshape(v.shape)).sum().backward()
+    rel64 = lambda a, b: ((a.double().cpu() - b).norm() / b.norm()).item()
+    e = (rel64(p2.grad, r2.grad), rel64(p3.grad, r3.grad))
+    worst = max(((p2.grad.double().cpu() - r2.grad).abs().max() / r2.grad.abs().max()).item(),
+                ((p3.grad.double().cpu() - r3.grad).abs().max() / r3.grad.abs().max()).item())
+    print("gated conv weight gradient, integer-exact inputs", (B, T, H, cin, cout), "rel L2 dW2, dW3", e, "worst element / max", worst)
+    assert max(e) <= 2e-6 and worst <= 1e-5
+
+
+@pytest.mark.parametrize("N,H,cin,cout,k,dens", [(16, 32, 128, 256, 1, 0.05), (9, 32, 64, 96, 1, 0.08), (64, 64, 32, 96, 1, 0.03), (12, 16, 64, 64, 3, 0.12),
+                                                 (6, 8, 256, 128, 3, 0.2), (32, 64, 32, 32, 3, 0.04), (130, 1, 64, 96, 1, 0.3)])
+def test_plain_conv_weight_gradient_integer_exact(N, H, cin, cout, k, dens):
+    """The same for MPConv (1x1 through the LDS-DMA GEMM weight-gradient kernel and the small-channel fallback, plain 3x3 of the 2-D
+    steps, a linear layer): sparse ternary x and dy, fp64 autograd through the forced normalisation."""
+    from autoregressive_diffusion_amd import ops
+    gen = torch.Generator().manual_seed(13 + cin + H)
+    kk = (k, k) if H > 1 else ()
+    w = torch.randn(cout, cin, *kk, generator=gen)
+    p = torch.nn.Parameter(w.clone().to(DEV))
+    bank, (pw,) = make_bank([p])
+    bank.prepare(training=True)
+    x0, g0 = _ternary((N, cin, H, H), dens, gen), _ternary((N, cout, H, H), dens, gen)
+    x = nhwc(x0).requires_grad_(True)
+    y = ops.conv(x, pw)
+    y.backward(nhwc(g0))
+    bank.backward()
+    r = w.double().requires_grad_(True)
+    e_, _ = O.weight_effective(r, 1.0, training=True)
+    (F.conv2d(x0.double(), e_.reshape(cout, cin, k, k), padding=k // 2) * g0.double()).sum().backward()
+    e = ((p.grad.double().cpu() - r.grad).norm() / r.grad.norm()).item()
+    worst = ((p.grad.double().cpu() - r.grad).abs().max() / r.grad.abs().max()).item()
+    print("plain conv weight gradient, integer-exact inputs", (N, H, cin, cout, k), "rel L2", e, "worst element / max", worst)
+    assert e <= 2e-6 and worst <= 1e-5
