@@ -622,6 +622,9 @@ def main():
             extra["rollout_32"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=32), quiet=True)
             extra["rollout_32"]["note"] = ("configs[4] settings (16 Heun steps = 31 evaluations per frame) on 32 generated frames behind a "
                                            "10-frame context; `python bench.py --mode rollout --gen-frames 256` runs the full 256")
+            r8 = rollout(types.SimpleNamespace(batch=8, ctx_frames=8, gen_frames=8), quiet=True)
+            extra["rollout_b8"] = {k: r8[k] for k in ("value", "unit", "ms_per_unet_eval", "frames_generated", "batch", "finite")}
+            extra["rollout_b8"]["note"] = "the same sampler on 8 sequences at once (throughput; rollout_32 is the one-sequence latency case)"
         except Exception as e:                                   # (never lose the headline to an extra)
             extra["error"] = f"{type(e).__name__}: {e}"
         out["extra"] = extra
