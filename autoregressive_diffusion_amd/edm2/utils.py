@@ -47,6 +47,9 @@ def mp_silu(x):
 
 
 def mp_sum(a, b, t=0.5):
+    """(1 - t) a + t b, renormalised (utils.py:118-123); t may be a per-sample (B,) / per-sample-and-channel (B, C) tensor."""
+    if torch.is_tensor(t) and t.dim() > 0:
+        return bmult(a + bmult(b - a, t), ((1 - t) ** 2 + t ** 2) ** -0.5)
     return (a + (b - a) * t) * (1.0 / math.sqrt((1 - t) ** 2 + t ** 2))
 
 
@@ -65,6 +68,110 @@ def resample_cl(x, mode="keep"):
         return x.reshape(N, H // 2, 2, W // 2, 2, C).float().mean(dim=(2, 4)).to(x.dtype)
     assert mode == "up"
     return x[:, :, None, :, None, :].expand(N, H, 2, W, 2, C).reshape(N, 2 * H, 2 * W, C)
+
+
+# ---- the rest of the reference's public `edm2.utils` names (utils.py:94-107, 118-134, 153-235).  Host-side helpers on plain
+# (N, C, ...) tensors for code OUTSIDE the accelerated path that imports them from here -- the reference's VAE
+# (vae/vae.py:13: bmult), its VAE training scripts (cs_vae_train.py:19: GaussianLoss), its debugging aids.  None of them is
+# called by the modules of this package.
+
+def bmult(x, t):
+    """x scaled per sample (t: (B,)) or per sample and channel (t: (B, C)); a 0-d t is an ordinary scalar (utils.py:153-158)."""
+    if t.dim() == 0:
+        return x * t
+    if t.dim() not in (1, 2):
+        raise ValueError("bmult: t must be 0-, 1- or 2-dimensional")
+    return x * t.reshape(*t.shape, *([1] * (x.dim() - t.dim())))
+
+
+def mp_cat(a, b, dim=1, t=0.5):
+    """Magnitude-preserving concatenation along `dim` (utils.py:128-134); channels-last twin: mp_cat_cl."""
+    Na, Nb = a.shape[dim], b.shape[dim]
+    C = math.sqrt((Na + Nb) / ((1 - t) ** 2 + t ** 2))
+    return torch.cat([a * (C / math.sqrt(Na) * (1 - t)), b * (C / math.sqrt(Nb) * t)], dim=dim)
+
+
+def resample(x, f=[1, 1], mode="keep"):
+    """(N, C, H, W): 'down' = 2x2 mean, 'up' = every pixel repeated 2x2 -- the reference's separable filter [1, 1]
+    (utils.py:94-107), the only one its networks use (networks_edm2.py:22); other filters are refused."""
+    if mode == "keep":
+        return x
+    if [float(v) for v in f] != [1.0, 1.0]:
+        raise NotImplementedError("resample: only the [1, 1] filter of the reference configurations")
+    if mode == "down":
+        return torch.nn.functional.avg_pool2d(x, 2)
+    if mode != "up":
+        raise ValueError(f"resample: unknown mode {mode!r}")
+    return x.repeat_interleave(2, dim=-2).repeat_interleave(2, dim=-1)
+
+
+def GaussianLoss(mean, logvar, target, eps=1e-4):
+    """Mean negative log-likelihood of `target` under N(mean, exp(logvar)), with the constant 0.918 ~ ln(2 pi) / 2 the
+    reference adds (utils.py:209-210; `eps` is unused there as well)."""
+    nll = 0.5 * (logvar + (mean - target).square() * torch.exp(-logvar)) + 0.918
+    return nll.mean()
+
+
+def nan_hook(module, input, output):
+    """Forward hook: raise as soon as a module emits a NaN (utils.py:165-174)."""
+    outs = output if isinstance(output, (tuple, list)) else (output,)
+    for o in outs:
+        if torch.is_tensor(o) and torch.isnan(o).any():
+            raise Exception(f"NaN detected in output of {module.__class__.__name__}")
+
+
+class nan_inspector:
+    """`with nan_inspector(model): ...` -- nan_hook on every submodule for the duration of the block (utils.py:177-206)."""
+
+    def __init__(self, model):
+        self.model, self.handles = model, []
+
+    def __enter__(self):
+        self.handles = [m.register_forward_hook(nan_hook) for m in self.model.modules() if m is not self.model]
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        self.handles = []
+        return False
+
+
+def compare_caches(cache1, cache2, rtol=1e-4, atol=1e-4, verbose=True):
+    """True when two cache structures (nested dicts / lists / tuples of tensors and numbers) agree within the tolerances;
+    with `verbose` the first difference is printed with its path (utils.py:214-235)."""
+    def walk(a, b, path):
+        if type(a) is not type(b):
+            return f"{path}: type {type(a).__name__} vs {type(b).__name__}"
+        if isinstance(a, dict):
+            if a.keys() != b.keys():
+                return f"{path}: keys {sorted(map(repr, a.keys() ^ b.keys()))} on one side only"
+            for k in a:
+                d = walk(a[k], b[k], f"{path}[{k!r}]")
+                if d:
+                    return d
+            return None
+        if isinstance(a, (list, tuple)):
+            if len(a) != len(b):
+                return f"{path}: length {len(a)} vs {len(b)}"
+            for i, (u, v) in enumerate(zip(a, b)):
+                d = walk(u, v, f"{path}[{i}]")
+                if d:
+                    return d
+            return None
+        if torch.is_tensor(a):
+            if a.shape != b.shape:
+                return f"{path}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+            if not torch.allclose(a.float(), b.float().to(a.device), rtol=rtol, atol=atol, equal_nan=True):
+                return f"{path}: max |diff| {(a.float() - b.float().to(a.device)).abs().max().item():.3g}"
+            return None
+        if isinstance(a, float):
+            return None if math.isclose(a, b, rel_tol=rtol, abs_tol=atol) else f"{path}: {a} vs {b}"
+        return None if a == b else f"{path}: {a!r} vs {b!r}"
+    diff = walk(cache1, cache2, "cache")
+    if diff and verbose:
+        print("compare_caches:", diff)
+    return diff is None
 
 
 class MPFourier(nn.Module):

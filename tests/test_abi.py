@@ -141,3 +141,66 @@ def test_optimizer_and_prelude_have_no_cpu_arithmetic_in_the_product():
         "try:\n    ops._prelude_ref('batched_gates'); print('HAS_REF')\nexcept RuntimeError as e:\n    print('NOREF')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "REFUSED True" in out.stdout and "NOREF" in out.stdout, out.stdout + out.stderr
+
+
+def test_edm2_shim_leaves_the_references_other_modules_importable(tmp_path):
+    """gym_train.py:18-23 imports edm2.plotting / edm2.vae / edm2.gym_dataloader / edm2.phema next to the accelerated modules.
+    With this repository FIRST on the path its `edm2` package must not hide the rest of the reference's `edm2` directory
+    (a namespace package): checked with a stand-in directory, in a fresh interpreter."""
+    import subprocess, sys
+    ref = tmp_path / "refcheckout" / "edm2"
+    (ref / "vae").mkdir(parents=True)
+    (ref / "plotting.py").write_text("from edm2.sampler import edm_sampler_with_mse\nMARK = 'reference plotting'\n")
+    (ref / "vae" / "__init__.py").write_text("VAE = 'reference vae'\n")
+    (ref / "conv.py").write_text("raise RuntimeError('the reference conv.py must not be imported')\n")
+    code = ("import sys; sys.path[:0] = [%r, %r]\n"
+            "import edm2, edm2.plotting\n"
+            "from edm2.vae import VAE\n"
+            "from edm2.conv import MPConv\n"
+            "from edm2.networks_edm2 import UNet\n"
+            "print(edm2.plotting.MARK, '|', VAE, '|', MPConv.__module__, '|', edm2.plotting.edm_sampler_with_mse.__module__)\n"
+            % (ROOT, str(tmp_path / "refcheckout")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "reference plotting | reference vae | autoregressive_diffusion_amd.edm2.conv | autoregressive_diffusion_amd.edm2.sampler" in out.stdout, out.stdout + out.stderr
+
+
+def test_edm2_utils_public_names():
+    """The reference's public `edm2.utils` names (utils.py:13-235) exist with the same meaning: the reference's VAE and
+    training scripts import bmult / GaussianLoss from here (vae/vae.py:13, cs_vae_train.py:19).  Compared with the formulas."""
+    import autoregressive_diffusion_amd  # noqa: F401
+    from edm2 import utils as U
+    for name in ("BetterModule", "normalize", "resample", "mp_silu", "mp_sum", "mp_cat", "MPFourier", "bmult", "nan_hook",
+                 "nan_inspector", "GaussianLoss", "compare_caches"):
+        assert hasattr(U, name), name
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 4, 6, 6, generator=g)
+    assert torch.allclose(U.bmult(x, torch.tensor(2.0)), 2 * x)
+    t1, t2 = torch.rand(3, generator=g), torch.rand(3, 4, generator=g)
+    assert torch.allclose(U.bmult(x, t1), x * t1[:, None, None, None]) and torch.allclose(U.bmult(x, t2), x * t2[:, :, None, None])
+    y = torch.randn(3, 4, 6, 6, generator=g)
+    assert torch.allclose(U.mp_sum(x, y, 0.3), (0.7 * x + 0.3 * y) / np.sqrt(0.7 ** 2 + 0.3 ** 2), atol=1e-6)
+    assert torch.allclose(U.mp_sum(x, y, t1), (x + (y - x) * t1[:, None, None, None]) / torch.sqrt((1 - t1) ** 2 + t1 ** 2)[:, None, None, None], atol=1e-6)
+    b = torch.randn(3, 2, 6, 6, generator=g)
+    c = U.mp_cat(x, b, dim=1, t=0.5)
+    assert c.shape == (3, 6, 6, 6) and torch.allclose(c[:, :4], x * np.sqrt(6 / 0.5) / np.sqrt(4) * 0.5, atol=1e-6)
+    assert torch.allclose(U.resample(x, mode="down"), x.reshape(3, 4, 3, 2, 3, 2).mean(dim=(3, 5)), atol=1e-6)
+    up = U.resample(x, mode="up")
+    assert up.shape == (3, 4, 12, 12) and torch.equal(up[:, :, ::2, ::2], x) and torch.equal(up[:, :, 1::2, 1::2], x)
+    assert U.resample(x, mode="keep") is x
+    m, lv = torch.randn(5, 7, generator=g), torch.randn(5, 7, generator=g)
+    tgt = torch.randn(5, 7, generator=g)
+    assert torch.allclose(U.GaussianLoss(m, lv, tgt), ((lv + (m - tgt) ** 2 * torch.exp(-lv)) * 0.5 + 0.918).mean())
+    c1 = {"a": {"x": torch.ones(2), "n": 3}, "b": [torch.zeros(1), 0.5]}
+    c2 = {"a": {"x": torch.ones(2), "n": 3}, "b": [torch.zeros(1), 0.5]}
+    assert U.compare_caches(c1, c2, verbose=False)
+    c2["a"]["x"] = torch.ones(2) * 1.1
+    assert not U.compare_caches(c1, c2, verbose=False)
+    lin = torch.nn.Sequential(torch.nn.Linear(2, 2))
+    with U.nan_inspector(lin):
+        lin(torch.zeros(1, 2))
+        try:
+            lin(torch.full((1, 2), float("nan")))
+            raise AssertionError("nan_inspector did not fire")
+        except Exception as e:
+            assert "NaN detected" in str(e)
+    assert len(lin[0]._forward_hooks) == 0
