@@ -818,3 +818,66 @@ def test_kept_context_product_follows_cache_and_weights():
         d_kept = net(x2, s2, l1, cache=c2)[0]
         d_fresh = net(x2, s2, l1, cache=fork(c2))[0]
         assert torch.equal(d_kept, d_fresh)
+
+
+def test_reference_training_loop_shape(tmp_path):
+    """The body of gym_train.py's loop (:94-141) with the calls it makes, unmodified in kind: torch.optim.AdamW over
+    precond.parameters(), loss.backward() on every micro-step with `just_2d = i % 4 == 0`, clip_grad_norm_ + step + zero_grad on
+    every second one (accumulation_steps = 2, :57), an EMA tracker of the phema.py:88-108 form (deep copies of the net, lerp_ on
+    their parameters), the learning-rate schedule through param_groups, noise_weight.fit_loss_curve(), save_to_state_dict /
+    from_pretrained, and the sampler call of the dashboard (plotting.py:131: guidance = 2).  Must run, stay finite, reduce the
+    loss on a fixed batch, and agree with the fused optimizer path (FlatAdamW over the same parameters) step for step."""
+    import copy
+    from edm2.loss import EDM2Loss, learning_rate_schedule
+    from edm2.networks_edm2 import UNet
+    from edm2.sampler import edm_sampler_with_mse
+    from autoregressive_diffusion_amd.parallel import FlatParams, FlatAdamW
+    g = torch.Generator().manual_seed(83)
+    latents = torch.randn(2, 4, 4, 32, 32, generator=g).to(DEV)
+    actions = torch.randint(0, 4, (2, 4), generator=g).to(DEV)
+    precond = build_precond(SMALL_CFG, 61, 1.0).train()
+    twin = copy.deepcopy(precond)
+    loss_fn = EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5)
+    optimizer = torch.optim.AdamW(precond.parameters(), lr=1e-2, eps=1e-8)
+    optimizer.zero_grad()
+    emas = [copy.deepcopy(precond) for _ in (0.05, 0.10)]
+    flat = FlatParams(twin)
+    fopt = FlatAdamW(flat, lr=1e-2, eps=1e-8, weight_decay=0.01)       # torch.optim.AdamW's default weight decay
+    losses, lr = [], 1e-2
+    for i in range(1, 9):
+        torch.manual_seed(100 + i)                                     # the loss draws sigma and the noise: same draw on both nets
+        loss, un_weighted = loss_fn(precond, latents, actions, just_2d=(i % 4 == 0))
+        losses.append(float(un_weighted))
+        loss.backward()
+        torch.manual_seed(100 + i)
+        loss2, _ = loss_fn(twin, latents, actions, just_2d=(i % 4 == 0))
+        loss2.backward()
+        if i % 2 == 0:
+            torch.nn.utils.clip_grad_norm_(precond.parameters(), 0.1)
+            optimizer.step()
+            optimizer.zero_grad()
+            with torch.no_grad():
+                for beta, ema in zip((0.9, 0.95), emas):
+                    for p_net, p_ema in zip(precond.parameters(), ema.parameters()):
+                        p_ema.lerp_(p_net, 1 - beta)
+            lr = learning_rate_schedule(i, 1e-2, 4, 4)
+            for grp in optimizer.param_groups:
+                grp["lr"] = lr
+            fopt.step(max_norm=0.1)
+            fopt.zero_grad()
+            fopt.param_groups[0]["lr"] = lr
+    assert all(np.isfinite(losses)), losses
+    worst = max(rel(a, b) for (n, a), (_, b) in zip(precond.named_parameters(), twin.named_parameters()) if a.numel() > 64)
+    print("gym_train.py loop shape: un-weighted losses", [round(v, 4) for v in losses], "| torch AdamW vs fused optimizer, worst parameter rel L2", worst)
+    assert worst < 2e-3          # same gradients (bit for bit), two implementations of clip + AdamW in fp32
+    precond.noise_weight.fit_loss_curve()
+    path = str(tmp_path / "unet.pt")
+    precond.unet.save_to_state_dict(path)
+    back = UNet.from_pretrained(path).to(DEV)
+    assert all(torch.equal(a, b) for a, b in zip(back.state_dict().values(), precond.unet.state_dict().values()))
+    precond.eval()
+    with torch.no_grad():
+        _, cache = precond(latents[:1, :3], torch.full((1, 3), 0.05, device=DEV), actions[:1, :3], update_cache=True)
+        x, _, _, cache = edm_sampler_with_mse(precond, cache, conditioning=actions[:1, 3:4], num_steps=4, sigma_min=0.4, sigma_max=80,
+                                              rho=7, guidance=2)
+    assert x.shape[1:] == (1, 4, 32, 32) and bool(torch.isfinite(x).all()) and bool(torch.isfinite(emas[0].unet.out_gain))
