@@ -159,8 +159,61 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
-        for p, _ in self._lazy:
-            p.grad = None
+        self._foreign = False
+        lazy = {id(p) for p, _ in self._lazy}
+        for p, o in zip(self.params, self.offsets):        # (re-alias whatever a foreign optimizer's zero_grad released)
+            if id(p) in lazy:
+                p.grad = None
+            elif p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    # ---- gradients released by somebody else: `torch.optim.AdamW(...).zero_grad()` (set_to_none=True is torch's default) is what
+    # the reference's loops call (gym_train.py:72,108, cs_train.py:77,121).  It sets every .grad to None -- also the permanent views
+    # into the flat gradient buffer -- and does NOT clear the buffer.  The next backward then creates fresh gradient tensors
+    # outside the buffer (autograd for its own parameters, WeightBank._ensure for the kernel-owned weights).  OnirisDDP notices
+    # (foreign_zero_grad), clears the buffer once per cycle (begin_foreign_cycle), and moves the fresh gradients into their
+    # slices before a slice is exchanged (adopt); parameters that received nothing keep .grad = None, so that the foreign
+    # optimizer skips them exactly as it would without this class.
+    def foreign_zero_grad(self):
+        lazy = getattr(self, "_lazy_ids", None)
+        if lazy is None or len(lazy) != len(self._lazy):
+            lazy = self._lazy_ids = {id(p) for p, _ in self._lazy}
+        seen = False
+        for p in self.params:
+            if id(p) in lazy or id(p) in self._direct:
+                continue
+            if p.grad is not None:
+                return False
+            seen = True
+        return seen
+
+    def begin_foreign_cycle(self):
+        self.grad.zero_()
+        self._foreign = True
+
+    def adopt(self, lo=None, hi=None):
+        """Foreign cycle only: the gradients that live outside the flat buffer move into their slices of [lo, hi) (everything by
+        default) and .grad is re-aliased; a parameter without a gradient keeps None (its slice is zero)."""
+        if not getattr(self, "_foreign", False):
+            return
+        lazy = self._lazy_ids if getattr(self, "_lazy_ids", None) is not None else {id(p) for p, _ in self._lazy}
+        base = self.grad.data_ptr()
+        src, dst = [], []
+        for p, o in zip(self.params, self.offsets):
+            if (lo is not None and o < lo) or (hi is not None and o >= hi) or id(p) in lazy:
+                continue                                   # (lazy parameters: gather() below, same rule)
+            view = self.grad[o:o + p.numel()].view_as(p)
+            g = p.grad
+            if g is None:
+                if id(p) in self._direct:                  # a fused backward kernel added into the slice itself
+                    p.grad = view
+                continue
+            if g.data_ptr() != base + 4 * o:
+                src.append(g); dst.append(view)
+                p.grad = view
+        if src:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, src)
 
     def offset_of(self, param):
         if not hasattr(self, "_off_by_id"):
@@ -175,12 +228,14 @@ class FlatParams:
     def gather(self):
         """Add the autograd-owned gradients into their flat slices (one multi-tensor add) and re-alias .grad."""
         src, dst = [], []
+        foreign = getattr(self, "_foreign", False)
         for p, view in self._lazy:
             g = p.grad
             if g is not None and g.data_ptr() != view.data_ptr():
                 src.append(g.reshape(view.shape)); dst.append(view)
                 self._got.add(id(p))
-            p.grad = view
+            if g is not None or not foreign:               # (foreign optimizer: None stays None -- "no gradient, skip me")
+                p.grad = view
         if src:
             with torch.no_grad():
                 torch._foreach_add_(dst, src)
@@ -237,11 +292,21 @@ class OnirisDDP(nn.Module):
                             average is rounded once per element)."""
 
     def __init__(self, module, process_group=None, bucket_mb=256, flat=None, exchange=None, grad_dtype=None,
-                 force_collectives=False):
-        """force_collectives: issue the collectives in a one-rank group too (tests / profiling of the exchange path)."""
+                 force_collectives=False, auto_wait=True, device_ids=None, output_device=None, find_unused_parameters=None,
+                 broadcast_buffers=None, gradient_as_bucket_view=None, static_graph=None):
+        """force_collectives: issue the collectives in a one-rank group too (tests / profiling of the exchange path).
+        auto_wait: the end of every synced backward also orders the current stream behind the exchange (a stream-side wait,
+        the host does not block), so `optimizer.step()` may follow `loss.backward()` directly, as in the reference's loops;
+        False: the caller places `wait()` itself (bench.py brackets it with events).
+        device_ids / output_device / find_unused_parameters / broadcast_buffers / gradient_as_bucket_view / static_graph:
+        torch.nn.parallel.DistributedDataParallel's keyword arguments, accepted so that `DDP(unet, device_ids=[local_rank],
+        output_device=local_rank, find_unused_parameters=True)` (cs_train.py:53-54) works with `DDP = OnirisDDP`; none of them
+        changes anything here (one device per process; parameters without a gradient are always allowed; buffers are
+        broadcast once at construction)."""
         super().__init__()
         import os
         self.module = module
+        self.auto_wait = bool(auto_wait)
         self.force_collectives = bool(force_collectives)
         self.process_group = process_group
         self.flat = flat if flat is not None else FlatParams(module)
@@ -306,6 +371,11 @@ class OnirisDDP(nn.Module):
             return getattr(self.module, name)
 
     def forward(self, *args, **kwargs):
+        if torch.is_grad_enabled() and self.flat.foreign_zero_grad():
+            if self.exchange == "mesh":
+                raise RuntimeError("OnirisDDP(exchange='mesh') shards the optimizer: it needs FlatAdamW (and its zero_grad()), "
+                                   "not a torch.optim optimizer -- use the default exchange='allreduce' with torch.optim")
+            self.flat.begin_foreign_cycle()
         out = self.module(*args, **kwargs)
         if torch.is_grad_enabled() and self._sync_enabled:
             first = out[0] if isinstance(out, (tuple, list)) else out
@@ -338,6 +408,7 @@ class OnirisDDP(nn.Module):
                 for j in range(i + 1):
                     if not self._sent[j]:
                         _, lo, hi = self.flat.stages[j]
+                        self.flat.adopt(lo, hi)
                         self._exchange(lo, hi)
                         self._sent[j] = True
             return None
@@ -351,6 +422,8 @@ class OnirisDDP(nn.Module):
         if not self._sync_enabled:
             return
         self.allreduce_grads()                           # (finalises weight gradients + gathers the small ones first)
+        if self.auto_wait:
+            self.wait()
 
     def _exchange(self, lo, hi):
         if hi <= lo:
@@ -416,6 +489,7 @@ class OnirisDDP(nn.Module):
         bank = self.module.__dict__.get("_oniris_bank")
         if bank is not None:
             bank._finish()                               # no-op unless a backward left it pending
+        self.flat.adopt()                                # (gradients a foreign zero_grad pushed outside the buffer)
         self.flat.gather()
         sent, self._sent = self._sent, [False] * len(self.flat.stages)
         if not self._active():

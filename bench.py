@@ -281,7 +281,7 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
     flat = FlatParams(unet, lazy_small=True)
     # exchange form / transport: ONIRIS_DDP_EXCHANGE=allreduce|mesh, ONIRIS_DDP_BF16=1 (parallel.OnirisDDP; default: fp32 all-reduce per stage)
     wd.beat("OnirisDDP construction (parameter / buffer broadcast)")
-    model = OnirisDDP(unet, flat=flat, force_collectives=force_dist) if multi else unet
+    model = OnirisDDP(unet, flat=flat, force_collectives=force_dist, auto_wait=False) if multi else unet      # (wait() is placed and timed below)
     net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
     opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
     # optimizer side as in the reference loops: clip_grad_norm_(0.1) (gym_train.py:105 only) + AdamW +

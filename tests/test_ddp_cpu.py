@@ -51,7 +51,7 @@ def _worker(rank, world, port, q, staged=False):
     from autoregressive_diffusion_amd.parallel import OnirisDDP, FlatAdamW
     torch.manual_seed(100 + rank)               # different init per rank: the wrapper must broadcast rank 0's
     net = StagedNet() if staged else Net()
-    ddp = OnirisDDP(net, bucket_mb=1e-4)        # tiny buckets -> several all-reduces
+    ddp = OnirisDDP(net, bucket_mb=1e-4, auto_wait=False)        # tiny buckets -> several all-reduces; wait() placed below
     assert ddp.flat.check()
     if staged:                                  # b's parameters sit at the end of the flat buffers
         assert ddp.flat.stage_at == "hidden" and 0 < ddp.flat.tail_start < ddp.flat.numel
@@ -576,7 +576,7 @@ def _real_tree_worker(rank, world, port, q, exchange, bf16, mismatch):
     torch.set_num_threads(3)                             # (two ranks share the container's 8 cores)
     unet = _build_gym_unet(400 + rank)                   # different init per rank: construction broadcasts rank 0's
     flat = FlatParams(unet, lazy_small=True)             # (bench.py's construction)
-    ddp = OnirisDDP(unet, flat=flat, exchange=exchange, grad_dtype=torch.bfloat16 if bf16 else None)
+    ddp = OnirisDDP(unet, flat=flat, exchange=exchange, grad_dtype=torch.bfloat16 if bf16 else None, auto_wait=False)
     opt = FlatAdamW(flat, lr=1e-3, weight_decay=0.01)
     ema = FlatEMA(flat, stds=(0.05,))
     keys = [k for k, _, _ in flat.stages]
@@ -657,3 +657,64 @@ def _real_tree_reference(p0, bf16):
 def test_real_unet_ranks_running_different_step_kinds_are_detected():
     res = _run2(_real_tree_worker, "allreduce", False, True)
     assert sorted(r[1] for r in res) == ["raised", "raised"], [r[1] for r in res]
+
+
+def _torch_optimizer_worker(rank, world, port, q, staged):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from autoregressive_diffusion_amd.parallel import OnirisDDP as DDP
+    import contextlib
+    torch.manual_seed(400 + rank)
+    net = MultiStageNet() if staged else Net()
+    # cs_train.py:53-54, with the one changed line `DDP = OnirisDDP`
+    ddp = DDP(net, device_ids=[0], output_device=0, find_unused_parameters=True, bucket_mb=1e-4)
+    optimizer = torch.optim.AdamW(ddp.parameters(), lr=1e-2, eps=1e-4)       # cs_train.py:76: a plain torch optimizer
+    optimizer.zero_grad()                                                      # :77 (set_to_none=True: every .grad is gone)
+    g = torch.Generator().manual_seed(13)
+    data = torch.randn(9, 2, 5, 6, generator=g)                               # [micro-step][rank][batch][features]
+    K = 2
+    none_seen = []
+    for i in range(9):
+        out, _ = ddp(data[i, rank])
+        with (contextlib.nullcontext() if i % K == 0 else ddp.no_sync()):      # :108
+            out.pow(2).mean().backward()
+        if i % K == 0 and i != 0:                                              # :117-121: no wait() anywhere
+            torch.nn.utils.clip_grad_norm_(ddp.parameters(), 0.5)
+            none_seen.append([n for n, p in net.named_parameters() if p.grad is None])
+            optimizer.step()
+            optimizer.zero_grad()
+    q.put((rank, {k: v.detach().numpy().copy() for k, v in net.state_dict().items()}, none_seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_ddp_with_a_torch_optimizer_in_the_reference_loop(staged):
+    """cs_train.py's loop with `DDP = OnirisDDP` and NOTHING else changed: torch.optim.AdamW, its zero_grad() (set_to_none: the
+    flat gradient views are released and the next backward creates gradients outside the flat buffer), no_sync() accumulation, a
+    synced micro-step 0 that no optimizer step follows, no wait() call, clip_grad_norm_.  Ranks must stay equal and match a single
+    process that averages the two ranks' gradients; a parameter that never receives a gradient must keep .grad = None (the
+    optimizer skips it, as in the reference with find_unused_parameters=True)."""
+    res = _run2(_torch_optimizer_worker, staged)
+    (_, sd0, none0), (_, sd1, none1) = res
+    for k in sd0:
+        assert (sd0[k] == sd1[k]).all(), f"ranks diverged on {k}"
+    assert none0 == none1 and all(set(n) == {"unused.weight", "unused.bias"} for n in none0), none0
+    torch.manual_seed(400)
+    ref = MultiStageNet() if staged else Net()
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2, eps=1e-4)
+    topt.zero_grad()
+    g = torch.Generator().manual_seed(13)
+    data = torch.randn(9, 2, 5, 6, generator=g)
+    K = 2
+    # what the loop computes: micro-step 0 is exchanged (averaged) and stays; every later cycle adds its unsynced micro-step locally
+    # and is averaged at the synced one -- in total the average over ranks of everything accumulated since the last zero_grad
+    for i in range(9):
+        for r in range(2):
+            out, _ = ref(data[i, r]); (out.pow(2).mean() / 2).backward()
+        if i % K == 0 and i != 0:
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+            topt.step()
+            topt.zero_grad()
+    for k, v in ref.state_dict().items():
+        assert torch.allclose(torch.from_numpy(sd0[k]), v, atol=2e-6), (k, (torch.from_numpy(sd0[k]) - v).abs().max())

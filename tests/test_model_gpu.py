@@ -650,7 +650,7 @@ def _ddp_worker(q):
             staged = len(flat.stages)
             if mode != "plain":
                 ddp = OnirisDDP(net.unet, flat=flat, exchange="mesh" if mode.startswith("mesh") else "allreduce",
-                                grad_dtype=torch.bfloat16 if mode.endswith("bf16") else None, force_collectives=True)
+                                grad_dtype=torch.bfloat16 if mode.endswith("bf16") else None, force_collectives=True, auto_wait=False)
                 assert (getattr(flat, "_owned_ranges", None) is not None) == (ddp.exchange == "mesh")
                 net.unet = ddp
             opt = FlatAdamW(flat, lr=1e-3)
@@ -881,3 +881,75 @@ def test_reference_training_loop_shape(tmp_path):
         x, _, _, cache = edm_sampler_with_mse(precond, cache, conditioning=actions[:1, 3:4], num_steps=4, sigma_min=0.4, sigma_max=80,
                                               rho=7, guidance=2)
     assert x.shape[1:] == (1, 4, 32, 32) and bool(torch.isfinite(x).all()) and bool(torch.isfinite(emas[0].unet.out_gain))
+
+
+def _ddp_torch_optimizer_worker(q):
+    """One RCCL rank, collectives really issued: the real UNet under OnirisDDP driven by torch.optim.AdamW and ITS zero_grad()
+    (cs_train.py:53-54,76-77,105-121 with `DDP = OnirisDDP`), against the same loop without any wrapper."""
+    import os
+    import sys
+    import contextlib
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29537", RANK="0", WORLD_SIZE="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here)); sys.path.insert(0, os.path.join(here, "golden"))
+    try:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
+        dist.init_process_group("nccl", init_method="env://", device_id=dev)
+        from edm2.loss import EDM2Loss
+        from autoregressive_diffusion_amd.parallel import OnirisDDP as DDP
+        import test_model_gpu as M
+        g = torch.Generator().manual_seed(47)
+        images = torch.randn(5, 1, 4, 4, 32, 32, generator=g).to(dev)
+        labels = torch.randint(0, 4, (1, 4), generator=g).to(dev)
+        out = {}
+        for mode in ("plain", "ddp"):
+            precond = M.build_precond(M.SMALL_CFG, 67, 1.0).train()
+            unet = precond.unet
+            if mode == "ddp":
+                precond.unet = unet = DDP(unet, device_ids=[0], output_device=0, find_unused_parameters=True, force_collectives=True)
+            optimizer = torch.optim.AdamW(precond.parameters(), lr=1e-2, eps=1e-4)
+            optimizer.zero_grad()
+            loss_fn = EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1)
+            nones = []
+            for i in range(5):
+                torch.manual_seed(500 + i)
+                loss, _ = loss_fn(precond, images[i], labels, just_2d=(i % 4 == 0))
+                with (contextlib.nullcontext() if (i % 2 == 0 or mode == "plain") else unet.no_sync()):
+                    loss.backward()
+                if i % 2 == 0 and i != 0:
+                    nones.append(sorted(n for n, p in precond.named_parameters() if p.grad is None))
+                    optimizer.step()
+                    optimizer.zero_grad()
+            torch.cuda.synchronize()
+            out[mode] = ({n.replace("unet.module.", "unet."): p.detach().float().cpu().numpy().copy() for n, p in precond.named_parameters()},
+                         [[n.replace("unet.module.", "unet.") for n in ns] for ns in nones])
+        q.put(("ok", out))
+        dist.destroy_process_group()
+    except Exception:      # noqa: BLE001
+        import traceback
+        q.put(("error", traceback.format_exc()))
+
+
+def test_ddp_with_torch_optimizer_on_the_unet():
+    """A torch optimizer's zero_grad() releases the flat gradient views of OnirisDDP; the wrapper must adopt the gradients the
+    next backward creates outside its buffer (kernel-written conv weight gradients included), exchange them, and hand them back
+    through .grad -- without any wait() call by the loop.  With one rank the average is the identity: the parameters after the
+    loop equal the un-wrapped loop's, and the same parameters are left without a gradient."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_ddp_torch_optimizer_worker, args=(q,))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert res[0] == "ok", res[1]
+    (pp, pn), (dp, dn) = res[1]["plain"], res[1]["ddp"]
+    pp, dp = ({k: torch.from_numpy(v) for k, v in d.items()} for d in (pp, dp))
+    assert pn == dn, (pn, dn)
+    worst = max(rel(dp[k], pp[k]) for k in pp if pp[k].numel() > 64)
+    moved = max(rel(pp[k], build_precond(SMALL_CFG, 67, 1.0).state_dict()[k].float().cpu()) for k in list(pp)[:40] if pp[k].numel() > 64)
+    print("OnirisDDP + torch.optim.AdamW vs the un-wrapped loop: worst parameter rel L2", worst, "(the loop moved them by", moved, ")")
+    assert worst < 1e-4 and moved > 1e-3
