@@ -1277,9 +1277,6 @@ def emb_scales(emb, gpw, gains):
 # ------------------------------------------------------------------------------------------------------------------
 # attention
 
-_rope_cache = {}
-
-
 def rope_tables(inv_freq, scale_vec, n_pos, device, scale_base=64):
     """fp32 cos/sin/scale tables (n_pos, 64) built from fp16-ROUNDED angles and scales exactly like
     RotaryEmbedding.make_rotary_embedding (RoPe.py:21-32: the fp16 rounding is part of the numerical spec).
@@ -1288,9 +1285,15 @@ def rope_tables(inv_freq, scale_vec, n_pos, device, scale_base=64):
     only -- so a rollout, whose key count grows by one per generated frame, uploads nothing per frame (a host->device
     copy from pageable memory waits for everything queued on the stream: it used to stall the host once per frame and
     layer, with the previous frame's 31 evaluations still in the queue)."""
-    # (numel: a freed module's buffer address is recycled by the allocator -- a module with another head dimension must not
-    # find the tables of a dead one; equal head dimensions have equal tables, RoPe.py:10-16)
-    key = (str(device), inv_freq.data_ptr(), scale_vec.data_ptr(), scale_base, inv_freq.numel())
+    # The tables live ON the `inv_freq` tensor object (a module buffer: same object for the module's life), keyed by the
+    # in-place versions of both buffers: no global map from device addresses -- the allocator recycles a freed module's
+    # addresses, and a dictionary keyed by them handed a 16-channel module the tables of a dead 64-channel one (round 4) --
+    # and a load_state_dict() that rewrites the buffers invalidates them.
+    try:
+        _rope_cache = inv_freq.__dict__.setdefault("_oniris_rope_tables", {})
+    except AttributeError:                                         # (a tensor type without a __dict__: no caching)
+        _rope_cache = {}
+    key = (str(device), id(scale_vec), scale_base, inv_freq._version, scale_vec._version, inv_freq.numel())
     m = _rope_cache.get(key)
     if m is None or m[0] < n_pos:
         cap = max(64, 2 * n_pos, 2 * (m[0] if m is not None else 0))
