@@ -219,6 +219,11 @@ class BetterModule(nn.Module):
         caller = sys._getframe(1).f_code.co_filename.replace("\\", "/")
         if not caller.endswith("torch/nn/parallel/distributed.py"):
             raise AttributeError("_ddp_params_and_buffers_to_ignore")
+        # ... and only when this module really holds kernel-written weights: the reference's VAE is a BetterModule too
+        # (vae/vae.py:13 takes the class from here) and is an ordinary torch model that torch DDP handles fine
+        from .conv import NormalizedWeight
+        if not any(isinstance(m, NormalizedWeight) for m in self.modules()):
+            raise AttributeError("_ddp_params_and_buffers_to_ignore")
         raise RuntimeError(
             "torch.nn.parallel.DistributedDataParallel cannot reduce the gradients of this network: its weight gradients "
             "are written by a HIP kernel at the end of backward, not by autograd.  Use "
