@@ -185,21 +185,61 @@ class MPFourier(nn.Module):
         return (y.cos() * math.sqrt(2)).to(x.dtype)
 
 
+def _s3_split(url):
+    """'s3://bucket/some/key' -> ('bucket', 'some/key')."""
+    rest = url[len("s3://"):]
+    bucket, _, key = rest.partition("/")
+    if not bucket or not key:
+        raise ValueError(f"not an s3://bucket/key URL: {url!r}")
+    return bucket, key
+
+
+def _s3_client():
+    try:
+        import boto3
+    except ImportError as e:                      # (the reference imports boto3 unconditionally: utils.py:16,39)
+        raise ImportError("s3:// checkpoints need the `boto3` package (as in the reference, edm2/utils.py:16-31,39-58); "
+                          "install it or pass a local path") from e
+    return boto3.client("s3")
+
+
 class BetterModule(nn.Module):
-    """save_to_state_dict / from_pretrained with the reference's {"state_dict", "kwargs"} file format (local paths;
-    s3:// URLs need boto3 exactly like the reference and are not part of the hot path)."""
+    """save_to_state_dict / from_pretrained with the reference's {"state_dict", "kwargs"} file format (utils.py:13-72): local
+    paths, or s3://bucket/key URLs through boto3 like the reference (uploaded from a temporary file; downloads are kept under
+    /tmp/cache/autoregressive_diffusion_models/ and reused).  The reference's VAE inherits this class through the `edm2` shim
+    (vae/vae.py:13), and its scripts load both models from S3 (gym_train.py:33, generation_code.py:30,34)."""
+
+    S3_CACHE_DIR = "/tmp/cache/autoregressive_diffusion_models/"
 
     def save_to_state_dict(self, path):
         data = {"state_dict": self.state_dict(), "kwargs": self.kwargs}
-        if str(path).startswith("s3://"):
-            raise NotImplementedError("s3:// checkpoints are outside the MI355X hot path; save locally")
-        torch.save(data, path)
+        path = str(path)
+        if not path.startswith("s3://"):
+            torch.save(data, path)
+            return
+        import os
+        import tempfile
+        bucket, key = _s3_split(path)
+        client = _s3_client()
+        fd, tmp = tempfile.mkstemp(suffix=".pt")
+        os.close(fd)
+        try:
+            torch.save(data, tmp)
+            client.upload_file(tmp, bucket, key)
+        finally:
+            os.remove(tmp)
 
     @classmethod
     def from_pretrained(cls, checkpoint):
         if isinstance(checkpoint, str):
             if checkpoint.startswith("s3://"):
-                raise NotImplementedError("s3:// checkpoints are outside the MI355X hot path; download first")
+                import os
+                bucket, key = _s3_split(checkpoint)
+                os.makedirs(cls.S3_CACHE_DIR, exist_ok=True)
+                local = os.path.join(cls.S3_CACHE_DIR, os.path.basename(key))
+                if not os.path.exists(local):
+                    _s3_client().download_file(bucket, key, local)
+                checkpoint = local
             checkpoint = torch.load(checkpoint, weights_only=False)
         model = cls(**checkpoint["kwargs"])
         model.load_state_dict(checkpoint["state_dict"])

@@ -204,3 +204,42 @@ def test_edm2_utils_public_names():
         except Exception as e:
             assert "NaN detected" in str(e)
     assert len(lin[0]._forward_hooks) == 0
+
+
+def test_better_module_s3_checkpoints(tmp_path, monkeypatch):
+    """save_to_state_dict / from_pretrained accept s3://bucket/key like the reference (utils.py:15-58, through boto3;
+    generation_code.py:34 loads the UNet that way).  Checked against a stand-in boto3 whose "bucket" is a directory: upload,
+    cached download, reuse of the cached file, and the error without boto3."""
+    import sys, types, shutil
+    import pytest
+    import autoregressive_diffusion_amd  # noqa: F401
+    from edm2.utils import BetterModule
+    store, calls = tmp_path / "bucket", []
+    store.mkdir()
+
+    class Client:
+        def upload_file(self, local, bucket, key):
+            calls.append(("up", bucket, key)); dst = store / bucket / key; dst.parent.mkdir(parents=True, exist_ok=True); shutil.copy(local, dst)
+
+        def download_file(self, bucket, key, local):
+            calls.append(("down", bucket, key)); shutil.copy(store / bucket / key, local)
+    monkeypatch.setitem(sys.modules, "boto3", types.SimpleNamespace(client=lambda name: Client()))
+    monkeypatch.setattr(BetterModule, "S3_CACHE_DIR", str(tmp_path / "cache") + "/")
+
+    class Tiny(BetterModule):
+        def __init__(self, width=3):
+            super().__init__()
+            self.kwargs = dict(width=width)
+            self.lin = torch.nn.Linear(width, width)
+    m = Tiny(5)
+    m.save_to_state_dict("s3://models/saved/tiny.pt")
+    assert calls == [("up", "models", "saved/tiny.pt")] and (store / "models" / "saved" / "tiny.pt").exists()
+    back = Tiny.from_pretrained("s3://models/saved/tiny.pt")
+    again = Tiny.from_pretrained("s3://models/saved/tiny.pt")                     # second load: the cached file
+    assert calls[1:] == [("down", "models", "saved/tiny.pt")]
+    assert back.kwargs == dict(width=5) and torch.equal(back.lin.weight, m.lin.weight) and torch.equal(again.lin.bias, m.lin.bias)
+    with pytest.raises(ValueError):
+        Tiny.from_pretrained("s3://nokey")
+    monkeypatch.setitem(sys.modules, "boto3", None)                               # `import boto3` now fails
+    with pytest.raises(ImportError, match="boto3"):
+        m.save_to_state_dict("s3://models/other.pt")
