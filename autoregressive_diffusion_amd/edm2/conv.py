@@ -60,6 +60,19 @@ class NormalizedWeight(nn.Module):
         self.perm3 = False
         self.pw = None
 
+    def forward(self, gain=1):
+        """The effective weight as a tensor, for code that asks the module itself (reference conv.py:14-21: forced normalisation
+        of the stored parameter in training mode, then normalize(w) * gain / sqrt(fan_in), gradients through the second
+        normalisation).  Plain torch on whatever device the parameter lives on; the convolutions of this package never call it --
+        they read the packed bf16 copies `weights_ready` prepares for all weights in one launch."""
+        from .utils import normalize
+        w = self.weight.to(torch.float32)
+        if self.training:
+            with torch.no_grad():
+                self.weight.copy_(normalize(w))
+        fan_in = w[0].numel()
+        return normalize(w) * (gain / fan_in ** 0.5)
+
 
 class MPConv(nn.Module):
     def __init__(self, in_channels, out_channels, kernel, dilation=1):

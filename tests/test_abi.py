@@ -243,3 +243,19 @@ def test_better_module_s3_checkpoints(tmp_path, monkeypatch):
     monkeypatch.setitem(sys.modules, "boto3", None)                               # `import boto3` now fails
     with pytest.raises(ImportError, match="boto3"):
         m.save_to_state_dict("s3://models/other.pt")
+
+
+def test_normalized_weight_forward_matches_the_reference_formula():
+    """NormalizedWeight.forward(gain) (conv.py:14-21) as a tensor-returning helper: forced normalisation of the stored parameter in
+    training mode, normalize(w) * gain / sqrt(fan_in) -- against the oracle (itself pinned by fixture G2)."""
+    import autoregressive_diffusion_amd  # noqa: F401
+    from edm2.conv import NormalizedWeight
+    from oracle import oniris_oracle as O
+    torch.manual_seed(3)
+    m = NormalizedWeight(6, 4, (2, 3, 3))
+    w0 = m.weight.detach().clone()
+    e, wn = O.weight_effective(w0.clone(), 0.8, training=True)
+    assert torch.allclose(m(gain=0.8), e, atol=1e-6) and torch.allclose(m.weight.detach(), wn, atol=1e-6)
+    m.eval()
+    w1 = m.weight.detach().clone()
+    assert torch.allclose(m(), O.weight_effective(w1, 1.0, training=False)[0], atol=1e-6) and torch.equal(m.weight.detach(), w1)
