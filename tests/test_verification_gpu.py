@@ -436,3 +436,38 @@ def test_plain_conv_weight_gradient_integer_exact(N, H, cin, cout, k, dens):
     worst = ((p.grad.double().cpu() - r.grad).abs().max() / r.grad.abs().max()).item()
     print("plain conv weight gradient, integer-exact inputs", (N, H, cin, cout, k), "rel L2", e, "worst element / max", worst)
     assert e <= 2e-6 and worst <= 1e-5
+
+
+@pytest.mark.parametrize("B,P,m,nk,kind", [(1, 64, 4, 10, "decode"), (2, 64, 4, 40, "decode"), (1, 256, 2, 12, "decode"), (2, 64, 2, 6, "prefill")])
+def test_attention_eval_kernels_bf16_faithful(B, P, m, nk, kind):
+    """The sampler's attention launches on prepared q, k, v: one new frame against nk cached frames (dense; from 2048 keys on the key
+    tiles are dealt to several workgroups whose un-normalised partials are added: OnirisAttnArgs.kv_splits) and the causal prefill
+    over nk frames (infer table, attention_masking.py:56-84).  Replay as for the grid kernel: P = bf16(2^s) without a row maximum in
+    front of P V, row sum of the fp32 P."""
+    import ctypes
+    from autoregressive_diffusion_amd import ops
+    from autoregressive_diffusion_amd._lib import lib, check
+    torch.manual_seed(14 + nk)
+    C = 64 * m
+    t = 1 if kind == "decode" else nk
+    unit = lambda n: O.normalize(torch.randn(B, n * P, m, 64), dim=-1)
+    q0, k0, v0 = bfr(unit(t) * (0.125 * 1.4426950408889634)), bfr(unit(nk)), bfr(unit(nk))
+    dev = lambda z: z.reshape(B, -1, C).to(DEV, torch.bfloat16).contiguous()
+    qd, kd, vd = dev(q0), dev(k0), dev(v0)
+    out = torch.empty((B * t, P, C), dtype=torch.bfloat16, device=DEV)
+    Lq, Lk = t * P, nk * P
+    tabs = None if kind == "decode" else ops.device_tables("infer", nk, P, DEV)
+    a = ops._attn_args(qd, kd, vd, None, None, None, out, None, tabs, B, m, Lq, Lk, C, 0 if kind == "decode" else 1, P, 0)
+    if kind == "decode":
+        ops._decode_splits(a, B, m, Lq, Lk, DEV)
+        assert (a.kv_splits > 1) == (Lk >= ops.DECODE_SPLIT_MIN_KEYS)
+    check(lib.oniris_attn_fwd(ctypes.byref(a), ops._stream()), "attn_fwd")
+    seq = lambda z: z.double().reshape(B, -1, m, 64).permute(0, 2, 1, 3)
+    q, k, v = seq(q0), seq(k0), seq(v0)
+    p32 = torch.exp2(q.float() @ k.float().transpose(-1, -2))
+    if kind == "prefill":
+        p32 = p32.masked_fill(~torch.from_numpy(O.infer_allowed_tokens(nk, P)), 0.0)
+    ref = bfr(((bfr(p32).double() @ v) / p32.double().sum(-1, keepdim=True)).permute(0, 2, 1, 3).reshape(B * t, P, C).float())
+    e = sd(out, ref)
+    print("attention eval kernels bf16-faithful", (B, P, m, nk, kind), "kv_splits", int(a.kv_splits), e)
+    assert e <= TIGHT
