@@ -471,3 +471,41 @@ def test_attention_eval_kernels_bf16_faithful(B, P, m, nk, kind):
     e = sd(out, ref)
     print("attention eval kernels bf16-faithful", (B, P, m, nk, kind), "kv_splits", int(a.kv_splits), e)
     assert e <= TIGHT
+
+
+@pytest.mark.parametrize("B,T,H,m", [(2, 4, 8, 2), (1, 8, 16, 1), (1, 16, 8, 4)])
+def test_qkv_norm_rope_bf16_faithful(B, T, H, m):
+    """The pass in front of the training attention kernel: split of the qkv conv output, pixel norm per head
+    (attention_modules.py:48-49 with utils.normalize), rotary embedding with the fp16-rounded xPos tables (RoPe.py:21-32,43-68,
+    positions 0..T-1 for the clean AND the noised half), q scaled by log2(e)/8 for the kernel -- one launch; and its adjoint."""
+    import ctypes
+    from autoregressive_diffusion_amd import ops
+    from autoregressive_diffusion_amd._lib import lib, check
+    torch.manual_seed(15 + T)
+    P, C, N = H * H, 64 * m, B * 2 * T
+    c = 0.125 * 1.4426950408889634
+    inv = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    sc = (torch.arange(0, 64, 2) + 0.4 * 64) / (1.4 * 64)
+    x0 = bfr(torch.randn(N, P, 3, m, 64) * 1.5)                                 # kernel channel order (s m c)
+    qkv = x0.reshape(N, P, 3 * C).to(DEV, torch.bfloat16).contiguous()
+    q, k, v = (torch.empty((N, P, C), dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    cs_, sn_, sc_ = ops.rope_tables(inv.to(DEV), sc.to(DEV), T, DEV)
+    check(lib.oniris_qkv_norm_rope(ops._p(qkv), ops._p(q), ops._p(k), ops._p(v), ops._p(cs_), ops._p(sn_), ops._p(sc_), N * P, C, P, T,
+                                   ops._stream()), "qkv_norm_rope")
+    xr = x0.double().requires_grad_(True)
+    y = O.normalize(xr, dim=-1)                                                  # (N, P, 3, m, 64)
+    to_seq = lambda z: z.reshape(B, 2 * T, P, m, 64).permute(0, 3, 1, 2, 4)     # (B, m, 2T, P, 64)
+    qq, kk = O.rope_apply(to_seq(y[:, :, 0]), to_seq(y[:, :, 1]), inv.double(), sc.double(), True)
+    back = lambda z: z.permute(0, 2, 3, 1, 4).reshape(N, P, C)
+    rq, rk, rv = back(qq) * c, back(kk), y[:, :, 2].reshape(N, P, C)
+    e = (sd(q, bfr(rq.detach().float())), sd(k, bfr(rk.detach().float())), sd(v, bfr(rv.detach().float())))
+    # adjoint: bf16 gradients of q (w.r.t. the UNSCALED q: the attention backward hands that over), k, v -> d qkv
+    gq, gk, gv = (bfr(torch.randn(N, P, C)) for _ in range(3))
+    dqkv = torch.empty_like(qkv)
+    gqd, gkd, gvd = (z.to(DEV, torch.bfloat16) for z in (gq, gk, gv))
+    check(lib.oniris_qkv_norm_rope_bwd(ops._p(qkv), ops._p(gqd), ops._p(gkd), ops._p(gvd), ops._p(dqkv), ops._p(cs_), ops._p(sn_),
+                                       ops._p(sc_), N * P, C, P, T, ops._stream()), "qkv_norm_rope_bwd")
+    ((rq / c) * gq.double() + rk * gk.double() + rv * gv.double()).sum().backward()
+    eb = sd(dqkv.reshape(N, P, 3, m, 64), bfr(xr.grad.float()))
+    print("qkv_norm_rope bf16-faithful", (B, T, H, m), "q, k, v", e, "d qkv", eb)
+    assert max(e) <= TIGHT and eb <= TIGHT
