@@ -509,3 +509,43 @@ def test_qkv_norm_rope_bf16_faithful(B, T, H, m):
     eb = sd(dqkv.reshape(N, P, 3, m, 64), bfr(xr.grad.float()))
     print("qkv_norm_rope bf16-faithful", (B, T, H, m), "q, k, v", e, "d qkv", eb)
     assert max(e) <= TIGHT and eb <= TIGHT
+
+
+@pytest.mark.parametrize("B,T,H,m,d", [(2, 4, 8, 4, 16), (1, 8, 8, 2, 32), (1, 4, 16, 4, 8)])
+def test_qkv_norm_hd_bf16_faithful(B, T, H, m, d):
+    """The same pass for heads of 8 / 16 / 32 channels (Block(channels_per_head=), networks_edm2.py:28; the reference's tests use
+    16): per-head norm over d channels, rotary embedding with its partner d/2 channels away, q scaled by log2(e)/sqrt(d), heads
+    zero-padded to the 64 channels the attention kernels are written for; and the adjoint, which takes dq as the 64-channel
+    kernels return it (scaled by 8: csrc/attention.hip:556) and the padded dk, dv."""
+    from autoregressive_diffusion_amd import ops
+    from autoregressive_diffusion_amd._lib import lib, check
+    torch.manual_seed(16 + d)
+    P, N = H * H, B * 2 * T
+    c = 1.4426950408889634 / math.sqrt(d)
+    inv = 1.0 / (10000 ** (torch.arange(0, d, 2).float() / d))
+    sc = (torch.arange(0, d, 2) + 0.4 * d) / (1.4 * d)
+    x0 = bfr(torch.randn(N, P, 3, m, d) * 1.5)                                  # channel = (s*heads + head)*d + c
+    qkv = x0.reshape(N, P, 3 * m * d).to(DEV, torch.bfloat16).contiguous()
+    q, k, v = (torch.full((N, P, 64 * m), float("nan"), dtype=torch.bfloat16, device=DEV) for _ in range(3))
+    cs_, sn_, sc_ = ops.rope_tables(inv.to(DEV), sc.to(DEV), T, DEV)
+    check(lib.oniris_qkv_norm_hd(ops._p(qkv), ops._p(q), ops._p(k), ops._p(v), ops._p(cs_), ops._p(sn_), ops._p(sc_), N * P, m, d, P, T, 0, 3, T,
+                                 ops._stream()), "qkv_norm_hd")
+    xr = x0.double().requires_grad_(True)
+    y = O.normalize(xr, dim=-1)
+    to_seq = lambda z: z.reshape(B, 2 * T, P, m, d).permute(0, 3, 1, 2, 4)
+    qq, kk = O.rope_apply(to_seq(y[:, :, 0]), to_seq(y[:, :, 1]), inv.double(), sc.double(), True)
+    back = lambda z: z.permute(0, 2, 3, 1, 4).reshape(N, P, m, d)
+    rq, rk, rv = back(qq) * c, back(kk), y[:, :, 2]
+    heads = lambda z: z.float().cpu().reshape(N, P, m, 64)
+    e = [sd(heads(a)[..., :d], bfr(b.detach().float())) for a, b in ((q, rq), (k, rk), (v, rv))]
+    pad = max(float(heads(a)[..., d:].abs().max()) for a in (q, k, v))
+    gq, gk, gv = (bfr(torch.randn(N, P, m, 64)) for _ in range(3))
+    gqd, gkd, gvd = (z.reshape(N, P, 64 * m).to(DEV, torch.bfloat16) for z in (gq, gk, gv))
+    dqkv = torch.empty_like(qkv)
+    check(lib.oniris_qkv_norm_hd_bwd(ops._p(qkv), ops._p(gqd), ops._p(gkd), ops._p(gvd), ops._p(dqkv), ops._p(cs_), ops._p(sn_), ops._p(sc_),
+                                     N * P, m, d, P, T, 0, 3, T, ops._stream()), "qkv_norm_hd_bwd")
+    c64 = 0.125 * 1.4426950408889634
+    ((rq / c64) * gq[..., :d].double() + rk * gk[..., :d].double() + rv * gv[..., :d].double()).sum().backward()
+    eb = sd(dqkv.reshape(N, P, 3, m, d), bfr(xr.grad.float()))
+    print("qkv_norm_hd bf16-faithful", (B, T, H, m, d), "q, k, v", e, "padding max", pad, "d qkv", eb)
+    assert max(e) <= TIGHT and pad == 0.0 and eb <= TIGHT
