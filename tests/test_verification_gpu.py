@@ -549,3 +549,29 @@ def test_qkv_norm_hd_bf16_faithful(B, T, H, m, d):
     eb = sd(dqkv.reshape(N, P, 3, m, d), bfr(xr.grad.float()))
     print("qkv_norm_hd bf16-faithful", (B, T, H, m, d), "q, k, v", e, "padding max", pad, "d qkv", eb)
     assert max(e) <= TIGHT and pad == 0.0 and eb <= TIGHT
+
+
+@pytest.mark.parametrize("N,H,cin,cout,k,clip", [(9, 32, 128, 128, 1, 1.0), (6, 16, 256, 256, 1, 0.0), (8, 32, 64, 64, 3, 1.5), (130, 8, 64, 96, 1, 2.0)])
+def test_plain_conv_mpsum_bf16_faithful(N, H, cin, cout, k, clip):
+    """MPConv with the fused mp_sum (+ clip) epilogue -- the attention projection (attention_modules.py:43,77 + networks_edm2.py
+    clip) and conv_res1 of the 2-D steps -- forward, and backward through oniris_mpsum_bwd (both gradients stored in bf16) +
+    the data gradient of the ROUNDED dout."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(17 + cin + k)
+    p = torch.nn.Parameter(torch.randn(cout, cin, k, k).to(DEV))
+    bank, (pw,) = make_bank([p])
+    bank.prepare(training=True)
+    w = packed_weight(pw, cout, cin, (k, k)).double()
+    x0, r0, g0 = bfr(torch.randn(N, cin, H, H)), bfr(torch.randn(N, cout, H, H)), bfr(torch.randn(N, cout, H, H))
+    x, res = nhwc(x0).requires_grad_(True), nhwc(r0).requires_grad_(True)
+    ta, tb = 0.7 / math.sqrt(0.58), 0.3 / math.sqrt(0.58)
+    y = ops.conv(x, pw, res=res, ta=ta, tb=tb, clip=clip)
+    y.backward(nhwc(g0))
+    v = ta * r0.double() + tb * F.conv2d(x0.double(), w, padding=k // 2)
+    out = bfr((v.clamp(-clip, clip) if clip > 0 else v).float())
+    mask = (out.double().abs() < clip).double() if clip > 0 else torch.ones_like(v)
+    dout = bfr((tb * g0.double() * mask).float()).double()
+    e = dict(y=sd(nchw(y)[:, :cout], out), dres=sd(nchw(res.grad), bfr((ta * g0.double() * mask).float())),
+             dx=sd(nchw(x.grad), bfr(F.conv_transpose2d(dout, w, padding=k // 2).float())))
+    print("plain conv + mp_sum bf16-faithful", (N, H, cin, cout, k, clip), e, "clipped fraction", 1 - mask.mean().item())
+    assert max(e.values()) <= TIGHT
