@@ -159,13 +159,14 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
-        self._foreign = False
-        lazy = {id(p) for p, _ in self._lazy}
-        for p, o in zip(self.params, self.offsets):        # (re-alias whatever a foreign optimizer's zero_grad released)
-            if id(p) in lazy:
-                p.grad = None
-            elif p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
-                p.grad = self.grad[o:o + p.numel()].view_as(p)
+        for p, _ in self._lazy:
+            p.grad = None
+        if getattr(self, "_foreign", False):               # a foreign optimizer's zero_grad released views at some point: re-alias
+            self._foreign = False
+            lazy = {id(p) for p, _ in self._lazy}
+            for p, o in zip(self.params, self.offsets):
+                if id(p) not in lazy and (p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o):
+                    p.grad = self.grad[o:o + p.numel()].view_as(p)
 
     # ---- gradients released by somebody else: `torch.optim.AdamW(...).zero_grad()` (set_to_none=True is torch's default) is what
     # the reference's loops call (gym_train.py:72,108, cs_train.py:77,121).  It sets every .grad to None -- also the permanent views
