@@ -562,7 +562,7 @@ def main():
     ap.add_argument("--gen-frames", type=int, default=8)
     ap.add_argument("--ctx-frames", type=int, default=8, help="rollout: frames of the prefill (+ 2 warm-up frames) before the timed ones")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--watchdog", type=float, default=120.0,
+    ap.add_argument("--watchdog", type=float, default=300.0,
                     help="multi-rank runs: seconds without progress after which a rank exits 124 naming its stage (0 = off)")
     ap.add_argument("--accum", type=int, default=1,
                     help="gradient accumulation as in the reference loops (gym_train.py:96-112, cs_train.py:105-127): the optimizer "
