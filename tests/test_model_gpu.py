@@ -881,6 +881,22 @@ def test_reference_training_loop_shape(tmp_path):
         x, _, _, cache = edm_sampler_with_mse(precond, cache, conditioning=actions[:1, 3:4], num_steps=4, sigma_min=0.4, sigma_max=80,
                                               rho=7, guidance=2)
     assert x.shape[1:] == (1, 4, 32, 32) and bool(torch.isfinite(x).all()) and bool(torch.isfinite(emas[0].unet.out_gain))
+    # phema.py:95 deep-copies the net -- here one that has ALREADY run (packed weights, device pointer tables, caches hang off
+    # it): the copy must evaluate like the original, on its own storage
+    with torch.no_grad():
+        xin, sg = latents[:1, :2], torch.full((1, 2), 0.7, device=DEV)
+        want, _ = precond(xin, sg, actions[:1, :2])
+        late = copy.deepcopy(precond)
+        got, _ = late(xin, sg, actions[:1, :2])
+        assert torch.equal(got, want)
+        for p_net, p_ema in zip(precond.parameters(), late.parameters()):
+            assert p_net.data_ptr() != p_ema.data_ptr()
+            p_ema.lerp_(torch.randn_like(p_ema), 0.3)                      # (what an EMA update does to the copy, exaggerated)
+        moved, _ = late(xin, sg, actions[:1, :2])
+        again, _ = precond(xin, sg, actions[:1, :2])
+        assert torch.equal(again, want) and not torch.equal(moved, want)
+        emas_out, _ = emas[1].eval()(xin, sg, actions[:1, :2])            # a copy made BEFORE the first forward, lerp_-ed since
+        assert bool(torch.isfinite(emas_out).all())
 
 
 def _ddp_torch_optimizer_worker(q):
