@@ -54,7 +54,9 @@ def test_conv_plain_bf16_faithful(N, H, cin, cout, k):
                                                 (1, 4, 16, 256, 128, "mpsum"), (1, 5, 32, 96, 32, "none"),
                                                 # several tiles per persistent workgroup (1024 tiles on 256 CUs) / the streaming kernel
                                                 # over whole 16-frame segments
-                                                (6, 16, 16, 128, 128, "mpsum"), (2, 16, 64, 32, 32, "silu")])
+                                                (6, 16, 16, 128, 128, "mpsum"), (2, 16, 64, 32, 32, "silu"),
+                                                # Counter-Strike net shapes (cs_train.py:35-45: 512 channels on 8x8 and 4x4 images)
+                                                (2, 4, 4, 512, 512, "silu"), (1, 3, 8, 512, 512, "mpsum"), (1, 4, 4, 1024, 512, "none")])
 def test_gated_conv_train_forward_bf16_faithful(B, T, H, cin, cout, epi):
     """DART training layout (edm2/conv.py:59-95): own 3x3 product + the two context taps over the CLEAN frames t-2, t-1 (padding
     frames of ones, :68), gated sum in fp32, fused epilogue -- every output the launch writes."""
@@ -168,7 +170,8 @@ def test_act_bf16_faithful(N, H, C):
     assert e[0] <= TIGHT and e[1] <= 2 * TIGHT        # (silu of the ROUNDED norm or of the fp32 one: whichever the kernel does, within a flip)
 
 
-@pytest.mark.parametrize("B,T,H,cin,cout", [(2, 4, 16, 64, 64), (1, 6, 32, 32, 32), (2, 3, 8, 128, 256), (1, 5, 16, 128, 64)])
+@pytest.mark.parametrize("B,T,H,cin,cout", [(2, 4, 16, 64, 64), (1, 6, 32, 32, 32), (2, 3, 8, 128, 256), (1, 5, 16, 128, 64),
+                                            (2, 4, 4, 512, 512), (1, 3, 8, 512, 512)])
 def test_gated_conv_train_backward_bf16_faithful(B, T, H, cin, cout):
     """Data gradient and gate-coefficient gradients of the gated conv (autograd of edm2/conv.py:74-95), replayed on what the
     backward kernels read: the bf16 incoming gradient, the bf16 raw output and context product the forward stored, and the
@@ -371,7 +374,7 @@ def _ternary(shape, density, gen):
 
 @pytest.mark.parametrize("B,T,H,cin,cout,dens", [(1, 2, 8, 32, 32, 0.25), (2, 8, 64, 32, 32, 0.05), (2, 4, 16, 128, 128, 0.12),
                                                  (2, 4, 8, 256, 256, 0.2), (1, 6, 32, 64, 64, 0.08), (1, 3, 16, 96, 160, 0.15),
-                                                 (2, 16, 64, 32, 32, 0.04)])
+                                                 (2, 16, 64, 32, 32, 0.04), (2, 4, 4, 512, 512, 0.3), (1, 3, 8, 1024, 512, 0.25)])
 def test_gated_conv_weight_gradient_integer_exact(B, T, H, cin, cout, dens):
     """Weight gradient of the gated conv -- own 3x3 weight over both slots, the two context taps over the clean frames, split-K
     slabs in bf16, slab reduction + normalisation backward in weight_bwd -- on sparse ternary activations and gradients with
