@@ -19,5 +19,11 @@ int conv_dispatch_s2ctx(const OnirisConvArgs& a, hipStream_t st) {
   // 8x8 images: two whole frames per workgroup, 4 position waves x 2 channel waves (32 channels each)
   if (a.big_tile >= 3 && a.W == 8 && a.H == 8 && a.CoutP % 64 == 0 && conv_glds_ok(a, 8, 8, 64))
     return launch_conv_glds<1, 8, 8, 1, 2>(a, st);
+  // the register-staged kernels do not report clips: the flag says "assume the forward clipped" (the backward pre-pass then reads
+  // the clipped output and masks the gradient -- always correct), whatever the caller predicted about the kernel family
+  if (a.clip_flag) {
+    const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.clip_flag, 1, 1, st);
+    if (e != hipSuccess) { oniris_set_error("conv: clip_flag fill failed: %s", hipGetErrorString(e)); return ONIRIS_ELAUNCH; }
+  }
   return conv3x3_pick<2, true>(a, st);
 }

@@ -9,7 +9,7 @@ import torch
 from torch import nn
 
 from .. import ops
-from .utils import to_cl, from_cl, BF16
+from .utils import to_cl, from_cl, BF16, strip_runtime_state
 
 _tls = threading.local()
 
@@ -22,8 +22,9 @@ def _bank_of(root):
     if bank is None or bank._n_mods != len(mods) or any(m.pw is None or m.pw.param is not m._parameters["weight"] or
                                                         m.pw.bank is not bank for m in mods):
         bank = ops.WeightBank()
+        pairs = {id(w) for c in root.modules() if isinstance(c, MPCausal3DGatedConv) for w in (c.last_frame_conv.weight, c.weight)}
         for m in mods:
-            m.pw = bank.add(m.weight, perm3=m.perm3)
+            m.pw = bank.add(m.weight, perm3=m.perm3, gated_pair=id(m) in pairs)
             m.pw.bank = bank
         bank._n_mods = len(mods)
         # 1x1 weights that read the same input (UNet: the emb_linear of every Block) become one row-concatenated GEMM
@@ -59,6 +60,8 @@ class NormalizedWeight(nn.Module):
         self.weight = nn.Parameter(torch.randn(out_channels, in_channels, *kernel))
         self.perm3 = False
         self.pw = None
+
+    __getstate__ = strip_runtime_state
 
     def forward(self, gain=1):
         """The effective weight as a tensor, for code that asks the module itself (reference conv.py:14-21: forced normalisation
@@ -224,9 +227,13 @@ class MPCausal3DGatedConv(nn.Module):
         self.weight = NormalizedWeight(in_channels, out_channels, (kernel[0] - 1, kernel[1], kernel[2]))
         self.gating = Gating()
 
+    __getstate__ = strip_runtime_state
+
     def _cl(self, x, batch_size, c_noise, cache=None, update_cache=False, just_2d=False, **epi):
         """x (B*t, H, W, C) bf16 -> (y, cache).  cache['activations'] is (B, 2, H, W, C) bf16.
-        **epi: fused epilogue, either cscale=(N,Cout) fp32 [silu(y*cscale)/0.596] or res/ta/tb/clip [mp_sum+clip]."""
+        **epi: fused epilogue, either cscale=(N,Cout) fp32 [silu(y*cscale)/0.596] or res/ta/tb/clip [mp_sum+clip];
+        grad_private (training, see ops.ConvCfg): the output's gradient will be a tensor only this op's backward reads."""
+        grad_private = epi.pop("grad_private", False)
         if just_2d:
             self.__dict__.pop("_gate_pre", None)
             return ops.conv(x, self.last_frame_conv.weight.pw, **epi), cache
@@ -244,7 +251,7 @@ class MPCausal3DGatedConv(nn.Module):
         pw2, pw3 = self.last_frame_conv.weight.pw, self.weight.pw
         if self.training:
             T = N // (2 * batch_size)
-            return ops.gated_conv_train(x, gate, pw2, pw3, batch_size, T, coefs, **epi), cache
+            return ops.gated_conv_train(x, gate, pw2, pw3, batch_size, T, coefs, grad_private=grad_private, **epi), cache
         t = N // batch_size
         pad = cache.get("activations")
         had_pair = pad is not None

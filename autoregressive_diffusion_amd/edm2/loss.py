@@ -1,8 +1,8 @@
 """EDM2 loss with DART duplication (reference edm2/loss.py:9-69): builds x = cat(images, images) + sigma*eps,
 calls net(x, sigma, conditioning, just_2d=...), weights the per-frame MSE of the noised half by lambda(sigma) and
 divides by the fitted mean loss."""
+import math
 import os
-import numpy as np
 import torch
 from .. import ops
 
@@ -66,9 +66,11 @@ class EDM2Loss:
 
 
 def learning_rate_schedule(current_step, ref_lr=1e-2, ref_step=7e4, rampup_steps=1e3):
-    lr = ref_lr
-    if ref_step > 0:
-        lr /= np.sqrt(max(current_step / ref_step, 1))
-    if rampup_steps > 0:
-        lr *= min(current_step / rampup_steps, 1)
-    return lr
+    """The learning rate of optimizer step `current_step` (the schedule the reference loops call, gym_train.py:110-112,
+    cs_train.py:123-125; reference edm2/loss.py:63-69): `ref_lr`, divided by sqrt(step / ref_step) once the step count has
+    passed `ref_step`, times a linear warm-up over the first `rampup_steps` steps.  A non-positive `ref_step` /
+    `rampup_steps` switches that factor off."""
+    step = float(current_step)
+    past_ref = max(step / ref_step, 1.0) if ref_step > 0 else 1.0
+    warm_up = min(step / rampup_steps, 1.0) if rampup_steps > 0 else 1.0
+    return ref_lr / math.sqrt(past_ref) * warm_up

@@ -11,7 +11,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .loss_weight import MultiNoiseLoss
-from .utils import BetterModule, MPFourier, to_cl, from_cl, BF16
+from .utils import BetterModule, MPFourier, to_cl, from_cl, BF16, strip_runtime_state
 from .conv import MPConv, MPCausal3DGatedConv, Gating, weights_ready, batched_gates
 from .attention import FrameAttention, VideoAttention
 
@@ -36,10 +36,13 @@ class Block(nn.Module):
         else:
             self.attn = FrameAttention(out_channels, self.num_heads, attn_balance)
 
+    __getstate__ = strip_runtime_state
+
     def _cl(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False, skip=None, cat_w=None,
-            c=None, in_slot=None, skip_slot=None):
+            c=None, in_slot=None, skip_slot=None, private_out=False):
         """x (N,H,W,C) bf16, emb (N,1,1,cemb) bf16; skip/cat_w: the decoder's mp_cat operand, fused into the first
-        activation kernel.  Elementwise chains of the reference's Block.forward (:62-94) run as fused HIP kernels:
+        activation kernel.  private_out: the caller consumes the block's output through ops of this package that join all of
+        its gradients in one kernel (UNet.forward with GradSlots) -- see ops.ConvCfg.grad_private.  Elementwise chains of the reference's Block.forward (:62-94) run as fused HIP kernels:
         [mp_cat | pixel norm] + mp_silu -> act;  *c + mp_silu -> conv_res0 epilogue;  mp_sum (+clip) -> conv_res1 /
         attn_proj epilogue."""
         if cache is None:
@@ -72,7 +75,8 @@ class Block(nn.Module):
         clip = float(self.clip_act) if self.clip_act is not None else 0.0
         x, cache["conv_res1"] = self.conv_res1._cl(y, batch_size, c_noise, cache.get("conv_res1"), update_cache, just_2d,
                                                    res=x, ta=(1 - t) * den, tb=t * den,
-                                                   clip=clip if self.num_heads == 0 else 0.0)
+                                                   clip=clip if self.num_heads == 0 else 0.0,
+                                                   grad_private=private_out and self.num_heads == 0)
         if self.num_heads > 0:
             x, cache["attn"] = self.attn._cl(x, batch_size, cache.get("attn"), update_cache, just_2d, clip=clip)
         else:
@@ -157,6 +161,15 @@ class UNet(BetterModule):
     _oniris_cl_io = True        # forward(..., _cl_io=(B, tt)) takes / returns channels-last bf16 (edm2/loss.py fast path)
 
     def forward(self, x, c_noise, conditioning=None, cache=None, update_cache=False, just_2d=False, _cl_io=None):
+        inner = self._ddp_inner()          # torch DistributedDataParallel around this net (utils.BetterModule)
+        if inner is None:
+            return self._forward(x, c_noise, conditioning, cache, update_cache, just_2d, _cl_io)
+        inner.inner_pre_forward()
+        out = self._forward(x, c_noise, conditioning, cache, update_cache, just_2d, _cl_io)
+        inner.inner_post_forward(out)
+        return out
+
+    def _forward(self, x, c_noise, conditioning=None, cache=None, update_cache=False, just_2d=False, _cl_io=None):
         """_cl_io = (B, tt): `x` is already the packed UNet input (B*tt, H, W, 16) bf16 with the ones channel
         (ops.dart_input) and the raw channels-last output (B*tt, H, W, 8k) bf16 is returned WITHOUT out_gain -- the
         fused DART loss applies it (ops.dart_loss).  Default: the reference signature (:191)."""
@@ -212,7 +225,7 @@ class UNet(BetterModule):
             for name, block in self.enc.items():
                 if isinstance(block, Block):
                     xcl, cache["enc", name] = block._cl(xcl, emb, B, c_noise, cache.get(("enc", name)), update_cache, just_2d,
-                                                        c=cs[id(block)], in_slot=slot)
+                                                        c=cs[id(block)], in_slot=slot, private_out=bool(use_slots))
                 else:
                     xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
                 slot = ops.GradSlot() if use_slots else None
@@ -229,7 +242,8 @@ class UNet(BetterModule):
                     cat_w = (Cn / math.sqrt(Na) * (1 - t), Cn / math.sqrt(Nb) * t)
                 # (the last encoder output enters the decoder as its main input: `slot` is still that tensor's slot)
                 xcl, cache["dec", name] = block._cl(xcl, emb, B, c_noise, cache.get(("dec", name)), update_cache, just_2d,
-                                                    skip=skip, cat_w=cat_w, c=cs[id(block)], in_slot=slot, skip_slot=skip_slot)
+                                                    skip=skip, cat_w=cat_w, c=cs[id(block)], in_slot=slot, skip_slot=skip_slot,
+                                                    private_out=bool(use_slots))
                 slot = None
                 cb = stage_hooks.get(("dec", name))
                 if cb is not None and xcl.requires_grad:
@@ -420,7 +434,31 @@ class Precond(BetterModule):
         self.unet, self.use_fp16, self.sigma_data = unet, use_fp16, sigma_data
         self.noise_weight = MultiNoiseLoss()
 
+    _fp32_warned = False
+
+    @classmethod
+    def _warn_fp32(cls, why):
+        """The reference's `use_fp16=False` / `force_fp32=True` select fp32 arithmetic for the whole net (networks_edm2.py:285,
+        294).  Here every operand between kernels is bf16 (fp32 accumulation) whatever the switch says: say so, once."""
+        if not cls._fp32_warned:
+            cls._fp32_warned = True
+            import warnings
+            warnings.warn(f"Precond({why}): this implementation always computes with bf16 operands and fp32 accumulation "
+                          "(DESIGN.md section 3, 'Numerics'); the switch is accepted for signature compatibility and changes "
+                          "nothing.  D_x is returned in fp32 as in the reference.", RuntimeWarning, stacklevel=3)
+
     def forward(self, x, sigma, conditioning=None, force_fp32=False, cache=None, update_cache=False, just_2d=False):
+        inner = self._ddp_inner()          # torch DistributedDataParallel around the Precond itself
+        if inner is None:
+            return self._forward(x, sigma, conditioning, force_fp32, cache, update_cache, just_2d)
+        inner.inner_pre_forward()
+        out = self._forward(x, sigma, conditioning, force_fp32, cache, update_cache, just_2d)
+        inner.inner_post_forward(out)
+        return out
+
+    def _forward(self, x, sigma, conditioning=None, force_fp32=False, cache=None, update_cache=False, just_2d=False):
+        if force_fp32 or not self.use_fp16:
+            self._warn_fp32("force_fp32=True" if force_fp32 else "use_fp16=False")
         if cache is None:
             cache = {}
         cache["shape"] = x.shape

@@ -174,6 +174,19 @@ def compare_caches(cache1, cache2, rtol=1e-4, atol=1e-4, verbose=True):
     return diff is None
 
 
+def strip_runtime_state(self):
+    """`__getstate__` of this package's modules (copy.deepcopy / pickle): what the package attached at run time -- handles into
+    the weight bank (`pw`), cached plans and packs (`_oniris_*`), a pending batched gate (`_gate_pre`) -- stays behind; the
+    copy rebuilds it at its first forward.  (The EMA trackers of the reference loops deep-copy the whole net, phema.py:95:
+    without this every copy carried its own packed weights and ~6 GB of split-K slabs.)"""
+    state = self.__dict__.copy()
+    for k in [k for k in state if k.startswith("_oniris_") or k == "_gate_pre"]:
+        del state[k]
+    if "pw" in state:
+        state["pw"] = None
+    return state
+
+
 class MPFourier(nn.Module):
     def __init__(self, num_channels, bandwidth=1):
         super().__init__()
@@ -240,7 +253,9 @@ class BetterModule(nn.Module):
                 if not os.path.exists(local):
                     _s3_client().download_file(bucket, key, local)
                 checkpoint = local
-            checkpoint = torch.load(checkpoint, weights_only=False)
+            # {"state_dict": tensors, "kwargs": plain constructor arguments}: nothing in the format needs the pickle machinery
+            # (the reference loads with weights_only=False, utils.py:59 -- arbitrary code execution from a downloaded file)
+            checkpoint = torch.load(checkpoint, weights_only=True)
         model = cls(**checkpoint["kwargs"])
         model.load_state_dict(checkpoint["state_dict"])
         return model
@@ -248,26 +263,71 @@ class BetterModule(nn.Module):
     @property
     def _ddp_params_and_buffers_to_ignore(self):
         """torch.nn.parallel.DistributedDataParallel reads exactly this attribute of the module it is handed (its
-        constructor; nothing else does) -- the one place where wrapping can be noticed.  torch's reducer learns about a
-        gradient from the parameter's AccumulateGrad node; the conv / attention weight gradients of this net are written
-        into `.grad` through raw pointers by ONE kernel after the backward pass (weights.hip: weight_bwd_kernel), so torch
-        DDP would wait for them forever or, worse, exchange stale buffers.  Refuse loudly (cs_train.py:53-54 becomes
-        `OnirisDDP(unet)`: same `.module`, `no_sync()`, broadcast at construction).
+        constructor, torch/nn/parallel/distributed.py: `parameters_to_ignore`; nothing else does) -- the one place where
+        `DDP(unet, device_ids=[local_rank], output_device=local_rank, find_unused_parameters=True)` (cs_train.py:53-54) can
+        be noticed.  torch's reducer learns about a gradient from the parameter's AccumulateGrad node; the conv / attention
+        / embedding weight gradients of this net are written into `.grad` through raw pointers by ONE kernel after the
+        backward pass (weights.hip: weight_bwd_kernel), so the reducer would never see them.  The two kinds of parameters
+        are therefore split:
+          * the kernel-owned weights (every NormalizedWeight) are named here -- torch's reducer and its construction-time
+            broadcast leave them alone -- and an inner `parallel.OnirisDDP` on the SAME process group takes them: re-homed
+            in one flat buffer (broadcast from rank 0 right here), exchanged by the staged tensor hooks during backward
+            and at its end, honouring `no_sync()` through torch DDP's own `require_backward_grad_sync`;
+          * everything autograd accumulates itself (gates, emb_gain, out_gain) stays an ordinary torch parameter that
+            torch's reducer buckets and averages as for any model.
+        A torch.optim optimizer over `parameters()` works on both (OnirisDDP's foreign-optimizer cycle).
         Every OTHER reader (inspect.getmembers, hasattr, debuggers, attribute-copying wrappers) sees a plain missing
-        attribute: the error is raised only when the caller is torch's distributed.py."""
+        attribute: the split happens only when the caller is torch's distributed.py."""
         import sys
-        caller = sys._getframe(1).f_code.co_filename.replace("\\", "/")
-        if not caller.endswith("torch/nn/parallel/distributed.py"):
+        frame = sys._getframe(1)
+        if not frame.f_code.co_filename.replace("\\", "/").endswith("torch/nn/parallel/distributed.py"):
             raise AttributeError("_ddp_params_and_buffers_to_ignore")
         # ... and only when this module really holds kernel-written weights: the reference's VAE is a BetterModule too
-        # (vae/vae.py:13 takes the class from here) and is an ordinary torch model that torch DDP handles fine
+        # (vae/vae.py:13 takes the class from here) and is an ordinary torch model that torch DDP handles alone
         from .conv import NormalizedWeight
-        if not any(isinstance(m, NormalizedWeight) for m in self.modules()):
+        owned = [m.weight for m in self.modules() if isinstance(m, NormalizedWeight) and m.weight.requires_grad]
+        if not owned:
             raise AttributeError("_ddp_params_and_buffers_to_ignore")
-        raise RuntimeError(
-            "torch.nn.parallel.DistributedDataParallel cannot reduce the gradients of this network: its weight gradients "
-            "are written by a HIP kernel at the end of backward, not by autograd.  Use "
-            "autoregressive_diffusion_amd.parallel.OnirisDDP(unet) instead (same .module / no_sync() / forward).")
+        outer = frame.f_locals.get("self")
+        inner = self.__dict__.get("_oniris_inner_ddp")
+        if inner is None or isinstance(inner, str) or inner._torch_ddp is None or inner._torch_ddp() is not outer:
+            # (torch reads the attribute twice -- hasattr, then the value: built on the first read)
+            from ..parallel import FlatParams, OnirisDDP
+            try:
+                inner = OnirisDDP(self, process_group=getattr(outer, "process_group", None),
+                                  flat=FlatParams(self, only=owned), torch_ddp=outer)
+            except AttributeError as e:      # (torch asks with hasattr(): an AttributeError from in here would read as "no
+                raise RuntimeError(f"building the gradient exchange for torch DDP failed: {e!r}") from e   # such attribute")
+            self.__dict__["_oniris_inner_ddp"] = inner
+        ids = {id(p) for p in inner.flat.params}
+        return [n for n, p in self.named_parameters() if id(p) in ids]
+
+    def _ddp_inner(self):
+        """The inner OnirisDDP when torch's DistributedDataParallel wraps this module (None otherwise).  A COPY of a wrapped
+        module (copy.deepcopy: the EMA trackers of the reference loops, phema.py:95) has no exchange of its own: fine for the
+        evaluations such copies are made for, an error as soon as it is trained on more than one rank."""
+        inner = self.__dict__.get("_oniris_inner_ddp")
+        if inner is None:
+            return None
+        if isinstance(inner, str):
+            import torch.distributed as dist
+            if (torch.is_grad_enabled() and self.training and dist.is_available() and dist.is_initialized()
+                    and dist.get_world_size() > 1):
+                raise RuntimeError("this network is a copy of one that torch's DistributedDataParallel wrapped: the copy has "
+                                   "no gradient exchange for its kernel-owned weights -- wrap it in DistributedDataParallel "
+                                   "itself before training it")
+            return None
+        return inner
+
+    def __getstate__(self):
+        """copy.deepcopy / pickle: everything this package attached at run time (`_oniris_*`: weight bank with its packed
+        buffers and split-K slabs, cached plans, stage hooks, the inner DDP engine with its process group) stays behind --
+        the copy rebuilds what it needs at its first forward."""
+        lost = self.__dict__.get("_oniris_inner_ddp") is not None
+        state = strip_runtime_state(self)
+        if lost:
+            state["_oniris_inner_ddp"] = "lost"
+        return state
 
     @property
     def device(self):

@@ -137,13 +137,15 @@ class PackedWeight:
                  "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched", "embcache", "gaincache")
 
 
-def _nsplit_cap(cin, cout, taps):
+def _nsplit_cap(cin, cout, taps, gated_pair=False):
     """Upper bound of the split-K columns (= slabs) the wgrad launchers use for a weight: launch_wgrad() in
-    csrc/conv_wgrad.hip (64x64 or 32x32 output tiles) and launch_wgrad1x1_glds() (128x128 tiles, 1x1 weights)."""
+    csrc/conv_wgrad.hip (64x64 or 32x32 output tiles) and launch_wgrad1x1_glds() (128x128 tiles, 1x1 weights).
+    gated_pair: the weight is the own-frame or the context weight of an MPCausal3DGatedConv -- the only weights whose
+    gradient launch_wgrad_stream() can take."""
     tile = 2 if (cin > 32 and cout > 32) else 1
     gy = -(-roundup(cin, 16) // (32 * tile)) * -(-roundup(cout, 8) // (32 * tile))
     cap = max(1, (256 if tile == 2 else 512) // gy)
-    if tile == 1 and taps >= 9:
+    if tile == 1 and taps >= 9 and gated_pair:
         cap = 512       # launch_wgrad_stream() (csrc/conv_wgrad_stream.h): one slab per (sequence, 8x16-pixel tile, segment)
     if taps == 1 and cin >= 64 and cout >= 64:
         cap = max(cap, 256 // (-(-cin // 128) * -(-cout // 128)))
@@ -201,9 +203,10 @@ class WeightBank:
         self.total_rows = 0
         self._finish_queued = False
         self.post_backward_hooks = []      # callables run after the weight gradients are final (DDP all-reduce)
+        self._flags, self._flag_off = None, 0
         self.groups = []                   # PackedWeight views over row-concatenated 1x1 weights (add_group)
 
-    def add(self, param, perm3=False, gain=1.0, need_dgrad=True):
+    def add(self, param, perm3=False, gain=1.0, need_dgrad=True, gated_pair=False):
         w = PackedWeight()
         w.param = param
         shp = tuple(param.shape)
@@ -217,7 +220,7 @@ class WeightBank:
         w.group, w.goff, w.members = None, 0, None
         w.touched = False              # a weight-gradient launch targeted this weight since the last optimizer step
         # split-K slabs of the weight-gradient kernel: same bound as launch_wgrad() in csrc/conv_wgrad.hip
-        w.nsplit_cap = _nsplit_cap(w.cin, w.cout, w.taps)
+        w.nsplit_cap = _nsplit_cap(w.cin, w.cout, w.taps, gated_pair)
         w.bank = self
         self.items.append((w, need_dgrad))
         return w
@@ -330,6 +333,7 @@ class WeightBank:
         self._ensure()
         if training or torch.is_grad_enabled():        # (a no_grad evaluation -- the rollout -- never takes from the arena)
             self.zero_arena.reset(self.items[0][0].param.device)   # the previous step's backward is done with its accumulators
+            self._flags = None                         # (clip flags: a fresh tensor per forward, see take_flag)
             GradSlot.live = []
         global _weights_epoch
         if training:
@@ -344,6 +348,18 @@ class WeightBank:
                                      _stream()),
               "weight_prep")
         self._packed_sig = None if training else (_weights_epoch, tuple(w.param._version for w, _ in self.items))
+
+    def take_flag(self, device):
+        """One zeroed int32 for a forward launch to report into and the matching backward to read (OnirisConvArgs.clip_flag).
+        Its storage lives as long as the autograd graph that holds it (the ctx keeps the slice): every grad-enabled forward
+        starts a fresh tensor (`prepare`), so a second forward before the first one's backward -- two micro-batches summed into
+        one loss, a train-mode evaluation in between -- neither clears nor aliases the first one's flags (the
+        step's zero arena, which they came from before, is rewound and refilled by every forward)."""
+        if self._flags is None or self._flags.device != device or self._flag_off >= self._flags.numel():
+            self._flags, self._flag_off = torch.zeros(256, dtype=torch.int32, device=device), 0
+        f = self._flags[self._flag_off:self._flag_off + 1]
+        self._flag_off += 1
+        return f
 
     def packed_valid(self):
         """True while the packed EVAL weights of the last `prepare(False)` still match the parameters."""
@@ -610,11 +626,17 @@ def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb
 
 class ConvCfg:
     """Static configuration of one conv op (not a tensor: passed through autograd untouched)."""
-    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad", "in_slot", "res_slot")
+    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad", "in_slot", "res_slot", "grad_private")
 
     def __init__(self, pw2, pw3=None, B=1, T=1, epi="none", ta=0.0, tb=0.0, clip=0.0, need_grad=True, in_slot=None,
-                 res_slot=None):
+                 res_slot=None, grad_private=False):
         self.pw2, self.pw3, self.B, self.T = pw2, pw3, B, T
+        # the caller vouches that the gradient of this op's output is a tensor nobody else reads (UNet.forward with GradSlots:
+        # it comes out of the ONE backward kernel that joined the gradients of all consumers): the backward may then mask it
+        # in place instead of writing a masked copy (the clip_flag aliasing protocol below).  Anywhere else -- y.backward(g)
+        # with the caller's g, torch.autograd.grad(grad_outputs=...), a consumer whose backward hands one tensor to two
+        # inputs -- the gradient is read-only.
+        self.grad_private = bool(grad_private)
         self.epi, self.ta, self.tb, self.clip, self.need_grad = epi, ta, tb, clip, need_grad
         self.in_slot = in_slot             # GradSlot of the input (plain convs): a second gradient of x joins in the dgrad epilogue
         self.res_slot = res_slot           # GradSlot that receives the gradient of `res` (mp_sum epilogue) instead of autograd
@@ -667,9 +689,11 @@ class _ConvOp(torch.autograd.Function):
                 raw = None
             # "did the clip change anything?" -- one int of the step's pre-zeroed arena, set by the forward launch (the kernel
             # families that support it), read by the backward pre-pass: see OnirisConvArgs.clip_flag
-            if (CLIP_FLAG and keep_raw and Co <= 512 and cfg.clip > 0 and
+            # (the family test only saves arming a flag the register-staged kernels would answer with "assume clipped":
+            # conv_dispatch_s2ctx sets the flag itself when it falls back to them)
+            if (CLIP_FLAG and keep_raw and cfg.grad_private and Co <= 512 and cfg.clip > 0 and
                     _s2ctx_family(cfg.T, H, W, Cin, pw2.CinP, pw2.CoutP, cfg.T, (-2, -1), 1.0) != "staged"):
-                clip_flag = pw2.bank.zero_arena.take(1, dev).view(torch.int32)
+                clip_flag = pw2.bank.take_flag(dev)
                 kw["clip_flag"] = clip_flag
         y3 = ca32 = cb32 = None
         ctx.clip_flag = kw.get("clip_flag")
@@ -806,11 +830,12 @@ def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None, r
     return _ConvOp.apply(x, pw.param, None, None, None, cscale, res, cfg)
 
 
-def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None):
-    """Training-mode MPCausal3DGatedConv.  gate: (B*2*T,) fp32 autograd tensor, or precomputed coefs=(ca, cb)."""
+def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, grad_private=False):
+    """Training-mode MPCausal3DGatedConv.  gate: (B*2*T,) fp32 autograd tensor, or precomputed coefs=(ca, cb).
+    grad_private: see ConvCfg."""
     ca, cb = coefs if coefs is not None else gate_coefs(gate)
     epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
-    cfg = ConvCfg(pw2, pw3, B, T, epi, ta, tb, clip, torch.is_grad_enabled())
+    cfg = ConvCfg(pw2, pw3, B, T, epi, ta, tb, clip, torch.is_grad_enabled(), grad_private=grad_private)
     return _ConvOp.apply(x, pw2.param, pw3.param, ca, cb, cscale, res, cfg)
 
 

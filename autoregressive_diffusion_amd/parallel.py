@@ -46,13 +46,17 @@ class FlatParams:
     def live(cls):
         return list(cls._instances) if cls._instances is not None else []
 
-    def __init__(self, module, lazy_small=False):
-        """lazy_small: gradients of the parameters autograd itself accumulates (everything except the conv weights,
+    def __init__(self, module, lazy_small=False, only=None):
+        """only: an iterable of parameters -- re-home just these (torch's own DistributedDataParallel around the net:
+        BetterModule._ddp_params_and_buffers_to_ignore hands the kernel-owned weights to an inner OnirisDDP and leaves every
+        other parameter an ordinary torch parameter for torch's reducer).
+        lazy_small: gradients of the parameters autograd itself accumulates (everything except the conv weights,
         whose .grad the HIP weight_bwd kernel writes through a raw pointer) are NOT accumulated into their flat slice
         one tiny `add_` kernel per parameter (~190 launches per step for the gym net); their .grad is None during
         backward, so autograd just hands the tensor over, and `gather()` adds all of them into the flat buffer with one
         multi-tensor call (called by OnirisDDP at the end of backward and by FlatAdamW.step)."""
-        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        only = None if only is None else {id(p) for p in only}
+        named = [(n, p) for n, p in module.named_parameters() if p.requires_grad and (only is None or id(p) in only)]
         self.params = [p for _, p in named]
         assert self.params, "no trainable parameters"
         self.module = module
@@ -62,17 +66,21 @@ class FlatParams:
         # buffers: OnirisDDP exchanges a stage's [lo, hi) while the rest of backward is still running.  The module names
         # the stages in the order they become final: _oniris_overlap_stages() -> [(hook key, [parameters])], or the
         # one-stage form _oniris_overlap_plan() -> (hook key, [parameters]).
-        if hasattr(module, "_oniris_overlap_stages"):
-            plan = [(k, list(ps)) for k, ps in (module._oniris_overlap_stages() or []) if ps]
-        elif hasattr(module, "_oniris_overlap_plan"):
-            one = module._oniris_overlap_plan()
+        # (the module itself, or the first submodule that names stages: a Precond around the UNet)
+        self.stage_module = stager = next((m for m in module.modules() if hasattr(m, "_oniris_overlap_stages")
+                                           or hasattr(m, "_oniris_overlap_plan")), None)
+        if stager is not None and hasattr(stager, "_oniris_overlap_stages"):
+            plan = [(k, list(ps)) for k, ps in (stager._oniris_overlap_stages() or []) if ps]
+        elif stager is not None:
+            one = stager._oniris_overlap_plan()
             plan = [(one[0], list(one[1]))] if one is not None and one[1] else []
         else:
             plan = []
         # parameters that receive a gradient on the same steps sit next to each other (module hint: 0 = every step,
         # 1 = 3-D steps only, 2 = never), so that FlatAdamW -- which, like torch.optim, skips parameters without a
         # gradient -- covers the buffer with a handful of contiguous launches.  Correctness never depends on the hint.
-        cls = module._oniris_param_classes() if hasattr(module, "_oniris_param_classes") else {}
+        classer = next((m for m in module.modules() if hasattr(m, "_oniris_param_classes")), None)
+        cls = classer._oniris_param_classes() if classer is not None else {}
         by_class = lambda ps: sorted(ps, key=lambda p: cls.get(id(p), 0))          # (stable)
         mine = {id(p) for p in self.params}
         staged, segs = set(), []
@@ -190,6 +198,7 @@ class FlatParams:
 
     def begin_foreign_cycle(self):
         self.grad.zero_()
+        self._got.clear()                  # (direct packs that deliver a gradient in this cycle: ParamPack.deliver)
         self._foreign = True
 
     def adopt(self, lo=None, hi=None):
@@ -206,7 +215,9 @@ class FlatParams:
             view = self.grad[o:o + p.numel()].view_as(p)
             g = p.grad
             if g is None:
-                if id(p) in self._direct:                  # a fused backward kernel added into the slice itself
+                # a fused backward kernel added into the slice itself -- IF its pack ran a backward in this cycle (gates on a
+                # 2-D-only cycle did not: .grad stays None and the foreign optimizer skips them, as in the reference)
+                if id(p) in self._direct and id(p) in self._got:
                     p.grad = view
                 continue
             if g.data_ptr() != base + 4 * o:
@@ -294,8 +305,13 @@ class OnirisDDP(nn.Module):
 
     def __init__(self, module, process_group=None, bucket_mb=256, flat=None, exchange=None, grad_dtype=None,
                  force_collectives=False, auto_wait=True, device_ids=None, output_device=None, find_unused_parameters=None,
-                 broadcast_buffers=None, gradient_as_bucket_view=None, static_graph=None):
-        """force_collectives: issue the collectives in a one-rank group too (tests / profiling of the exchange path).
+                 broadcast_buffers=None, gradient_as_bucket_view=None, static_graph=None, torch_ddp=None):
+        """torch_ddp: the torch.nn.parallel.DistributedDataParallel instance this object works UNDER (inner mode, built by
+        BetterModule._ddp_params_and_buffers_to_ignore while torch's constructor runs): torch's reducer owns every autograd-
+        accumulated parameter, this object the kernel-owned weights in `flat`; nobody calls its forward() -- the wrapped
+        module's own forward calls inner_pre_forward() / inner_post_forward(out) -- and "are gradients exchanged in this
+        pass" is torch DDP's `require_backward_grad_sync` (its no_sync()), read at forward AND at backward time.
+        force_collectives: issue the collectives in a one-rank group too (tests / profiling of the exchange path).
         auto_wait: the end of every synced backward also orders the current stream behind the exchange (a stream-side wait,
         the host does not block), so `optimizer.step()` may follow `loss.backward()` directly, as in the reference's loops;
         False: the caller places `wait()` itself (bench.py brackets it with events).
@@ -307,6 +323,8 @@ class OnirisDDP(nn.Module):
         super().__init__()
         import os
         self.module = module
+        import weakref
+        self._torch_ddp = weakref.ref(torch_ddp) if torch_ddp is not None else None
         self.auto_wait = bool(auto_wait)
         self.force_collectives = bool(force_collectives)
         self.process_group = process_group
@@ -317,8 +335,10 @@ class OnirisDDP(nn.Module):
         if grad_dtype is None and os.environ.get("ONIRIS_DDP_BF16"):
             grad_dtype = torch.bfloat16
         self.grad_dtype = grad_dtype
-        self._sync_enabled = True
+        self._sync_flag = True
         self._queued = False
+        self._fwd_synced = True            # inner mode: the flag torch DDP's forward saw (torch prepares its reducer there)
+        self._bank_holder = None
         self._works = []                   # [(work, finish callable | None)]
         self._sent = [False] * len(self.flat.stages)
         self._g16 = None                   # bf16 transport buffer (grad_dtype)
@@ -331,15 +351,18 @@ class OnirisDDP(nn.Module):
         self.flat._active_check = self._check_active
         if self.flat.stages:                             # early exchanges (see FlatParams / _stage)
             hooks = {key: self._make_stage(i) for i, (key, _, _) in enumerate(self.flat.stages)}
-            module.__dict__["_oniris_stage_hooks"] = hooks
-            module.__dict__["_oniris_stage_at"] = self.flat.stages[0][0]       # (one-stage form, toy modules)
-            module.__dict__["_oniris_stage_cb"] = hooks[self.flat.stages[0][0]]
+            stager = getattr(self.flat, "stage_module", None) or module       # (a Precond around the UNet: the UNet)
+            stager.__dict__["_oniris_stage_hooks"] = hooks
+            stager.__dict__["_oniris_stage_at"] = self.flat.stages[0][0]       # (one-stage form, toy modules)
+            stager.__dict__["_oniris_stage_cb"] = hooks[self.flat.stages[0][0]]
+            self._stager = stager
         # every rank starts from rank 0's parameters AND buffers (what torch DDP does at construction: MPFourier's
         # random freqs / phases are buffers, utils.py:63-64 -- ranks built from different RNG states would otherwise
         # keep different noise / time embeddings under shared weights)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self.flat.flat, src=0, group=self.process_group)
-            self._broadcast_buffers()
+            if torch_ddp is None:                        # (inner mode: torch DDP broadcasts the buffers and its own parameters)
+                self._broadcast_buffers()
         if self.exchange == "mesh" and self._active():
             world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
             segs = [self.flat.head] + [(lo, hi) for _, lo, hi in self.flat.stages]
@@ -370,6 +393,47 @@ class OnirisDDP(nn.Module):
             return super().__getattr__(name)
         except AttributeError:
             return getattr(self.module, name)
+
+    @property
+    def _sync_enabled(self):
+        if self._torch_ddp is not None:
+            outer = self._torch_ddp()
+            if outer is None:
+                raise RuntimeError("the torch DistributedDataParallel wrapper of this network is gone, but the network is still "
+                                   "being trained: its kernel-owned weight gradients would no longer be exchanged -- wrap it again")
+            return bool(outer.require_backward_grad_sync) and self._sync_flag
+        return self._sync_flag
+
+    @_sync_enabled.setter
+    def _sync_enabled(self, v):
+        self._sync_flag = bool(v)
+
+    def _bank(self):
+        """The WeightBank of the wrapped tree (it lives on the module whose forward entered `weights_ready` first: the UNet,
+        also when a Precond around it is what got wrapped)."""
+        m = self._bank_holder
+        if m is not None:
+            b = m.__dict__.get("_oniris_bank")
+            if b is not None:
+                return b
+        for m in self.module.modules():
+            b = m.__dict__.get("_oniris_bank")
+            if b is not None:
+                self._bank_holder = m
+                return b
+        return None
+
+    # ---- inner mode (under torch's DistributedDataParallel): called by the wrapped module's forward
+    def inner_pre_forward(self):
+        if torch.is_grad_enabled() and self.flat.foreign_zero_grad():
+            self.flat.begin_foreign_cycle()
+
+    def inner_post_forward(self, out):
+        self._fwd_synced = self._sync_enabled
+        if torch.is_grad_enabled() and self._fwd_synced:
+            first = out[0] if isinstance(out, (tuple, list)) else out
+            if torch.is_tensor(first) and first.requires_grad:
+                first.register_hook(self._on_backward_start)
 
     def forward(self, *args, **kwargs):
         if torch.is_grad_enabled() and self.flat.foreign_zero_grad():
@@ -402,8 +466,8 @@ class OnirisDDP(nn.Module):
             weights with no pending slab) and start their exchange; RCCL runs it on its own stream, beside the backward
             kernels that are still to come.  Stages that did not fire by themselves (their activation needed no
             gradient) go out with the next one."""
-            if self._sync_enabled and self._active() and not self._sent[i]:
-                bank = self.module.__dict__.get("_oniris_bank")
+            if self._sync_enabled and self._fwd_synced and self._active() and not self._sent[i]:
+                bank = self._bank()
                 if bank is not None:
                     bank.backward()
                 for j in range(i + 1):
@@ -416,11 +480,11 @@ class OnirisDDP(nn.Module):
         return hook
 
     def _stage(self, grad):                              # (one-stage form kept for callers of the round-2 API)
-        return self.module.__dict__["_oniris_stage_cb"](grad)
+        return getattr(self, "_stager", self.module).__dict__["_oniris_stage_cb"](grad)
 
     def _end_of_backward(self):
         self._queued = False
-        if not self._sync_enabled:
+        if not (self._sync_enabled and self._fwd_synced):
             return
         self.allreduce_grads()                           # (finalises weight gradients + gathers the small ones first)
         if self.auto_wait:
@@ -487,11 +551,14 @@ class OnirisDDP(nn.Module):
         from a hipGraph and exchanges eagerly): the weight gradients are finalised and the autograd-owned small
         gradients (gates, emb_gain, out_gain, grouped emb weights) are gathered into the flat buffer FIRST, so that
         they take part in the average instead of being added, un-averaged, by the optimizer's own gather()."""
-        bank = self.module.__dict__.get("_oniris_bank")
+        bank = self._bank()
         if bank is not None:
             bank._finish()                               # no-op unless a backward left it pending
+        foreign = getattr(self.flat, "_foreign", False)
         self.flat.adopt()                                # (gradients a foreign zero_grad pushed outside the buffer)
         self.flat.gather()
+        if foreign:
+            self._check_foreign_active()
         sent, self._sent = self._sent, [False] * len(self.flat.stages)
         if not self._active():
             return
@@ -504,6 +571,19 @@ class OnirisDDP(nn.Module):
         self._opt_steps += 1
         if not self._active() or (self._opt_steps > 2 and self._opt_steps % self.active_check_every):
             return
+        self._compare_bitmaps(active)
+
+    def _check_foreign_active(self):
+        """A torch.optim optimizer skips a parameter whose .grad is None, decided per rank, while the exchange averages the
+        whole buffer: ranks that ran different step kinds would update different sets of weights.  (torch's reducer makes
+        "received a gradient" global for ITS parameters; this is the same guarantee for the kernel-owned ones, as a check:
+        the None-bitmaps are compared on the first exchanges of foreign cycles and on every `active_check_every`-th.)"""
+        self._foreign_syncs = getattr(self, "_foreign_syncs", 0) + 1
+        if not self._active() or (self._foreign_syncs > 2 and self._foreign_syncs % self.active_check_every):
+            return
+        self._compare_bitmaps([p.grad is not None for p in self.flat.params])
+
+    def _compare_bitmaps(self, active):
         import zlib
         h = zlib.crc32(bytes(bytearray(int(bool(a)) for a in active)))
         t = torch.tensor([h, -h], dtype=torch.int64, device=self.flat.grad.device)
@@ -561,11 +641,11 @@ class OnirisDDP(nn.Module):
 
     @contextlib.contextmanager
     def no_sync(self):
-        old, self._sync_enabled = self._sync_enabled, False
+        old, self._sync_flag = self._sync_flag, False
         try:
             yield
         finally:
-            self._sync_enabled = old
+            self._sync_flag = old
 
 
 def power_function_exponent(std):

@@ -85,7 +85,7 @@ def install():
             y = torch.nn.functional.silu(y.float() * cscale.float()[:, None, None, :]).to(BF16)
         return y
 
-    def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None):
+    def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, grad_private=False):
         ca, cb = coefs if coefs is not None else ops.gate_coefs(gate)
         N = x.shape[0]
         y = _mix(x, pw2.cout, [pw2, pw3]).float() * (ca.float() + cb.float()).reshape(N, 1, 1, 1)

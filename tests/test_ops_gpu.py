@@ -694,6 +694,42 @@ def test_resample_fused():
         assert rel(nchw(y), yr) < 5e-3 and rel(nchw(x.grad), xr.grad) < 5e-3
 
 
+def test_clip_flags_survive_a_second_forward_before_backward():
+    """the forward's "did the clip change anything" flag is read by the backward.  A second grad-enabled forward
+    before that backward (two micro-batches summed into one loss; a train-mode evaluation in between) rewinds and refills the
+    step's zero arena -- where the flags lived in round 4 -- so the first forward's flag was cleared (mask dropped: gradient
+    flows through clipped elements) or aliased with the second forward's.  Now a flag's storage lives with its autograd graph."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(3)
+    B, T, cin, cout, H = 1, 4, 32, 64, 16
+    N = B * 2 * T
+    p2 = torch.nn.Parameter(O.normalize(O.normalize(torch.randn(cout, cin, 3, 3))).to(DEV))
+    p3 = torch.nn.Parameter(O.normalize(O.normalize(torch.randn(cout, cin, 2, 3, 3))).to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    xa0, xb0 = bfr(torch.randn(N, cin, H, H)), bfr(torch.randn(N, cin, H, H))
+    ra0, rb0 = bfr(torch.randn(N, cout, H, H) * 200), bfr(torch.randn(N, cout, H, H))       # A clips, B does not
+    g0, gy0 = torch.rand(N) * 0.5 + 0.05, bfr(torch.randn(N, cout, H, H))
+
+    def run(interleave):
+        bank.prepare(training=True)
+        xa, ra = nhwc(xa0).requires_grad_(True), nhwc(ra0).requires_grad_(True)
+        ya = ops.gated_conv_train(xa, g0.to(DEV), pw2, pw3, B, T, res=ra, ta=0.9, tb=0.4, clip=256.0, grad_private=True)
+        if interleave:
+            bank.prepare(training=True)                     # what the second forward of a net does first
+            xb, rb = nhwc(xb0).requires_grad_(True), nhwc(rb0).requires_grad_(True)
+            yb = ops.gated_conv_train(xb, g0.to(DEV), pw2, pw3, B, T, res=rb, ta=0.9, tb=0.4, clip=256.0, grad_private=True)
+        ya.backward(nhwc(gy0).clone())
+        if interleave:
+            yb.backward(nhwc(gy0).clone())
+        torch.cuda.synchronize()
+        return xa.grad.clone(), ra.grad.clone(), float((ya.abs() >= 256).float().mean())
+    dx1, dr1, frac = run(False)
+    dx2, dr2, _ = run(True)
+    assert frac > 0.01, "clip not exercised"
+    assert float((dr1 == 0).float().mean()) > 0.01, "the mask of the clipped elements is missing in the single-forward run"
+    assert torch.equal(dr1, dr2) and torch.equal(dx1, dx2), "a second forward changed the first one's backward"
+
+
 # H = 16: the LDS-DMA tile kernel's epilogues (cout = 64) and the streaming kernel's (cout = 32); clipped = False: the +-256 clip
 # is armed but never reached -- the usual case, in which the backward pre-pass reads no mask (OnirisConvArgs.clip_flag)
 @pytest.mark.parametrize("gated,H,cout,clipped", [(False, 8, 64, True), (True, 8, 64, True), (True, 16, 64, True),
@@ -707,7 +743,10 @@ def test_conv_epilogues(gated, H, cout, clipped):
     w2 = O.normalize(O.normalize(torch.randn(cout, cin, 3, 3)))
     w3 = O.normalize(O.normalize(torch.randn(cout, cin, 2, 3, 3)))
     F = torch.nn.functional
-    for epi in ("emb_silu", "mpsum"):
+    # private: the caller vouches that nobody else reads the output's gradient (ops.ConvCfg.grad_private, what UNet.forward does):
+    # the clip_flag aliasing protocol -- no masked copy; the gradient is masked IN PLACE when the forward clipped.  Without it
+    # (the default: y.backward(g) with the caller's own g) the gradient tensor must come back untouched.
+    for epi, private in (("emb_silu", False), ("mpsum", False)) + ((("mpsum", True),) if gated else ()):
         p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
         bank, (pw2, pw3) = make_bank([p2, p3])
         bank.prepare(training=True)
@@ -721,8 +760,14 @@ def test_conv_epilogues(gated, H, cout, clipped):
         cs = c0.clone().to(DEV).requires_grad_(True)
         res = nhwc(r0).requires_grad_(True)
         kw = dict(cscale=cs) if epi == "emb_silu" else dict(res=res, ta=0.9, tb=0.4, clip=256.0)
-        y = ops.gated_conv_train(x, gate, pw2, pw3, B, T, **kw) if gated else ops.conv(x, pw2, **kw)
-        y.backward(nhwc(gy0))
+        y = ops.gated_conv_train(x, gate, pw2, pw3, B, T, grad_private=private, **kw) if gated else ops.conv(x, pw2, **kw)
+        gy = nhwc(gy0)
+        gy_before = gy.clone()
+        y.backward(gy)
+        if not private:
+            assert torch.equal(gy, gy_before), "the backward wrote into the caller's gradient tensor"
+        elif clipped and ops.CLIP_FLAG:
+            assert not torch.equal(gy, gy_before), "aliasing protocol not exercised (expected the in-place mask)"
         # oracle
         xr, gr = x0.clone().requires_grad_(True), g0.clone().requires_grad_(True)
         cr, rr = c0.clone().requires_grad_(True), r0.clone().requires_grad_(True)
@@ -755,7 +800,7 @@ def test_conv_epilogues(gated, H, cout, clipped):
             assert (float((nchw(y).abs() >= 256).float().mean()) > 0.01) == clipped, "clip (not) exercised"
         if gated:
             e["dw3"], e["dg"] = rel(p3.grad, w3r.grad), rel(gate.grad, gr.grad)
-        print("conv epilogue", epi, "gated" if gated else "plain", e)
+        print("conv epilogue", epi, "gated" if gated else "plain", "private" if private else "", e)
         assert e["y"] < 1e-2 and e["dx"] < 1.5e-2 and e["dw2"] < 2e-2
         assert all(v_ < 3e-2 for v_ in e.values()), e
 

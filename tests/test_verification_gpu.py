@@ -278,7 +278,7 @@ def test_gated_conv_train_backward_epilogues_bf16_faithful(B, T, H, cin, cout, e
     else:
         r0 = bfr(torch.randn(N, cout, H, H))
         res = nhwc(r0).requires_grad_(True)
-        y = ops.gated_conv_train(x, None, pw2, pw3, B, T, coefs=(ca, cb), res=res, ta=ta, tb=tb, clip=clip)
+        y = ops.gated_conv_train(x, None, pw2, pw3, B, T, coefs=(ca, cb), res=res, ta=ta, tb=tb, clip=clip, grad_private=True)
     y.backward(nhwc(g0).clone())
     # forward quantities as stored
     xs = x0.double().reshape(B, 2, T, cin, H, H)
