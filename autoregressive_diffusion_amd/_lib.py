@@ -74,6 +74,7 @@ _SIGS = {
     "oniris_struct_sizes": (c_int, [c_void_p]),
     "oniris_profile_arm": (c_int, [c_void_p, c_void_p]),
     "oniris_profile_disarm": (c_int, []),
+    "oniris_set_cu_reserve": (c_int, [c_int]),
     "oniris_train_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_infer_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_mask_transpose": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

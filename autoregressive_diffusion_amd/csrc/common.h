@@ -55,6 +55,13 @@ static inline void oniris_launch(K kern, dim3 grid, dim3 block, hipStream_t stre
   }
 }
 
+// Persistent launches (one workgroup per CU: conv_glds.h, conv1x1_glds.h; the attention work lists are sized by the caller):
+// the CU count of the current device minus oniris_set_cu_reserve()'s k -- CUs left to the collective library's kernels while
+// a gradient exchange is in flight (a persistent workgroup that finds its CU's LDS taken waits for a whole other workgroup
+// to finish: the launch takes up to twice as long).  misc.cpp.
+extern int oniris_cu_reserve;
+int oniris_persistent_wgs(void);
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int roundup(int a, int b) { return cdiv(a, b) * b; }
 

@@ -225,13 +225,7 @@ static int launch_conv1x1_glds(const OnirisConvArgs& a, hipStream_t stream) {
   d.ncob = cdiv(a.CoutP, C1Cfg::BN);
   d.ntx = d.nty = 1; d.ksplit = 1; d.reduce = 0;
   const long long ntiles = (long long)d.ntt * d.ncob;
-  static int ncu = 0;
-  if (ncu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-      ncu = 256;
-  }
+  const int ncu = oniris_persistent_wgs();       // one workgroup per CU (minus the CUs reserved for a gradient exchange in flight)
   const long long nblk = ntiles < ncu ? ntiles : ncu;
   oniris_launch(conv1x1_glds_kernel, dim3((unsigned)nblk), dim3(C1Cfg::NTHR), stream, d);
   ONIRIS_LAUNCH_CHECK();

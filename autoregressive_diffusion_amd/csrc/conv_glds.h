@@ -518,13 +518,7 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
   d.ntx = a.W / P::PW; d.nty = a.H / P::PH; d.ntt = cdiv(a.T, P::FT);
   const long long ntiles = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
   if (ntiles <= 0 || ntiles > 0x7fffffffLL) { oniris_set_error("conv_fwd: bad grid %lld", ntiles); return ONIRIS_EINVAL; }
-  static int ncu = 0;                  // persistent workgroups: one per CU (the two LDS buffers fill a CU)
-  if (ncu == 0) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
-      ncu = 256;
-  }
+  const int ncu = oniris_persistent_wgs();       // one workgroup per CU (minus the CUs reserved for a gradient exchange in flight)
   const long long nblk = ntiles < ncu ? ntiles : ncu;
   auto kern = conv_glds_kernel<NT, PW, NW, MT, WC, CTX, RES>;
   oniris_launch(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), stream, d);

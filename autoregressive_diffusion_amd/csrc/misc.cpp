@@ -31,7 +31,26 @@ extern "C" int oniris_profile_disarm(void) {          // 1: the pair was still a
   oniris_prof_ev[0] = oniris_prof_ev[1] = nullptr;
   return armed;
 }
-extern "C" int oniris_abi_version(void) { return 11; }
+extern "C" int oniris_abi_version(void) { return 12; }
+
+int oniris_cu_reserve = 0;
+int oniris_persistent_wgs(void) {
+  static int ncu = 0;
+  if (ncu == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+      ncu = 256;
+  }
+  const int n = ncu - oniris_cu_reserve;
+  return n < 8 ? 8 : n;
+}
+extern "C" int oniris_set_cu_reserve(int k) {          // returns the previous value; k is rounded up to whole XCD octets
+  ONIRIS_CHECK_ARG(k >= 0 && k <= 128, "set_cu_reserve: 0 <= k <= 128");
+  const int old = oniris_cu_reserve;
+  oniris_cu_reserve = (k + 7) / 8 * 8;
+  return old;
+}
 
 // ---- mask tables (reference: edm2/attention/attention_masking.py:27-53, 64-90); 128 = flex default block
 static const int kFlexBlock = 128;

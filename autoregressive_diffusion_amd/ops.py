@@ -104,6 +104,26 @@ _cu_count = {}
 ATTN_PERSISTENT = int(__import__("os").environ.get("ONIRIS_ATTN_PERSISTENT", "1"))   # 0: grid kernels (A/B knob)
 
 
+_cu_reserve = 0
+
+
+def set_cu_reserve(k):
+    """CUs the persistent kernels leave free from the next launch on (oniris_set_cu_reserve: the LDS-DMA convolutions; here:
+    the attention work lists, which are built per workgroup count).  parallel.OnirisDDP sets ONIRIS_COMM_CUS while a gradient
+    exchange is in flight; ONIRIS_COMM_CUS_ALWAYS=k keeps k reserved for the whole process (one-GPU measurement of what the
+    reservation costs the step).  Returns the previous value."""
+    global _cu_reserve
+    old = lib.oniris_set_cu_reserve(int(k))
+    if old < 0:
+        check(old, "set_cu_reserve")
+    _cu_reserve = (int(k) + 7) // 8 * 8
+    return old
+
+
+if int(__import__("os").environ.get("ONIRIS_COMM_CUS_ALWAYS", "0")) > 0:
+    set_cu_reserve(int(__import__("os").environ["ONIRIS_COMM_CUS_ALWAYS"]))
+
+
 def attn_schedule(weights, n_pairs, device, n_wg=None):
     """Device copy of the static balanced schedule (oniris_attn_schedule) of n_pairs x len(weights) work items over
     the persistent workgroups (one per CU); cached per (weights, pairs, device).  Returns (tensor [n_wg][slots], n_wg,
@@ -112,6 +132,7 @@ def attn_schedule(weights, n_pairs, device, n_wg=None):
         n_wg = _cu_count.get(str(device))
         if n_wg is None:
             n_wg = _cu_count[str(device)] = torch.cuda.get_device_properties(device).multi_processor_count
+        n_wg = max(8, n_wg - _cu_reserve)
     w = np.ascontiguousarray(weights, dtype=np.int32)
     key = (w.tobytes(), n_pairs, str(device), n_wg)
     hit = _sched_cache.get(key)

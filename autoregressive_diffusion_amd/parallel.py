@@ -338,6 +338,8 @@ class OnirisDDP(nn.Module):
         self._sync_flag = True
         self._queued = False
         self._fwd_synced = True            # inner mode: the flag torch DDP's forward saw (torch prepares its reducer there)
+        self.comm_cus = int(os.environ.get("ONIRIS_COMM_CUS", "0"))    # CUs left to RCCL while an exchange is in flight
+        self._reserved = False
         self._bank_holder = None
         self._works = []                   # [(work, finish callable | None)]
         self._sent = [False] * len(self.flat.stages)
@@ -474,7 +476,7 @@ class OnirisDDP(nn.Module):
                     if not self._sent[j]:
                         _, lo, hi = self.flat.stages[j]
                         self.flat.adopt(lo, hi)
-                        self._exchange(lo, hi)
+                        self._exchange(lo, hi, f"stage{j}")
                         self._sent[j] = True
             return None
         return hook
@@ -490,14 +492,27 @@ class OnirisDDP(nn.Module):
         if self.auto_wait:
             self.wait()
 
-    def _exchange(self, lo, hi):
+    def _reserve_cus(self, on):
+        """ONIRIS_COMM_CUS=k: while an exchange is in flight the persistent kernels (one workgroup per CU) launch on k fewer
+        CUs, so RCCL's workgroups do not have to share a CU's LDS with a convolution workgroup that fills it.  Host-side
+        toggle = exactly the launches that can overlap the exchange: RCCL's stream waits for the compute stream at the
+        point the collective is issued, and wait() orders everything issued after it behind the exchange."""
+        k = self.comm_cus
+        if k <= 0 or not self.flat.grad.is_cuda or on == self._reserved:
+            return
+        from . import ops
+        ops.set_cu_reserve(k if on else ops_always_reserve())
+        self._reserved = on
+
+    def _exchange(self, lo, hi, label=None):
         if hi <= lo:
             return
+        self._reserve_cus(True)
         g = self.flat.grad
         world = dist.get_world_size(self.process_group)
         nccl = g.is_cuda and dist.get_backend(self.process_group) == "nccl"    # RCCL averages in the collective; gloo has no AVG
         if self.exchange == "mesh":
-            return self._exchange_mesh(lo, hi, world)
+            return self._exchange_mesh(lo, hi, world, label)
         buf = g
         if self.grad_dtype is not None:                  # bf16 transport: one cast pass each way, half the bytes on the links
             if self._g16 is None:
@@ -511,9 +526,9 @@ class OnirisDDP(nn.Module):
             e = min(hi, s + self.bucket_elems)
             w = dist.all_reduce(buf[s:e], op=op, group=self.process_group, async_op=True)
             fin = (lambda s=s, e=e: g[s:e].copy_(self._g16[s:e])) if buf is not g else None
-            self._works.append((w, fin))
+            self._works.append((w, fin, label))
 
-    def _exchange_mesh(self, lo, hi, world):
+    def _exchange_mesh(self, lo, hi, world, label=None):
         """Reduce-scatter of segment [lo, hi) as ONE all-to-all (chunk r goes straight to rank r) + a local sum; the
         averaged chunk this rank owns lands in `flat.grad_reduced` (laid out like the flat buffers; only the owned ranges
         are ever written or read: the optimizer runs on them).  `flat.grad` itself stays purely LOCAL: an exchange that
@@ -543,7 +558,7 @@ class OnirisDDP(nn.Module):
             own = red[lo + rank * chunk: lo + (rank + 1) * chunk]
             torch.sum(recv.view(world, chunk).float() if recv.dtype != g.dtype else recv.view(world, chunk), dim=0, out=own)
             own.mul_(1.0 / world)
-        self._works.append((w, fin))
+        self._works.append((w, fin, label))
 
     def allreduce_grads(self):
         """Exchange whatever the stage hooks have not sent yet (everything, when none fired in this backward).
@@ -562,10 +577,10 @@ class OnirisDDP(nn.Module):
         sent, self._sent = self._sent, [False] * len(self.flat.stages)
         if not self._active():
             return
-        for (_, lo, hi), done in zip(self.flat.stages, sent):
+        for j, ((_, lo, hi), done) in enumerate(zip(self.flat.stages, sent)):
             if not done:
-                self._exchange(lo, hi)
-        self._exchange(*self.flat.head)
+                self._exchange(lo, hi, f"stage{j}")
+        self._exchange(*self.flat.head, "head")
 
     def _check_active(self, active):
         self._opt_steps += 1
@@ -630,14 +645,23 @@ class OnirisDDP(nn.Module):
                 self._allgather_like_params(optimizer.v)
         optimizer._state_complete_at = optimizer.steps
 
-    def wait(self):
-        """Block the current stream until the gradient exchange is done (call before the optimizer step)."""
-        for w, fin in self._works:
+    def wait(self, timing=None):
+        """Block the current stream until the gradient exchange is done (call before the optimizer step).
+        timing: a dict -- per exchange label ("stage0" .. / "head") a list of (before, after) event pairs recorded on the
+        current stream around that exchange's wait: how long the compute stream stood still for EACH stage (bench.py)."""
+        for w, fin, label in self._works:
+            if timing is not None and self.flat.grad.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             w.wait()
             if fin is not None:
                 with torch.no_grad():
                     fin()
+            if timing is not None and self.flat.grad.is_cuda:
+                e1.record()
+                timing.setdefault(label or "exchange", []).append((e0, e1))
         self._works = []
+        self._reserve_cus(False)
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -646,6 +670,11 @@ class OnirisDDP(nn.Module):
             yield
         finally:
             self._sync_flag = old
+
+
+def ops_always_reserve():
+    import os
+    return int(os.environ.get("ONIRIS_COMM_CUS_ALWAYS", "0"))
 
 
 def power_function_exponent(std):

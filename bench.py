@@ -250,7 +250,7 @@ def _claim_stdout():
     sys.stdout = os.fdopen(keep, "w", buffering=1)
 
 
-def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light_batch=2):
+def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light_batch=2, light_frames=None):
     """The timed training job on this rank: build the net, W warm-up + K timed steps between fences, max over ranks.
     light: an extra measurement inside the headline run (no per-kernel profile, no CPU baseline): {frames_s, ms_per_step, ...}.
     Returns the JSON record (rank 0) or None."""
@@ -293,7 +293,7 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
                EDM2Loss(P_mean=1.2, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.5))         # gym_train.py:66-67
 
     B = args.batch if not light else light_batch
-    T = (args.frames if not light else None) or (32 if cs else 64)
+    T = (args.frames if not light else light_frames) or (32 if cs else 64)
     g = torch.Generator(device=dev).manual_seed(1234 + rank)
     res = unet.img_resolution
     latents = torch.randn(B, T, 8, res, res, device=dev, generator=g)
@@ -321,13 +321,14 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
     ref_lr, sched_steps = 1e-2, 100000 / 50                      # gym_train.py:69,110-112 (total_number_of_steps / 50)
     micro = [0]                                                  # micro-steps taken (the reference's loop index i)
     comm_events = []                                             # (before, after) model.wait() on the compute stream
+    comm_stage = {}                                              # exchange label -> [(before, after)] around ITS wait
 
     def wait_exchange():
         """model.wait() makes the compute stream wait for RCCL's: the events around it measure how long the compute stream
         stood still for communication that the backward pass did not hide (+ the bf16 / mesh finishing passes)."""
         if comm_events is not None and len(comm_events) < 4096:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); model.wait(); e1.record()
+            e0.record(); model.wait(timing=comm_stage); e1.record()
             comm_events.append((e0, e1))
         else:
             model.wait()
@@ -383,6 +384,7 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
     if _host_t:
         _host_t[0] = _host_t[1] = _host_t[2] = 0.0
     del comm_events[:]
+    comm_stage.clear()
     t0 = time.perf_counter()
     hist = []
     for i in range(steps):
@@ -405,6 +407,8 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
         dt = float(tt.item())
     loss_val = float(last.item())
     exposed = (sum(a.elapsed_time(b) for a, b in comm_events) / max(1, steps)) if (multi and comm_events) else None
+    exposed_stage = ({k: round(sum(a.elapsed_time(b) for a, b in v) / max(1, steps), 4) for k, v in sorted(comm_stage.items())}
+                     if (multi and comm_stage) else None)
     comm_events = None                                            # (no events in the extra steps below)
     if light:
         return dict(frames_s=world * B * T * steps / dt, ms_per_step=dt / steps * 1e3, steps=steps, warmup=warmup,
@@ -430,18 +434,18 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
             ts.append((time.perf_counter() - t1) * 1e3)
         per_mode[name] = sorted(ts)[1]
 
-    roof, kernels, roof_attn, roof_attn_bwd, roof_step = None, None, None, None, None
+    roof, kernels, roof_attn, roof_attn_bwd, roof_step, roof_step_2d = None, None, None, None, None, None
     if rank == 0 and not args.no_profile:
         # one full 3:1 cycle (eager), every MFMA launch bracketed by HIP events on its own stream; the 2-D step and the three
         # 3-D steps are aggregated separately (roofline_step is the 3-D step's)
-        agg, agg3 = {}, {}
+        agg, agg3, agg2 = {}, {}, {}
         for i in range(4):
             wd.beat(f"{tag}profiled step {i}")
             ops.KernelProfile.start()
             step(i)
             part = ops.KernelProfile.stop()
             for k, v in part.items():
-                for tgt in ((agg, agg3) if i % 4 else (agg,)):
+                for tgt in ((agg, agg3) if i % 4 else (agg, agg2)):
                     a = tgt.setdefault(k, dict(launches=0, flops=0.0, ms=0.0, bytes=0.0, t_min=0.0))
                     for f_ in ("launches", "flops", "ms", "bytes", "t_min"):
                         a[f_] += v[f_]
@@ -503,6 +507,21 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
                                   "sum_t_min over its MFMA launches = sum of max(FLOPs / 2.5 PF, algorithmic bytes / 6.3 TB/s); "
                                   "mfma_kernels_ms = their measured time, the rest of ms_3d_step is elementwise / weight / optimizer "
                                   "passes and launch boundaries")
+        # the 2-D step (one step in four, gym_train.py:96: own-frame convolutions on the T real frames, 1x1 convs, per-frame
+        # attention at both attention levels -- conv.py:60 `just_2d`): algorithmic FLOPs = the sum over its MFMA launches
+        # (attention backward priced at 2.5 x its forward, as above) x 1, against its own wall time
+        if agg2:
+            fl2 = sum((2.5 / 3.5 if k.startswith("attn_bwd") else 1.0) * v["flops"] for k, v in agg2.items())
+            ms2 = per_mode["ms_2d_step"]
+            tmin2 = sum(v["t_min"] for v in agg2.values()) * 1e3
+            roof_step_2d = dict(bound="mfma", flops_per_step=fl2, flops_source="sum of the launches' algorithmic FLOPs",
+                                ms_2d_step=ms2, achieved=fl2 / (ms2 * 1e-3) / 1e12, peak=MFMA_BF16_PEAK / 1e12, unit="TFLOP/s",
+                                frac=fl2 / (ms2 * 1e-3) / MFMA_BF16_PEAK, sum_t_min_ms=tmin2, frac_t_min=tmin2 / ms2,
+                                mfma_kernels_ms=sum(v["ms"] for v in agg2.values()),
+                                kernels={k: dict(launches=v["launches"], ms_total=round(v["ms"], 3),
+                                                 frac=round(v["flops"] / (v["ms"] * 1e-3) / MFMA_BF16_PEAK, 3),
+                                                 roof=round(v["t_min"] / (v["ms"] * 1e-3), 3))
+                                         for k, v in sorted(agg2.items(), key=lambda kv: -kv[1]["ms"])[:8]})
     elif world > 1:
         for i in range(4):
             wd.beat(f"{tag}unprofiled cycle step {i} (collectives matched across ranks)")
@@ -520,6 +539,8 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
                      "stage_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for _, lo, hi in flat.stages],
                      "head_mb": round((flat.head[1] - flat.head[0]) * 4 / 2 ** 20, 1),
                      "exposed_comm_ms_per_step": exposed,
+                     "exposed_comm_ms_per_step_by_stage": exposed_stage,
+                     "comm_cus": getattr(model, "comm_cus", 0),
                      "exposed_comm_note": "compute-stream time spent inside OnirisDDP.wait() per timed step on rank 0 (HIP events): "
                                           "what of the gradient exchange the backward pass did not hide"}
                     if multi else None),
@@ -534,7 +555,8 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
                        **({"shared_gpu_gloo_NOT_A_MEASUREMENT": True} if share else {}),
                        **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
                        **{k: round(v, 2) for k, v in per_mode.items()}},
-            "loss": loss_val, "roofline": roof, "roofline_step": roof_step, "roofline_attention": roof_attn,
+            "loss": loss_val, "roofline": roof, "roofline_step": roof_step, "roofline_step_2d": roof_step_2d,
+            "roofline_attention": roof_attn,
             "roofline_attention_bwd": roof_attn_bwd, "kernels": kernels}
 
 
@@ -550,6 +572,7 @@ def main():
     ap.add_argument("--net", choices=["gym", "cs"], default="gym",
                     help="gym = BASELINE configs[1] (the headline metric); cs = the Counter-Strike net of configs[2]/[3] "
                          "(32x32 latents, 310 M parameters, no conditioning) as an extra measurement")
+    ap.add_argument("--extra-rollout-frames", type=int, default=256, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-frames", type=int, default=64,
                     help="frames of the CPU-baseline sample: 64 = BASELINE configs[1] at B = 1 (BASELINE.md section 3: about two "
                          "minutes of host time); smaller = a shorter sample; 0 = skip")
@@ -619,9 +642,13 @@ def main():
             if args.batch != 2:      # rounds 1-3 quoted the headline at 2 sequences per GPU: kept for round-over-round comparison
                 extra["gym_t64_b2"] = train(args, "gym", 8, 4, rank, world, dev, wd, light=True, light_batch=2)
                 torch.cuda.empty_cache()
-            extra["rollout_32"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=32), quiet=True)
-            extra["rollout_32"]["note"] = ("configs[4] settings (16 Heun steps = 31 evaluations per frame) on 32 generated frames behind a "
-                                           "10-frame context; `python bench.py --mode rollout --gen-frames 256` runs the full 256")
+            # BASELINE configs[3]'s per-GPU share: the 310 M net on 64-frame sequences, cs_train.py:59's 2 sequences per GPU
+            extra["cs_t64"] = train(args, "cs", 8, 4, rank, world, dev, wd, light=True, light_batch=2, light_frames=64)
+            torch.cuda.empty_cache()
+            # BASELINE configs[4] at its stated size: 256 generated frames (31 evaluations each) behind a 10-frame context
+            extra["rollout_256"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=256), quiet=True)
+            extra["rollout_256"]["note"] = ("configs[4]: 256 generated frames, plotting.py:165 settings (16 Heun steps = 31 UNet "
+                                            "evaluations per frame), one sequence, KV / activation caches growing from 10 to 266 frames")
             r8 = rollout(types.SimpleNamespace(batch=8, ctx_frames=8, gen_frames=8), quiet=True)
             extra["rollout_b8"] = {k: r8[k] for k in ("value", "unit", "ms_per_unet_eval", "frames_generated", "batch", "finite")}
             extra["rollout_b8"]["note"] = "the same sampler on 8 sequences at once (throughput; rollout_32 is the one-sequence latency case)"

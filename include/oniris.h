@@ -23,7 +23,7 @@ extern "C" {
 typedef void* oniris_stream_t;
 
 const char* oniris_last_error(void);
-int oniris_abi_version(void);   /* 11.  10 -> 11: OnirisConvArgs.ctx_prod / ctx_prod_mode (appended fields); 9 -> 10: OnirisConvArgs.clip_flag,
+int oniris_abi_version(void);   /* 12.  11 -> 12: oniris_set_cu_reserve; 10 -> 11: OnirisConvArgs.ctx_prod / ctx_prod_mode (appended fields); 9 -> 10: OnirisConvArgs.clip_flag,
                                  * oniris_gconv_bwd_fused(+ clip_flag, coef_own_scaled), oniris_qkv_norm_hd / _hd_bwd / oniris_rope_hd       */
 /* Measurement aid: arm a pair of HIP events (hipEvent_t created with timing); the next MFMA conv / weight-gradient /
  * scheduled attention-forward kernel this THREAD launches records its own begin and end into them (hipExtLaunchKernel:
@@ -31,6 +31,12 @@ int oniris_abi_version(void);   /* 11.  10 -> 11: OnirisConvArgs.ctx_prod / ctx_
  * oniris_profile_disarm returns 1 when the pair was not consumed (the entry point took a path without the hook).       */
 int oniris_profile_arm(void* start_event, void* stop_event);
 int oniris_profile_disarm(void);
+/* CUs the persistent kernels (one workgroup per CU: the LDS-DMA convolutions) leave free from now on: the data-parallel
+ * wrapper sets k while a gradient exchange is in flight beside the backward kernels, so that RCCL's workgroups find CUs of
+ * their own instead of delaying a persistent workgroup by a whole tile run (the reference: torch DDP's bucketed all-reduce
+ * overlapping backward, cs_train.py:53-54,108-114).  Process-wide, host-side, takes effect at the next launch; k is rounded
+ * up to a multiple of 8 (one CU per XCD).  Returns the previous value, or a negative error code.                        */
+int oniris_set_cu_reserve(int k);
 /* sizeof(OnirisWeightDesc, OnirisConvArgs, OnirisWgradArgs, OnirisAttnArgs) for binding self-checks */
 int oniris_struct_sizes(int32_t* out4 /* [host] */);
 

@@ -7,7 +7,9 @@ Adaptations (none touch reference files):
   1. device="cuda" -> "cpu" rewriting through a TorchFunctionMode + no-op .cuda()/.to("cuda").
   2. edm2.attention.attention_modules.compiled_flex_attention replaced by a dense SDPA whose mask is
      block_mask.to_dense() (expanded to token granularity) AND mask_mod  -- this is what the compiled
-     FlexAttention kernel computes on GPU, and it supports autograd on CPU.
+     FlexAttention kernel computes, and it supports autograd on CPU.  The claim is CHECKED at generation time:
+     `reference_compiled_flex` runs the same module calls through the reference's real torch.compile'd function (forward,
+     no_grad) and make_golden.py asserts equality to 1e-6 and stores those outputs (`*_y_compiledflex`) in G6 / G6b.
 """
 import sys
 import torch
@@ -78,6 +80,26 @@ def install():
             allowed = torch.isfinite(neg)
         return torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
 
+    if not hasattr(am, "_reference_compiled_flex_attention"):
+        am._reference_compiled_flex_attention = am.compiled_flex_attention      # the reference's own @torch.compile'd function
     am.compiled_flex_attention = dense_flex
     sys.path.append(root)
     return edm2
+
+
+class reference_compiled_flex:
+    """`with reference_compiled_flex(): y = module(x)` -- the module call runs the reference's OWN `compiled_flex_attention`
+    (attention_modules.py:85-88: torch.compile(flex_attention); inductor's CPU backend in this container, forward / no_grad
+    only -- with autograd it raises, which is why the fixtures' gradients come from `dense_flex`).  make_golden.py uses it to
+    assert, at generation time, that `dense_flex` (block table AND mask_mod) IS what the compiled kernel computes,
+    and stores the compiled kernel's output in the fixture."""
+
+    def __enter__(self):
+        from edm2.attention import attention_modules as am
+        self.am, self.saved = am, am.compiled_flex_attention
+        am.compiled_flex_attention = am._reference_compiled_flex_attention
+        return self
+
+    def __exit__(self, *exc):
+        self.am.compiled_flex_attention = self.saved
+        return False

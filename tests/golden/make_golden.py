@@ -197,6 +197,32 @@ def g5():
     save("g5_rope", **out)
 
 
+def compiled_flex_check(att, x, B, y_dense, what):
+    """The same training-mode call through the reference's REAL compiled FlexAttention (forward only): must equal the
+    dense `table AND mask_mod` stand-in the gradients were taken through, and must differ from `mask_mod` alone whenever a
+    frame has fewer than 128 tokens (the F2 quirk: eager flex_attention, which ignores the block table, gives that answer)."""
+    with torch.no_grad(), _refshim.reference_compiled_flex():
+        y_c, _ = att(x.detach(), B)
+    d = (y_c - y_dense.detach()).abs().max().item()
+    # ... and what `mask_mod` alone -- the answer of the un-compiled flex_attention, which ignores the block table -- would have
+    # given: the F2 quirk (nonzero whenever a frame has fewer than 128 tokens)
+    from edm2.attention import attention_modules as am
+
+    def mask_mod_only(q, k, v, score_mod=None, block_mask=None):
+        qi, ki = torch.arange(q.shape[-2])[:, None], torch.arange(k.shape[-2])[None, :]
+        return torch.nn.functional.scaled_dot_product_attention(q, k, v, attn_mask=block_mask.mask_mod(0, 0, qi, ki))
+    saved, am.compiled_flex_attention = am.compiled_flex_attention, mask_mod_only
+    try:
+        with torch.no_grad():
+            y_e, _ = att(x.detach(), B)
+    finally:
+        am.compiled_flex_attention = saved
+    q = (y_e - y_c).abs().max().item()
+    print(f"  compiled FlexAttention vs dense(table AND mask_mod) [{what}]: max |diff| {d:.2e};  vs mask_mod alone (not what the reference computes): {q:.2e}")
+    assert d <= 1e-6, (what, d)
+    return y_c
+
+
 def attn_params(C, g, video=True):
     p = {"attn_qkv.weight.weight": torch.randn(3 * C, C, 1, 1, generator=g),
          "attn_proj.weight.weight": torch.randn(C, C, 1, 1, generator=g)}
@@ -223,6 +249,7 @@ def g6():
         (y * gy).sum().backward()
         out.update({f"{tag}_x": x, f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_gx": x.grad,
                     f"{tag}_g_qkv": att.attn_qkv.weight.weight.grad, f"{tag}_g_proj": att.attn_proj.weight.weight.grad})
+        out[f"{tag}_y_compiledflex"] = compiled_flex_check(att, x, B, y, f"G6 {tag}: T={T} P={H * H} heads={m}")
         y2d, _ = att(x.detach(), B, just_2d=True)
         out[f"{tag}_y_just2d"] = y2d
         if tag == "a":
@@ -236,8 +263,13 @@ def g6():
                 y5, cache = att(xs[:, 4:5].reshape(-1, C, H, H), B, cache, update_cache=True)
                 k5 = cache[0].clone()
                 y6, cache2 = att(xs[:, 5:6].reshape(-1, C, H, H), B, cache, update_cache=False)
+                with _refshim.reference_compiled_flex():                                  # the causal prefill, compiled
+                    ye_c, _ = att(xe, B)
+            d = (ye_c - ye).abs().max().item()
+            print(f"  compiled FlexAttention vs dense, causal prefill of 6 frames: max |diff| {d:.2e}")
+            assert d <= 1e-6, d
             out.update(a_eval_x=xe, a_eval_y=ye, a_eval_y4=y4, a_eval_y5=y5, a_eval_y6=y6, a_eval_k5=k5,
-                       a_eval_v5=cache[1])
+                       a_eval_v5=cache[1], a_eval_y_compiledflex=ye_c)
     fa = FrameAttention(64, 1)
     p = attn_params(64, g, video=False)
     fa.load_state_dict(p, strict=True)
@@ -279,6 +311,7 @@ def g6b():
         (y * gy).sum().backward()
         out.update({f"{tag}_x": x, f"{tag}_y": y, f"{tag}_gy": gy, f"{tag}_gx": x.grad,
                     f"{tag}_g_qkv": att.attn_qkv.weight.weight.grad, f"{tag}_g_proj": att.attn_proj.weight.weight.grad})
+        out[f"{tag}_y_compiledflex"] = compiled_flex_check(att, x, B, y, f"G6b {tag}: T={T} P={H * H} heads={m}")
         y2d, _ = att(x.detach(), B, just_2d=True)
         out[f"{tag}_y_just2d"] = y2d
         if tag == "h16":

@@ -151,6 +151,10 @@ def test_g6_attention():
         x = T(z[tag + "_x"]).requires_grad_(True)
         y, _ = O.video_attention(p, "a.", x, B, m, None, False, False, True)
         close(y, z[tag + "_y"], rtol=5e-5, what=tag + " y")
+        # the reference's REAL compiled FlexAttention on the same inputs (make_golden.py: asserted equal to the dense
+        # `table AND mask_mod` stand-in at generation time, stored beside it): the oracle against the compiled kernel itself
+        close(y, z[tag + "_y_compiledflex"], rtol=5e-5, what=tag + " y (compiled FlexAttention)")
+        assert np.abs(z[tag + "_y_compiledflex"] - z[tag + "_y"]).max() <= 1e-6
         (y * T(z[tag + "_gy"])).sum().backward()
         close(x.grad, z[tag + "_gx"], rtol=1e-4, what=tag + " gx")
         close(p["a.attn_qkv.weight.weight"].grad, z[tag + "_g_qkv"], rtol=2e-4, what=tag + " g_qkv")
@@ -162,6 +166,7 @@ def test_g6_attention():
         xe = T(z["a_eval_x"]); B = 2
         ye, _ = O.video_attention(p, "a.", xe, B, 1, None, False, False, False)
         close(ye, z["a_eval_y"], rtol=5e-5, what="prefill")
+        close(ye, z["a_eval_y_compiledflex"], rtol=5e-5, what="prefill (compiled FlexAttention)")
         xs = xe.reshape(B, 6, *xe.shape[1:])
         y4, c = O.video_attention(p, "a.", xs[:, :4].reshape(-1, *xe.shape[1:]), B, 1, None, True, False, False)
         y5, c = O.video_attention(p, "a.", xs[:, 4:5].reshape(-1, *xe.shape[1:]), B, 1, c, True, False, False)
@@ -299,6 +304,7 @@ def test_g6b_attention_small_heads():
         x = T(z[tag + "_x"]).requires_grad_(True)
         y, _ = O.video_attention(p, "a.", x, B, m, None, False, False, True)
         close(y, z[tag + "_y"], rtol=5e-5, what=tag + " y")
+        close(y, z[tag + "_y_compiledflex"], rtol=5e-5, what=tag + " y (compiled FlexAttention)")
         (y * T(z[tag + "_gy"])).sum().backward()
         close(x.grad, z[tag + "_gx"], rtol=1e-4, what=tag + " gx")
         close(p["a.attn_qkv.weight.weight"].grad, z[tag + "_g_qkv"], rtol=2e-4, what=tag + " g_qkv")
