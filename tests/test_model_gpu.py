@@ -150,6 +150,7 @@ def test_g6b_attention_small_heads():
 
 
 WEIGHT_GN_TOL = dict(enc=5e-2, dec=5e-2)      # (tightened to 2x the measured floor below)
+G7_GATE_BOUNDS = dict(enc=(1.0, 1.0), dec=(1.0, 1.0))      # (own-relative, relative to the largest): set from the measurement
 
 
 def test_g7_blocks():
@@ -181,6 +182,16 @@ def test_g7_blocks():
         # gradient of 1e-3 that is the difference of two sums of order 1) -- bounds at 2x
         assert wmax < WEIGHT_GN_TOL[tag], gn
         assert gmax < (0.02 if tag == "enc" else 0.15), gn
+        # the same statement in the form test_cs_shaped_unet_vs_oracle uses for the full nets (SCALAR_GRAD_BOUNDS): error relative to
+        # the parameter's own gradient norm where that is at least 1 % of the block's largest gate gradient norm, relative to that
+        # largest one for all of them
+        refs = {n: float(z[f"{tag}_gn_{n}"]) for n in gn if "gating" in n}
+        top = max(refs.values())
+        own = {n: gn[n] for n in refs if refs[n] >= 1e-2 * top}
+        rtop = {n: gn[n] * refs[n] / top for n in refs}
+        print("g7", tag, "gate gradient norms: worst own-relative", max(own, key=own.get), max(own.values()),
+              "; worst relative to the largest", max(rtop, key=rtop.get), max(rtop.values()))
+        assert max(own.values()) < G7_GATE_BOUNDS[tag][0] and max(rtop.values()) < G7_GATE_BOUNDS[tag][1], (own, rtop)
 
 
 SMALL_CFG = dict(img_resolution=32, img_channels=4, label_dim=4, model_channels=16, channel_mult=[1, 4, 4],
@@ -194,6 +205,9 @@ def build_precond(cfg, seed, sigma_data):
     p = paramgen.prenormalise(paramgen.precond_params(cfg, seed))
     net = Precond(UNet(**cfg), use_fp16=True, sigma_data=sigma_data)
     return load_params(net, p)
+
+
+G8_SCALAR_BOUNDS = {(t_, m_): (1.0, 1.0) for t_ in ("small", "c1") for m_ in ("3d", "2d")}      # set from the measurement
 
 
 @pytest.mark.parametrize("tag,cfg", [("small", SMALL_CFG), ("c1", C1_CFG)])
@@ -245,6 +259,11 @@ def test_g8_unet_loss(tag, cfg):
         gmax = max(refs.values())
         for n, v in refs.items():
             assert abs(prm[n].grad.norm().item() - v) <= 3e-2 * v + 3e-3 * gmax, (n, prm[n].grad.norm().item(), v)
+        own = {n: abs(prm[n].grad.norm().item() - v) / v for n, v in refs.items() if v >= 1e-2 * gmax}
+        rtop = {n: abs(prm[n].grad.norm().item() - v) / gmax for n, v in refs.items()}
+        print("   scalar gradient norms: worst own-relative", max(own, key=own.get), max(own.values()), "; worst relative to the largest",
+              max(rtop, key=rtop.get), max(rtop.values()))
+        assert max(own.values()) < G8_SCALAR_BOUNDS[(tag, mode)][0] and max(rtop.values()) < G8_SCALAR_BOUNDS[(tag, mode)][1]
         unused = set(str(s) for s in z[f"{tag}_{mode}_unused"])
         for n in unused:       # parameters the reference leaves without gradient must not get one here either
             g = prm[n].grad
@@ -417,9 +436,12 @@ GYM_FULL = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=3
                 num_blocks=2, video_attn_resolutions=[8], frame_attn_resolutions=[16])        # gym_train.py:37-47, 46.2 M
 
 
-# (own-relative, relative to the largest gate gradient): 2x the values measured on the MI355X (round 5, profiles/r05_scalar_grads.txt)
-SCALAR_GRAD_BOUNDS = {"cs-shaped": (1.0, 1.0), "cs-full-net": (1.0, 1.0), "gym-full-net": (1.0, 1.0), "gym-full-net-T64": (1.0, 1.0),
-                      "cs-full-net-T32": (1.0, 1.0)}
+# (own-relative, relative to the largest scalar gradient): 2x the values measured on the MI355X against the oracle (round 5,
+# profiles/r05_scalar_grads.txt: own-relative 1.1 % / 1.8 % / 1.4 % / 0.80 % / 0.58 %, relative to the largest 0.14 % / 0.03 % /
+# 0.07 % / 0.07 % / 0.03 %).  At BASELINE configs[1] itself (gym net, T = 64) every gate / emb_gain gradient that matters is
+# within 0.8 % of the oracle's: the error does not grow with the sequence length, it shrinks (more terms per sum).
+SCALAR_GRAD_BOUNDS = {"cs-shaped": (2.2e-2, 2.8e-3), "cs-full-net": (3.6e-2, 6e-4), "gym-full-net": (2.8e-2, 1.4e-3),
+                      "gym-full-net-T64": (1.6e-2, 1.4e-3), "cs-full-net-T32": (1.2e-2, 5.6e-4)}
 
 
 @pytest.mark.parametrize("tag,cfg,Tn,labelled", [("cs-shaped", CS_SMALL, 8, False), ("cs-full-net", CS_FULL, 8, False),
