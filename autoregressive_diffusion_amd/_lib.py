@@ -60,7 +60,7 @@ class AttnArgs(C.Structure):
                 ("mask_mode", c_int32), ("P", c_int32), ("T", c_int32), ("tab_block", c_int32),
                 ("dout", c_void_p), ("doutt", c_void_p), ("delta", c_void_p),
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
-                ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("pad_", c_int32),
+                ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("dkv_item_keys", c_int32),
                 ("sched", c_void_p), ("sched_wgs", c_int32), ("sched_slots", c_int32), ("v_bstride", c_int64),
                 ("k_bstride", c_int64), ("split_ws", c_void_p), ("kv_splits", c_int32), ("pad2_", c_int32)]
 

@@ -1262,7 +1262,7 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
     return ONIRIS_OK;
   }
   // two key streams per workgroup (64 query rows) when the key lists are long and causal, else one (128 rows)
-  const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048 && d.a.pad_ == 0;
+  const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048;
   if (d.a.kv_splits > 1) {                           // split-KV decode: partials + reduction (two launches)
     ONIRIS_CHECK_ARG(d.a.mask_mode == 0 && d.a.split_ws && d.a.kv_splits <= 256,
                      "attn_fwd: kv_splits serves the dense (mask_mode 0) kernel and needs split_ws");
@@ -1338,8 +1338,15 @@ extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t s
                      "attn_bwd_dkv: the scheduled kernel needs the transposed table with <= 64 blocks per row");
     ONIRIS_CHECK_ARG(d.a.Lq % 128 == 0 && d.a.Lq == d.a.Lk && d.a.Lk / 64 < 65536,
                      "attn_bwd_dkv: the scheduled kernel needs Lq == Lk, a multiple of 128 (got %d, %d)", d.a.Lq, d.a.Lk);
-    if (d.a.mask_mode == 1) oniris_launch(attn_bwd_dkv_ws_kernel<1>, dim3(d.a.sched_wgs), dim3(512), stream, d);
-    else oniris_launch(attn_bwd_dkv_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    ONIRIS_CHECK_ARG(d.a.dkv_item_keys == 0 || d.a.dkv_item_keys == 64 || d.a.dkv_item_keys == 128,
+                     "attn_bwd_dkv: dkv_item_keys is 0 / 64 or 128");
+    if (d.a.dkv_item_keys == 128) {
+      if (d.a.mask_mode == 1) oniris_launch(attn_bwd_dkv_ws_kernel<1, 128>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+      else oniris_launch(attn_bwd_dkv_ws_kernel<2, 128>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    } else {
+      if (d.a.mask_mode == 1) oniris_launch(attn_bwd_dkv_ws_kernel<1, 64>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+      else oniris_launch(attn_bwd_dkv_ws_kernel<2, 64>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    }
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }

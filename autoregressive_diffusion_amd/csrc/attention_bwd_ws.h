@@ -22,7 +22,12 @@
 // OnirisAttnArgs.lse / .delta of THIS kernel point at the NEGATED rows (oniris_attn_bwd_prep's `neg` output).
 #pragma once
 
-template <int MODE>
+// KEYS = 128 (round 5): a work item is a whole 128-token table block.  Wave w of the compute waves owns keys [32 w, 32 w + 32) of
+// it against ALL four 32-row sub-blocks of every 128-row query block: 64 MFMAs per wave and block instead of 32, i.e. half the
+// LDS-DMA instructions (the loaders' issue time, which bounds the 64-key form: profiles/r05_pmc_attn_bwd_sq.txt) and half the
+// ring bytes per MFMA, and nothing to merge at the end of an item.  The heaviest item doubles, so the host picks this form only
+// when a workgroup's average load is well above it (ops._attn_core_bwd: B = 8 at the bench shape, not B = 2).
+template <int MODE, int KEYS = 64>
 __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TQ = 128 * 128;                    // one tile: 128 rows x 128 B (64 channels of a head)
@@ -50,9 +55,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     struct Src { i32x4 rs_q, rs_do, rs_l, rs_d; int qvo, nblk, qvl; };
     auto open_item = [&](int itm) __attribute__((always_inline)) {
       Src s;
-      const int pair = itm >> 16, kb64 = itm & 0xffff;
+      const int pair = itm >> 16, kb64 = itm & 0xffff;                // (KEYS = 128: the index of the 128-key block)
       const int b = pair / a.heads, head = pair - b * a.heads;
-      const int trow = (kb64 >> 1) >> d.tshift;
+      const int trow = (KEYS == 128 ? kb64 : (kb64 >> 1)) >> d.tshift;
       const int nent = __builtin_amdgcn_readfirstlane(a.q_num[trow]);
       s.nblk = nent << d.tshift;
       s.qvl = (lane < nent) ? a.q_idx[(size_t)trow * a.qtab_cols + lane] : 0;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
   }
 
   // -------------------------------------------------------------------------------------------------- compute waves
-  const int kh = wave & 1, qh = wave >> 1;
+  const int kh = (KEYS == 128) ? wave : (wave & 1), qh = (KEYS == 128) ? 0 : (wave >> 1);
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
   typedef __attribute__((ext_vector_type(8))) short s16x8;
 
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     int le = lane;
     asm volatile("" : "+v"(le));
     const int r = le & 31, h = le >> 5;
-    const int kw0 = kb64 * 64 + kh * 32;
+    const int kw0 = kb64 * KEYS + kh * 32;
     const int krow = kw0 + r;
     const int rr0 = r * 128 + ((h ^ ((((r >> 1) & 1) << 2) | (((r >> 3) & 1) << 1) | ((r >> 2) & 1))) << 4);
     // transposing reads: lane (grp, q4, p) takes row tokbase + 4 hh + q4 (+ 8 for the second read), logical bytes
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
 
-    const int trow = (kb64 >> 1) >> d.tshift;
+    const int trow = (KEYS == 128 ? kb64 : (kb64 >> 1)) >> d.tshift;
     const int nent = __builtin_amdgcn_readfirstlane(a.q_num[trow]);
     const int nblk = nent << d.tshift, nb = nblk > 0 ? nblk : 1;
     const int qvl = (lane < nent) ? a.q_idx[(size_t)trow * a.qtab_cols + lane] : 0;
@@ -262,10 +267,18 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     auto block = [&](auto first_, int j) __attribute__((always_inline)) {
       const unsigned char* S0 = smem + (j & 3) * SLOT;
       const int q0 = q_start(j);
-      stageA(first_, sA, dpA, S0, trw0, q0);
-      stageBC(sA, dpA, S0, trw0);
-      stageA(first_, sA, dpA, S0, trw1, q0);
-      stageBC(sA, dpA, S0, trw1);
+      if constexpr (KEYS == 128) {
+#pragma unroll
+        for (int trw = 0; trw < 128; trw += 32) {
+          stageA(first_, sA, dpA, S0, trw, q0);
+          stageBC(sA, dpA, S0, trw);
+        }
+      } else {
+        stageA(first_, sA, dpA, S0, trw0, q0);
+        stageBC(sA, dpA, S0, trw0);
+        stageA(first_, sA, dpA, S0, trw1, q0);
+        stageBC(sA, dpA, S0, trw1);
+      }
     };
     __syncthreads();                               // barrier_0: blocks 0 and 1 landed
     if (work) block(std::true_type{}, 0);
@@ -276,9 +289,9 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     }
 
     // ---- epilogue: the two query halves of a key half meet in ring slot 3 (2 x 16 KB), wave (kh, 0) writes dK, dV
-    float* red = (float*)(smem + 3 * SLOT) + kh * 4096 + le;       // [kh][64 registers][64 lanes]
+    float* red = (float*)(smem + 3 * SLOT) + (kh & 1) * 4096 + le;       // [kh][64 registers][64 lanes]
     __syncthreads();                               // E1: every compute wave is done with the ring
-    if (qh == 1) {
+    if (KEYS == 64 && qh == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         red[i * 64] = dk[0][i]; red[(16 + i) * 64] = dk[1][i];
@@ -287,10 +300,12 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv_ws_kernel(const AttnDev d
     }
     __syncthreads();                               // E2
     if (qh == 0 && krow < Lk) {
+      if constexpr (KEYS == 64) {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        dk[0][i] += red[i * 64]; dk[1][i] += red[(16 + i) * 64];
-        dv[0][i] += red[(32 + i) * 64]; dv[1][i] += red[(48 + i) * 64];
+        for (int i = 0; i < 16; ++i) {
+          dk[0][i] += red[i * 64]; dk[1][i] += red[(16 + i) * 64];
+          dv[0][i] += red[(32 + i) * 64]; dv[1][i] += red[(48 + i) * 64];
+        }
       }
       bf16* dkg = (bf16*)a.dk + ((size_t)b * Lk + krow) * C + head * 64;
       bf16* dvg = (bf16*)a.dv + ((size_t)b * Lk + krow) * C + head * 64;

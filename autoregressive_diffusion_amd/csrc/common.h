@@ -55,6 +55,23 @@ static inline void oniris_launch(K kern, dim3 grid, dim3 block, hipStream_t stre
   }
 }
 
+// Streaming loads / stores of the HBM-bound passes (elementwise.hip, gconv_bwd_fused): tensors far larger than the caches are
+// read and written exactly once per pass -- the non-temporal policy (no retention in L2 / the Infinity Cache) measured +10 %
+// on act_bwd's 3-reads-1-write mix at 268 MB per tensor (scratch/ubench/ew_mix.hip: 5.84 -> 6.45 TB/s).  NT is chosen on the
+// host per launch: tensors of at least oniris_ew_nt_bytes() bytes (ONIRIS_EW_NT_MB, default 96; smaller ones may still be in
+// the 256 MB Infinity Cache when their consumer runs).
+long long oniris_ew_nt_bytes(void);
+template <bool NT, typename V>
+__device__ __forceinline__ V ldv(const V* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void stv(V* p, V v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // Persistent launches (one workgroup per CU: conv_glds.h, conv1x1_glds.h; the attention work lists are sized by the caller):
 // the CU count of the current device minus oniris_set_cu_reserve()'s k -- CUs left to the collective library's kernels while
 // a gradient exchange is in flight (a persistent workgroup that finds its CU's LDS taken waits for a whole other workgroup

@@ -23,7 +23,7 @@ __device__ __forceinline__ float dsilu_f(float z) {
 // rs != 0: x is resampled on the way in (Block.forward resamples before anything else, networks_edm2.py:63): rs = 1 the
 // 2x2 mean, rs = 2 nearest x2, Ho x Wo = the OUTPUT grid (= the grid of pix); the resampled value is rounded to bf16 first,
 // exactly what the separate resample pass stored.
-template <bool NORM>
+template <bool NORM, bool NT>
 __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x, const bf16* __restrict__ skip,
                                                       bf16* __restrict__ xo, bf16* __restrict__ a,
                                                       float* __restrict__ sden, long long npix, int C1, int C2, float w1,
@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x
     float w;
     if (c < C1) {
       w = w1;
-      if (rs == 0) in = *(const bf16x8*)(x + pix * C1 + c);
+      if (rs == 0) in = ldv<NT>((const bf16x8*)(x + pix * C1 + c));
       else {
         const int xo_ = (int)(pix % Wo), yo_ = (int)((pix / Wo) % Ho);
         const long long n = pix / ((long long)Wo * Ho);
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x
         }
       }
     }
-    else { in = *(const bf16x8*)(skip + pix * C2 + (c - C1)); w = w2; }
+    else { in = ldv<NT>((const bf16x8*)(skip + pix * C2 + (c - C1))); w = w2; }
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = bf2f(in[i]) * w;
   }
@@ -88,14 +88,14 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const bf16* __restrict__ x
     o[i] = f2bf(v[i]);
     av[i] = f2bf(silu_f(bf2f(o[i])) * SILU_SCALE);
   }
-  if (xo) *(bf16x8*)(xo + pix * C + cg * 8) = o;
-  *(bf16x8*)(a + pix * C + cg * 8) = av;
+  if (xo) stv<NT>((bf16x8*)(xo + pix * C + cg * 8), o);
+  stv<NT>((bf16x8*)(a + pix * C + cg * 8), av);
 }
 
 // g = dxo + da * silu'(xo)/0.596 ; NORM: g <- (g - xo * sum(g*xo) * k) / s ; dx = w1*g[:C1] (+ dadd), dskip = w2*g[C1:]
 // dadd: a second gradient of x that is already complete (the decoder's gradient of an encoder output that is also a skip
 // connection): added here instead of by a separate pass over the three tensors
-template <bool NORM>
+template <bool NORM, bool NT>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ da, const bf16* __restrict__ dxo,
                                                       const bf16* __restrict__ xo, const float* __restrict__ sden,
                                                       bf16* __restrict__ dx, bf16* __restrict__ dskip,
@@ -110,12 +110,12 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ d
 #pragma unroll
   for (int i = 0; i < 8; ++i) { g[i] = 0.f; xv[i] = 0.f; }
   if (ok) {
-    const bf16x8 xin = *(const bf16x8*)(xo + pix * C + cg * 8);
-    const bf16x8 dain = *(const bf16x8*)(da + pix * C + cg * 8);
+    const bf16x8 xin = ldv<NT>((const bf16x8*)(xo + pix * C + cg * 8));
+    const bf16x8 dain = ldv<NT>((const bf16x8*)(da + pix * C + cg * 8));
 #pragma unroll
     for (int i = 0; i < 8; ++i) { xv[i] = bf2f(xin[i]); g[i] = bf2f(dain[i]) * dsilu_f(xv[i]) * SILU_SCALE; }
     if (dxo) {
-      const bf16x8 d2 = *(const bf16x8*)(dxo + pix * C + cg * 8);
+      const bf16x8 d2 = ldv<NT>((const bf16x8*)(dxo + pix * C + cg * 8));
 #pragma unroll
       for (int i = 0; i < 8; ++i) g[i] += bf2f(d2[i]);
     }
@@ -138,18 +138,18 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ d
   bf16x8 o;
   if (c < C1) {
     if (dadd) {
-      const bf16x8 d3 = *(const bf16x8*)(dadd + pix * C1 + c);
+      const bf16x8 d3 = ldv<NT>((const bf16x8*)(dadd + pix * C1 + c));
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w1 + bf2f(d3[i]));
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w1);
     }
-    *(bf16x8*)(dx + pix * C1 + c) = o;
+    stv<NT>((bf16x8*)(dx + pix * C1 + c), o);
   } else {
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = f2bf(g[i] * w2);
-    *(bf16x8*)(dskip + pix * C2 + (c - C1)) = o;
+    stv<NT>((bf16x8*)(dskip + pix * C2 + (c - C1)), o);
   }
 }
 
@@ -165,8 +165,11 @@ extern "C" int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a
   ONIRIS_CHECK_ARG(!norm || ((C / 8) <= 64 && ((C / 8) & (C / 8 - 1)) == 0 && sden), "act_fwd: pixel norm needs C/8 = 2^k <= 64");
   const long long nthr = npix * (C / 8);
   const dim3 grid((unsigned)((nthr + 255) / 256));
-  if (norm) hipLaunchKernelGGL(act_fwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2, resample, Ho, Wo);
-  else hipLaunchKernelGGL(act_fwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2, resample, Ho, Wo);
+  const bool nt = (long long)npix * C * 2 >= oniris_ew_nt_bytes();
+#define ACT_FWD_LAUNCH(NORM_, NT_) hipLaunchKernelGGL((act_fwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2, resample, Ho, Wo)
+  if (norm) { if (nt) ACT_FWD_LAUNCH(true, true); else ACT_FWD_LAUNCH(true, false); }
+  else { if (nt) ACT_FWD_LAUNCH(false, true); else ACT_FWD_LAUNCH(false, false); }
+#undef ACT_FWD_LAUNCH
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -181,8 +184,11 @@ extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, c
   ONIRIS_CHECK_ARG(!norm || ((C / 8) <= 64 && ((C / 8) & (C / 8 - 1)) == 0 && sden), "act_bwd: pixel norm needs C/8 = 2^k <= 64");
   const long long nthr = npix * (C / 8);
   const dim3 grid((unsigned)((nthr + 255) / 256));
-  if (norm) hipLaunchKernelGGL(act_bwd_kernel<true>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2);
-  else hipLaunchKernelGGL(act_bwd_kernel<false>, grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2);
+  const bool nt = (long long)npix * C * 2 >= oniris_ew_nt_bytes();
+#define ACT_BWD_LAUNCH(NORM_, NT_) hipLaunchKernelGGL((act_bwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2)
+  if (norm) { if (nt) ACT_BWD_LAUNCH(true, true); else ACT_BWD_LAUNCH(true, false); }
+  else { if (nt) ACT_BWD_LAUNCH(false, true); else ACT_BWD_LAUNCH(false, false); }
+#undef ACT_BWD_LAUNCH
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -190,6 +196,7 @@ extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, c
 // ---------------------------------------------------------------------------------------------------------------
 // u = silu(y*c)/0.596:  dz = du*silu'(y*c)/0.596 ; dy = dz*c ; dc[n][co] += sum_pixels dz*y
 // grid = (frames, pixel slices); threads: channel group = tid % G, pixel lane = tid / G
+template <bool NT>
 __global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restrict__ du, const bf16* __restrict__ y,
                                                            const float* __restrict__ c, bf16* __restrict__ dy,
                                                            float* __restrict__ dc, int P, int C, int pix_per_block,
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restric
     const int p1 = min(P, p0 + pix_per_block);
     for (int p = p0 + pl; p < p1; p += npl) {
       const size_t off = ((size_t)n * P + p) * C + cg * 8;
-      const bf16x8 duv = *(const bf16x8*)(du + off), yv = *(const bf16x8*)(y + off);
+      const bf16x8 duv = ldv<NT>((const bf16x8*)(du + off)), yv = ldv<NT>((const bf16x8*)(y + off));
       bf16x8 o;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -218,7 +225,7 @@ __global__ __launch_bounds__(256) void emb_silu_bwd_kernel(const bf16* __restric
         o[i] = f2bf(dz * cv[i]);
         part[i] += dz * yy;
       }
-      *(bf16x8*)(dy + off) = o;
+      stv<NT>((bf16x8*)(dy + off), o);
     }
     if ((G & (G - 1)) != 0) {                        // (channel groups not a power of two: every lane adds its own)
 #pragma unroll
@@ -264,21 +271,26 @@ extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c
   if (!dc_is_zero) hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
   const int cp = c_pitch > 0 ? c_pitch : C;
   ONIRIS_CHECK_ARG(cp >= C && cp % 4 == 0, "emb_silu_bwd: c_pitch must be a multiple of 4 and >= C");
-  hipLaunchKernelGGL(emb_silu_bwd_kernel, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
-                     (bf16*)dy, dc, P, C, ppb, cp);
+  if ((long long)N * P * C * 2 >= oniris_ew_nt_bytes())
+    hipLaunchKernelGGL(emb_silu_bwd_kernel<true>, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
+                       (bf16*)dy, dc, P, C, ppb, cp);
+  else
+    hipLaunchKernelGGL(emb_silu_bwd_kernel<false>, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
+                       (bf16*)dy, dc, P, C, ppb, cp);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // out = clip(ta*res + tb*v): given g = d out  ->  dres = ta*g*[|out|<clip], dv = tb*g*[|out|<clip]
+template <bool NT>
 __global__ void mpsum_bwd_kernel(const bf16* __restrict__ g, const bf16* __restrict__ out, bf16* __restrict__ dres,
                                  bf16* __restrict__ dv, size_t n8, float ta, float tb, float clip) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
-    const bf16x8 gv = *(const bf16x8*)(g + i * 8);
+    const bf16x8 gv = ldv<NT>((const bf16x8*)(g + i * 8));
     bf16x8 a, b;
     if (clip > 0.f) {
-      const bf16x8 ov = *(const bf16x8*)(out + i * 8);
+      const bf16x8 ov = ldv<NT>((const bf16x8*)(out + i * 8));
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const float gg = (fabsf(bf2f(ov[k])) < clip) ? bf2f(gv[k]) : 0.f;
@@ -288,8 +300,8 @@ __global__ void mpsum_bwd_kernel(const bf16* __restrict__ g, const bf16* __restr
 #pragma unroll
       for (int k = 0; k < 8; ++k) { const float gg = bf2f(gv[k]); a[k] = f2bf(gg * ta); b[k] = f2bf(gg * tb); }
     }
-    *(bf16x8*)(dres + i * 8) = a;
-    *(bf16x8*)(dv + i * 8) = b;
+    stv<NT>((bf16x8*)(dres + i * 8), a);
+    stv<NT>((bf16x8*)(dv + i * 8), b);
   }
 }
 
@@ -300,8 +312,12 @@ extern "C" int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void
   const size_t n8 = (size_t)numel / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 8192) nb = 8192;
-  hipLaunchKernelGGL(mpsum_bwd_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
-                     (bf16*)dres, (bf16*)dv, n8, ta, tb, clip);
+  if (numel * 2 >= oniris_ew_nt_bytes())
+    hipLaunchKernelGGL(mpsum_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
+                       (bf16*)dres, (bf16*)dv, n8, ta, tb, clip);
+  else
+    hipLaunchKernelGGL(mpsum_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
+                       (bf16*)dres, (bf16*)dv, n8, ta, tb, clip);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

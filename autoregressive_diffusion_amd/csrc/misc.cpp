@@ -1,3 +1,4 @@
+#include <cstdlib>
 // Host-only pieces of liboniris_hip.so: error string, ABI version, mask tables, attention schedule.
 #include <stdarg.h>
 #include <stdio.h>
@@ -32,6 +33,16 @@ extern "C" int oniris_profile_disarm(void) {          // 1: the pair was still a
   return armed;
 }
 extern "C" int oniris_abi_version(void) { return 12; }
+
+long long oniris_ew_nt_bytes(void) {
+  static long long v = -1;
+  if (v < 0) {
+    const char* e = getenv("ONIRIS_EW_NT_MB");
+    const long long mb = e ? atoll(e) : 96;
+    v = mb <= 0 ? (1LL << 62) : mb * (1LL << 20);          // 0 / negative: never
+  }
+  return v;
+}
 
 int oniris_cu_reserve = 0;
 int oniris_persistent_wgs(void) {

@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_prep_kernel(const bf16* __restr
 //   mode 1 (EPI_EMB_SILU): g = d u, u = silu(y*c)/0.596  ->  dout = g*silu'(y*c)/0.596*c ; dc[n][co] += sum_pixels(...)*y
 //   mode 2 (EPI_MPSUM):    g = d out, out = clip(ta*res + tb*v) -> dres = ta*g*mask ; dout = tb*g*mask
 // then S1/S2/dy3 exactly as gconv_bwd_prep_kernel.  raw = y (mode 1) or v (mode 2).
-template <int MODE>
+template <int MODE, bool NT>
 __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* g, const bf16* __restrict__ raw,
                                                               const bf16* __restrict__ y3, const float* __restrict__ ca,
                                                               const float* __restrict__ cb, const float* __restrict__ cs,
@@ -505,18 +505,18 @@ __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* g, co
     const int p0 = blockIdx.y * pix_per_block, p1 = min(P, p0 + pix_per_block);
     for (int p = p0 + pl; p < p1; p += npl) {
       const size_t off = (size_t)p * C + cg * 8;
-      const bf16x8 yv3 = *(const bf16x8*)(y3 + (size_t)bt * PC + off);
+      const bf16x8 yv3 = ldv<NT>((const bf16x8*)(y3 + (size_t)bt * PC + off));
       float acc3[8];
 #pragma unroll
       for (int i = 0; i < 8; ++i) acc3[i] = 0.f;
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         const size_t o = nn[s] * PC + off;
-        const bf16x8 gv = *(const bf16x8*)(g + o);
-        const bf16x8 rv = *(const bf16x8*)(raw + o);
+        const bf16x8 gv = ldv<NT>((const bf16x8*)(g + o));
+        const bf16x8 rv = ldv<NT>((const bf16x8*)(raw + o));
         bf16x8 dv, drv;
         bf16x8 xv;
-        if (masked) xv = *(const bf16x8*)(xo + o);
+        if (masked) xv = ldv<NT>((const bf16x8*)(xo + o));
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           const float r_ = bf2f(rv[i]);
@@ -538,13 +538,13 @@ __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* g, co
           if (!alias) { dv[i] = f2bf(d); dr = bf2f(dv[i]); }      // else: the rounded value is what dgrad / wgrad will consume
           s1[s] += dr * r_; s2[s] += dr * bf2f(yv3[i]); acc3[i] += cbv[s] * dr;
         }
-        if (!alias || masked) *(bf16x8*)(dout + o) = dv;       // (aliasing + masked: dout IS g -- every element is read
-        if (MODE == 2) *(bf16x8*)(dres + o) = drv;             //  and rewritten by the same lane)
+        if (!alias || masked) stv<NT>((bf16x8*)(dout + o), dv);   // (aliasing + masked: dout IS g -- every element is read
+        if (MODE == 2) stv<NT>((bf16x8*)(dres + o), drv);         //  and rewritten by the same lane)
       }
       bf16x8 o3;
 #pragma unroll
       for (int i = 0; i < 8; ++i) o3[i] = f2bf(acc3[i]);
-      *(bf16x8*)(dy3 + (size_t)bt * PC + off) = o3;
+      stv<NT>((bf16x8*)(dy3 + (size_t)bt * PC + off), o3);
     }
     if (MODE == 1 && (G8 & (G8 - 1)) != 0) {                      // (channel groups not a power of two: every lane adds its own)
 #pragma unroll
@@ -611,15 +611,13 @@ extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, 
   const int ppb = cdiv(P, slices);
   const int csp = cscale_pitch > 0 ? cscale_pitch : C;
   ONIRIS_CHECK_ARG(csp >= C && csp % 4 == 0, "gconv_bwd_fused: cscale_pitch must be a multiple of 4 and >= C");
-  if (mode == 1)
-    hipLaunchKernelGGL(gconv_bwd_fused_kernel<1>, dim3(B * T, slices), dim3(nth), 0, stream, (const bf16*)g,
-                       (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
-                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp, nullptr, nullptr);
-  else
-    hipLaunchKernelGGL(gconv_bwd_fused_kernel<2>, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)g,
-                       (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout,
-                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp,
-                       (const int*)clip_flag, coef_own_scaled);
+  const bool nt = 2LL * B * T * P * C * 2 >= oniris_ew_nt_bytes();       // (the gradient tensor: both slots)
+#define GCONV_BWD_LAUNCH(MODE_, NT_, NTH_, FLAG_, CAS_) hipLaunchKernelGGL((gconv_bwd_fused_kernel<MODE_, NT_>), dim3(B * T, slices), dim3(NTH_), 0, stream, (const bf16*)g, \
+                       (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout, \
+                       (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp, FLAG_, CAS_)
+  if (mode == 1) { if (nt) GCONV_BWD_LAUNCH(1, true, nth, nullptr, nullptr); else GCONV_BWD_LAUNCH(1, false, nth, nullptr, nullptr); }
+  else { if (nt) GCONV_BWD_LAUNCH(2, true, 256, (const int*)clip_flag, coef_own_scaled); else GCONV_BWD_LAUNCH(2, false, 256, (const int*)clip_flag, coef_own_scaled); }
+#undef GCONV_BWD_LAUNCH
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -1382,11 +1382,32 @@ def _train_sched(T, P, n_pairs, dev, which):
     if which == "fwd":
         per = blk // 128
         w = np.repeat(num * per + 1, per)                    # a table row of `blk` tokens = per 128-row query blocks
-    else:                                                    # items of 64 keys: 2 per 128-token block, whole query list each
+    elif which == "dkv":                                     # items of 64 keys: 2 per 128-token block, whole query list each
         qn, _ = mask_transpose(num, idx)
         per = blk // 128
         w = np.repeat(qn * per + 1, 2 * per)
+    else:                                                    # 'dkv128': items of 128 keys (twice the work per listed block)
+        qn, _ = mask_transpose(num, idx)
+        per = blk // 128
+        w = np.repeat(qn * per + 1, per)
     return attn_schedule(w, n_pairs, dev)
+
+
+DKV_ITEM_KEYS = int(_os.environ.get("ONIRIS_DKV_ITEM_KEYS", "0"))     # 64 / 128: force the dK/dV item size (A/B, tests); 0: by load
+
+
+def _dkv_item_keys(T, P, n_pairs, dev):
+    """128-key items for the persistent dK/dV kernel when the launch has enough of them: the heaviest item (the first key block:
+    every later query block attends it) must stay well below a workgroup's average load, or the launch takes as long as that
+    one item (C2 at B = 2: 8 pairs x 64 items of up to 64 units on 256 workgroups = 35 units on average -> 64-key items;
+    B = 8: 140 on average -> 128-key items)."""
+    if DKV_ITEM_KEYS in (64, 128):
+        return DKV_ITEM_KEYS
+    num, idx, blk = train_mask_table(T, P)
+    qn, _ = mask_transpose(num, idx)
+    w = qn * (blk // 128) + 1
+    n_wg = max(8, (_cu_count.get(str(dev)) or torch.cuda.get_device_properties(dev).multi_processor_count) - _cu_reserve)
+    return 128 if float(w.sum()) * (blk // 128) * n_pairs / n_wg >= 1.5 * float(w.max()) else 64
 
 
 def _attn_core_fwd(qr, kr, v, kind, B, T, heads, P):
@@ -1449,8 +1470,10 @@ def _attn_core_bwd(qr, kr, v, out, lse, dout, tabs, meta):
     if dkv_ws:
         # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
         # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch); it reads the NEGATED row constants
-        sched = _train_sched(T, P, Bq * heads, dev, "dkv")
+        keys = _dkv_item_keys(T, P, Bq * heads, dev)
+        sched = _train_sched(T, P, Bq * heads, dev, "dkv128" if keys == 128 else "dkv")
         a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
+        a.dkv_item_keys = keys
         a.lse, a.delta = _p(neg[0]), _p(neg[1])
         _profiled(f"attn_bwd_dkv_ws_kernel<MODE={mask_mode}>", 2.0 * fl,
                   lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))

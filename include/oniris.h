@@ -433,7 +433,12 @@ typedef struct OnirisAttnArgs {
    * fp32 partial sums to dkv_part [2 (dk|dv)][chunks][B][Lk][C]; a second kernel adds them in chunk order
    * (deterministic, no atomics) and writes the bf16 dk, dv.  0 / 1: one workgroup per key block, no scratch.       */
   float* dkv_part;
-  int32_t dkv_chunks, pad_;
+  /* dkv_item_keys (scheduled dK/dV launch only; ABI 12, was padding): keys per work item of `sched` -- 0 / 64: half a 128-token
+   * table block per item (two query halves per key half: the two halves of a workgroup meet through LDS at the end), 128: a
+   * whole table block per item, every compute wave owns 32 keys against all 128 rows of a query block -- half the LDS-DMA
+   * bytes and instructions per MFMA, no merge; needs enough items per workgroup for the heaviest one not to dominate
+   * (the caller decides from the schedule's weights).                                                                  */
+  int32_t dkv_chunks, dkv_item_keys;
   /* static balanced schedule for the persistent kernels (oniris_attn_schedule): device int32 [sched_wgs][sched_slots],
    * entry = (pair << 16) | block with pair = b * heads + head, or -1.  NULL: one workgroup per block (grid kernels).   */
   const int32_t* sched;
