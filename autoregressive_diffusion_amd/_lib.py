@@ -112,7 +112,8 @@ _SIGS = {
     "oniris_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float,
                                c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
-                               c_float, c_float, c_int, c_void_p]),
+                               c_float, c_float, c_int, c_float, c_void_p]),
+    "oniris_mpsum_mask": (c_int, [c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "oniris_emb_silu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p]),
     "oniris_mpsum_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p]),

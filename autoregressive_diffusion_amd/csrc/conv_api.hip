@@ -18,6 +18,12 @@ extern "C" int oniris_conv_fwd(const OnirisConvArgs* args, oniris_stream_t strea
   ONIRIS_CHECK_ARG(a.epi != ONIRIS_EPI_EMB_SILU || (a.escale && a.out2), "conv_fwd: EPI_EMB_SILU needs escale/out2");
   const bool has_ctx = a.ctx != nullptr;
   ONIRIS_CHECK_ARG(!has_ctx || (a.w_ctx && a.taps == 9), "conv_fwd: context path needs w_ctx and taps == 9");
+  // clip_flag is answered by the LDS-DMA / streaming 3x3 kernels of the training layouts only (conv_dispatch_s2ctx, _s1); every
+  // other variant reports "assume clipped", which is always correct for the backward (it then reads the clipped output)
+  if (a.clip_flag && (a.taps == 1 || (a.S == 1 && has_ctx))) {
+    const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.clip_flag, 1, 1, st);
+    if (e != hipSuccess) { oniris_set_error("conv: clip_flag fill failed: %s", hipGetErrorString(e)); return ONIRIS_ELAUNCH; }
+  }
   if (a.taps == 1) {
     ONIRIS_CHECK_ARG(a.S == 1, "conv_fwd: 1x1 variant expects S == 1 (fold slots into T)");
     return conv_dispatch_1x1(a, st);

@@ -14,6 +14,10 @@ int conv_dispatch_s1(const OnirisConvArgs& a, hipStream_t st) {
     if (a.W == 8 && a.H == 8 && a.CoutP % 64 == 0 && conv_glds_ok(a, 8, 8, 64, true))
       return launch_conv_glds<1, 8, 8, 1, 2, false>(b, st);
   }
+  if (a.clip_flag) {       // the register-staged kernels do not report clips: "assume clipped" (see conv_dispatch_s2ctx)
+    const hipError_t e = hipMemsetD32Async((hipDeviceptr_t)a.clip_flag, 1, 1, st);
+    if (e != hipSuccess) { oniris_set_error("conv: clip_flag fill failed: %s", hipGetErrorString(e)); return ONIRIS_ELAUNCH; }
+  }
   return conv3x3_pick<1, false>(a, st);
 }
 int conv_dispatch_1x1(const OnirisConvArgs& a, hipStream_t st) {

@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ d
                                                       const bf16* __restrict__ xo, const float* __restrict__ sden,
                                                       bf16* __restrict__ dx, bf16* __restrict__ dskip,
                                                       const bf16* __restrict__ dadd, long long npix,
-                                                      int C1, int C2, float w1, float w2) {
+                                                      int C1, int C2, float w1, float w2, float dxo_scale) {
   const int C = C1 + C2, G = C >> 3;
   const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long pix = gid / G;
@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const bf16* __restrict__ d
     if (dxo) {
       const bf16x8 d2 = ldv<NT>((const bf16x8*)(dxo + pix * C + cg * 8));
 #pragma unroll
-      for (int i = 0; i < 8; ++i) g[i] += bf2f(d2[i]);
+      for (int i = 0; i < 8; ++i) g[i] += dxo_scale * bf2f(d2[i]);
     }
   }
   if (NORM) {
@@ -176,7 +176,7 @@ extern "C" int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a
 
 extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
                               const void* dadd, int64_t npix, int C1, int C2, float w1, float w2, int norm,
-                              oniris_stream_t stream_) {
+                              float dxo_scale, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const int C = C1 + C2;
   ONIRIS_CHECK_ARG(da && xo && dx && npix > 0 && C1 > 0 && C1 % 8 == 0 && C2 >= 0 && C2 % 8 == 0 && (C2 == 0 || dskip),
@@ -185,7 +185,7 @@ extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, c
   const long long nthr = npix * (C / 8);
   const dim3 grid((unsigned)((nthr + 255) / 256));
   const bool nt = (long long)npix * C * 2 >= oniris_ew_nt_bytes();
-#define ACT_BWD_LAUNCH(NORM_, NT_) hipLaunchKernelGGL((act_bwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2)
+#define ACT_BWD_LAUNCH(NORM_, NT_) hipLaunchKernelGGL((act_bwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2, dxo_scale)
   if (norm) { if (nt) ACT_BWD_LAUNCH(true, true); else ACT_BWD_LAUNCH(true, false); }
   else { if (nt) ACT_BWD_LAUNCH(false, true); else ACT_BWD_LAUNCH(false, false); }
 #undef ACT_BWD_LAUNCH
@@ -301,14 +301,14 @@ __global__ void mpsum_bwd_kernel(const bf16* __restrict__ g, const bf16* __restr
       for (int k = 0; k < 8; ++k) { const float gg = bf2f(gv[k]); a[k] = f2bf(gg * ta); b[k] = f2bf(gg * tb); }
     }
     stv<NT>((bf16x8*)(dres + i * 8), a);
-    stv<NT>((bf16x8*)(dv + i * 8), b);
+    if (dv) stv<NT>((bf16x8*)(dv + i * 8), b);
   }
 }
 
 extern "C" int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv, int64_t numel, float ta, float tb,
                                 float clip, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  ONIRIS_CHECK_ARG(g && dres && dv && numel > 0 && numel % 8 == 0 && (clip <= 0.f || out), "mpsum_bwd: bad arguments");
+  ONIRIS_CHECK_ARG(g && dres && numel > 0 && numel % 8 == 0 && (clip <= 0.f || out), "mpsum_bwd: bad arguments");
   const size_t n8 = (size_t)numel / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 8192) nb = 8192;
@@ -318,6 +318,37 @@ extern "C" int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void
   else
     hipLaunchKernelGGL(mpsum_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
                        (bf16*)dres, (bf16*)dv, n8, ta, tb, clip);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// The aliasing protocol for a PLAIN conv with the mp_sum + clip epilogue (the 2-D training steps' conv_res1): dv = tb * g * mask and
+// dres = ta * g * mask are scaled copies of g, so nothing is written -- dgrad / wgrad read g with the coefficient tb, the
+// residual's consumer with the scale ta -- unless the forward really clipped something (OnirisConvArgs.clip_flag != 0): only
+// then this launch reads the clipped output and masks g IN PLACE (g must be a buffer this backward owns).  Flag clear: every
+// thread leaves after one scalar load.
+__global__ void mpsum_mask_kernel(bf16* __restrict__ g, const bf16* __restrict__ out, size_t n8, float clip,
+                                  const int* __restrict__ flag) {
+  if (*flag == 0) return;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+    bf16x8 gv = *(const bf16x8*)(g + i * 8);
+    const bf16x8 ov = *(const bf16x8*)(out + i * 8);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (!(fabsf(bf2f(ov[k])) < clip)) gv[k] = f2bf(0.f);
+    *(bf16x8*)(g + i * 8) = gv;
+  }
+}
+
+extern "C" int oniris_mpsum_mask(void* g, const void* out, int64_t numel, float clip, const int32_t* clip_flag,
+                                 oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(g && out && clip_flag && clip > 0.f && numel > 0 && numel % 8 == 0, "mpsum_mask: bad arguments");
+  const size_t n8 = (size_t)numel / 8;
+  size_t nb = (n8 + 255) / 256;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(mpsum_mask_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (bf16*)g, (const bf16*)out, n8, clip,
+                     (const int*)clip_flag);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -469,7 +469,7 @@ __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* g, co
                                                               const int* __restrict__ clip_flag, float* __restrict__ ca_scaled) {
   // mode 2, aliasing protocol (include/oniris.h): dgrad / wgrad read g itself with tb folded into the own-frame coefficient;
   // only a forward that really clipped something makes this pass read xo and write the masked gradient (in place)
-  const bool alias = MODE == 2 && clip_flag != nullptr;
+  const bool alias = MODE == 2 && ca_scaled != nullptr;
   const bool masked = MODE == 2 && clip > 0.f && (!alias || *clip_flag != 0);
   __shared__ float red[16];
   __shared__ float accs[2][512];
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(1024) void gconv_bwd_fused_kernel(const bf16* g, co
           s1[s] += dr * r_; s2[s] += dr * bf2f(yv3[i]); acc3[i] += cbv[s] * dr;
         }
         if (!alias || masked) stv<NT>((bf16x8*)(dout + o), dv);   // (aliasing + masked: dout IS g -- every element is read
-        if (MODE == 2) stv<NT>((bf16x8*)(dres + o), drv);         //  and rewritten by the same lane)
+        if (MODE == 2 && dres) stv<NT>((bf16x8*)(dres + o), drv); //  and rewritten by the same lane)
       }
       bf16x8 o3;
 #pragma unroll
@@ -590,10 +590,12 @@ extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, 
   ONIRIS_CHECK_ARG((mode == 1 || mode == 2) && g && raw && y3 && coef_own && coef_ctx && dout && dy3 && d_coef_own &&
                    d_coef_ctx && B > 0 && T > 0 && P > 0 && C % 8 == 0 && C <= 512, "gconv_bwd_fused: bad arguments");
   ONIRIS_CHECK_ARG(mode != 1 || (cscale && d_cscale), "gconv_bwd_fused: mode 1 needs cscale / d_cscale");
-  ONIRIS_CHECK_ARG(mode != 2 || (dres && (clip <= 0.f || xo)), "gconv_bwd_fused: mode 2 needs dres (and xo when clipping)");
-  ONIRIS_CHECK_ARG((clip_flag == nullptr) == (coef_own_scaled == nullptr) && (mode == 2 || !clip_flag),
-                   "gconv_bwd_fused: clip_flag and coef_own_scaled come together, in mode 2");
-  ONIRIS_CHECK_ARG(!clip_flag || dout == g, "gconv_bwd_fused: the aliasing protocol masks g in place (pass dout = g)");
+  ONIRIS_CHECK_ARG(mode != 2 || ((dres || coef_own_scaled) && (clip <= 0.f || xo)),
+                   "gconv_bwd_fused: mode 2 needs dres (optional under the aliasing protocol) and xo when clipping");
+  ONIRIS_CHECK_ARG((mode == 2 || (!clip_flag && !coef_own_scaled)) && (!clip_flag || coef_own_scaled) &&
+                   (!coef_own_scaled || clip <= 0.f || clip_flag),
+                   "gconv_bwd_fused: coef_own_scaled selects the aliasing protocol (mode 2); with clip > 0 it needs clip_flag");
+  ONIRIS_CHECK_ARG(!coef_own_scaled || dout == g, "gconv_bwd_fused: the aliasing protocol masks g in place (pass dout = g)");
   // pixel slices so that the launch covers the chip (B*T alone is ~128 blocks); partial sums meet through atomics,
   // so d_coef_own / d_coef_ctx / d_cscale must be ZERO on entry.
   int slices = 1;

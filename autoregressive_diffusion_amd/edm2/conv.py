@@ -234,9 +234,11 @@ class MPCausal3DGatedConv(nn.Module):
         **epi: fused epilogue, either cscale=(N,Cout) fp32 [silu(y*cscale)/0.596] or res/ta/tb/clip [mp_sum+clip];
         grad_private (training, see ops.ConvCfg): the output's gradient will be a tensor only this op's backward reads."""
         grad_private = epi.pop("grad_private", False)
+        slot_kw = dict(res_slot=epi.pop("res_slot", None), res_alias=epi.pop("res_alias", False))
         if just_2d:
             self.__dict__.pop("_gate_pre", None)
-            return ops.conv(x, self.last_frame_conv.weight.pw, **epi), cache
+            train_kw = dict(grad_private=grad_private, **slot_kw) if self.training else {}
+            return ops.conv(x, self.last_frame_conv.weight.pw, **epi, **train_kw), cache
         if cache is None:
             cache = {}
         pre = self.__dict__.pop("_gate_pre", None)            # (ca, cb, n_new) batched by UNet.forward for all layers
@@ -251,7 +253,7 @@ class MPCausal3DGatedConv(nn.Module):
         pw2, pw3 = self.last_frame_conv.weight.pw, self.weight.pw
         if self.training:
             T = N // (2 * batch_size)
-            return ops.gated_conv_train(x, gate, pw2, pw3, batch_size, T, coefs, grad_private=grad_private, **epi), cache
+            return ops.gated_conv_train(x, gate, pw2, pw3, batch_size, T, coefs, grad_private=grad_private, **slot_kw, **epi), cache
         t = N // batch_size
         pad = cache.get("activations")
         had_pair = pad is not None

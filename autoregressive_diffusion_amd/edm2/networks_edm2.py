@@ -53,14 +53,18 @@ class Block(nn.Module):
         rs = self.resample_mode
         if rs != "keep" and (skip is not None or (self.flavor == "enc" and self.conv_skip is not None)):
             x, in_slot, rs = ops.resample(x, rs, in_slot), None, "keep"
+        # xs: the activation's xo is the residual of conv_res1 (no 1x1 skip conv in between): that conv parks the residual gradient
+        # as (gradient of its output, ta) and the activation's backward kernel applies the factor -- ta * g is never written
+        xs = ops.GradSlot() if (private_out and ops.ALIAS2 and self.training and torch.is_grad_enabled()
+                                and not (self.flavor == "dec" and self.conv_skip is not None)) else None
         if self.flavor == "enc":
             if self.conv_skip is not None:
                 x, in_slot = self.conv_skip._cl(x, in_slot=in_slot), None
-            x, a = ops.act(x, norm=True, in_slot=in_slot, resample=rs)     # x <- pixel norm(x); a = mp_silu(x)
+            x, a = ops.act(x, norm=True, in_slot=in_slot, resample=rs, xo_slot=xs)     # x <- pixel norm(x); a = mp_silu(x)
         elif skip is not None:
-            x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True, in_slot=in_slot, skip_slot=skip_slot)   # x <- mp_cat(x, skip); a = mp_silu(x)
+            x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True, in_slot=in_slot, skip_slot=skip_slot, xo_slot=xs)   # x <- mp_cat(x, skip); a = mp_silu(x)
         else:
-            x, a = ops.act(x, want_xo=True, in_slot=in_slot, resample=rs)  # (no resampling: x comes back as an alias of itself)
+            x, a = ops.act(x, want_xo=True, in_slot=in_slot, resample=rs, xo_slot=xs)  # (no resampling: x comes back as an alias of itself)
         N = x.shape[0]
         if c is None:          # (the UNet hands in all of its blocks' scales from one grouped GEMM: ops.emb_scales)
             c = (self.emb_linear._cl(emb).reshape(N, -1).float() * self.emb_gain + 1)      # (N, Cout) fp32
@@ -76,7 +80,8 @@ class Block(nn.Module):
         x, cache["conv_res1"] = self.conv_res1._cl(y, batch_size, c_noise, cache.get("conv_res1"), update_cache, just_2d,
                                                    res=x, ta=(1 - t) * den, tb=t * den,
                                                    clip=clip if self.num_heads == 0 else 0.0,
-                                                   grad_private=private_out and self.num_heads == 0)
+                                                   grad_private=private_out,
+                                                   **(dict(res_slot=xs, res_alias=True) if xs is not None else {}))
         if self.num_heads > 0:
             x, cache["attn"] = self.attn._cl(x, batch_size, cache.get("attn"), update_cache, just_2d, clip=clip)
         else:

@@ -511,6 +511,7 @@ def _s2ctx_family(T, H, W, Cin, CinP, CoutP, ctx_T, coff, ctx_fill):
     return "staged"
 
 
+ALIAS2 = int(_os.environ.get("ONIRIS_ALIAS2", "1"))          # 0: round-4 extent of the aliasing protocol only (A/B: no residual alias, no plain-conv alias)
 CLIP_FLAG = int(_os.environ.get("ONIRIS_CLIP_FLAG", "1"))    # 0: the mp_sum backward always reads the clipped output and writes a masked gradient copy (A/B, tests)
 
 
@@ -647,10 +648,10 @@ def _wgrad_launch(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb
 
 class ConvCfg:
     """Static configuration of one conv op (not a tensor: passed through autograd untouched)."""
-    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad", "in_slot", "res_slot", "grad_private")
+    __slots__ = ("pw2", "pw3", "B", "T", "epi", "ta", "tb", "clip", "need_grad", "in_slot", "res_slot", "grad_private", "res_alias")
 
     def __init__(self, pw2, pw3=None, B=1, T=1, epi="none", ta=0.0, tb=0.0, clip=0.0, need_grad=True, in_slot=None,
-                 res_slot=None, grad_private=False):
+                 res_slot=None, grad_private=False, res_alias=False):
         self.pw2, self.pw3, self.B, self.T = pw2, pw3, B, T
         # the caller vouches that the gradient of this op's output is a tensor nobody else reads (UNet.forward with GradSlots:
         # it comes out of the ONE backward kernel that joined the gradients of all consumers): the backward may then mask it
@@ -658,6 +659,9 @@ class ConvCfg:
         # with the caller's g, torch.autograd.grad(grad_outputs=...), a consumer whose backward hands one tensor to two
         # inputs -- the gradient is read-only.
         self.grad_private = bool(grad_private)
+        # res_slot's taker applies a scale itself (GradSlot.take_scaled: the activation whose output `res` is): under the
+        # aliasing protocol the residual gradient ta * g is then not written at all
+        self.res_alias = bool(res_alias) and res_slot is not None
         self.epi, self.ta, self.tb, self.clip, self.need_grad = epi, ta, tb, clip, need_grad
         self.in_slot = in_slot             # GradSlot of the input (plain convs): a second gradient of x joins in the dgrad epilogue
         self.res_slot = res_slot           # GradSlot that receives the gradient of `res` (mp_sum epilogue) instead of autograd
@@ -716,6 +720,12 @@ class _ConvOp(torch.autograd.Function):
                     _s2ctx_family(cfg.T, H, W, Cin, pw2.CinP, pw2.CoutP, cfg.T, (-2, -1), 1.0) != "staged"):
                 clip_flag = pw2.bank.take_flag(dev)
                 kw["clip_flag"] = clip_flag
+            # plain 3x3 conv (conv_res1 of the 2-D steps): the same protocol, with oniris_mpsum_mask as the backward's (almost
+            # always empty) masking pass
+            if (CLIP_FLAG and ALIAS2 and not gated and cfg.need_grad and cfg.grad_private and pw2.taps == 9 and cfg.clip > 0 and
+                    Cin % 32 == 0 and (H % 16 == 0 and W % 16 == 0 or H == 8 and W == 8 and pw2.CoutP % 64 == 0) and N % 2 == 0):
+                clip_flag = pw2.bank.take_flag(dev)
+                kw["clip_flag"] = clip_flag
         y3 = ca32 = cb32 = None
         ctx.clip_flag = kw.get("clip_flag")
         first_out = ret if cfg.epi == "mpsum" else (raw if raw is not None else ret)
@@ -746,12 +756,15 @@ class _ConvOp(torch.autograd.Function):
         dev = x.device
         dcs = dres = None
         dx = dca = dcb = None
+        plain_coef = None                           # per-frame coefficient of `dout` for a plain conv's dgrad / wgrad (aliasing)
         fused = gated and cfg.epi in ("emb_silu", "mpsum") and Co <= 512
         ca_own = ca                                 # the own-frame coefficient dgrad / wgrad apply to `dout`
         if fused:                                   # epilogue adjoint + gate/context pre-pass in ONE pass over g
             B, T = cfg.B, cfg.T
             flag = getattr(ctx, "clip_flag", None) if cfg.epi == "mpsum" else None
-            if flag is not None:
+            # (clip <= 0 -- conv_res1 in front of an attention layer, which clips later: nothing to mask, no flag needed)
+            alias = cfg.epi == "mpsum" and cfg.grad_private and CLIP_FLAG and (flag is not None or (cfg.clip <= 0 and ALIAS2))
+            if alias:
                 # aliasing protocol (include/oniris.h): dout = tb * g * mask is not written -- dgrad and wgrad read g with
                 # the coefficient vector tb * ca; the mask exists (and is applied to g in place) only if the forward clipped
                 # (g is the gradient of this conv's output alone -- produced by the one kernel that joined all of its
@@ -763,19 +776,38 @@ class _ConvOp(torch.autograd.Function):
             dy3 = torch.empty_like(y3)
             acc = pw2.bank.zero_arena.take(N * (2 + (Co if cfg.epi == "emb_silu" else 0)), dev)
             dca, dcb = acc[:N], acc[N:2 * N]
+            res_alias = alias and cfg.res_alias            # the residual's consumer reads g itself, times ta
             if cfg.epi == "emb_silu":
                 dcs = acc[2 * N:2 * N + N * Co].view(N, Co)
-            else:
+            elif not res_alias:
                 dres = torch.empty_like(g)
             check(lib.oniris_gconv_bwd_fused(1 if cfg.epi == "emb_silu" else 2, _p(g), _p(raw), _p(y3), _p(ca), _p(cb),
                                              _p(cs), _p(xo), _p(dout), _p(dres), _p(dy3), _p(dca), _p(dcb), _p(dcs), B, T,
                                              H * W, Co, cfg.ta, cfg.tb, cfg.clip, cs.stride(0) if cs is not None else 0,
-                                             _p(flag), _p(ca_own) if flag is not None else None, _stream()), "gconv_bwd_fused")
+                                             _p(flag) if alias else None, _p(ca_own) if alias else None, _stream()), "gconv_bwd_fused")
+            if res_alias:
+                cfg.res_slot.put(g, cfg.ta)
+                cfg = _no_res_slot(cfg)
         elif cfg.epi == "emb_silu":
             dout = torch.empty_like(g)
             dcs = pw2.bank.zero_arena.take(N * Co, dev)[:N * Co].view(N, Co)     # (zero-filled once per step with all the others)
             check(lib.oniris_emb_silu_bwd(_p(g), _p(raw), _p(cs), _p(dout), _p(dcs), N, H * W, Co, cs.stride(0), 1, _stream()),
                   "emb_silu_bwd")
+        elif cfg.epi == "mpsum" and not gated and cfg.grad_private and CLIP_FLAG and ALIAS2 and pw2.taps == 9 and (
+                getattr(ctx, "clip_flag", None) is not None or cfg.clip <= 0):
+            # aliasing protocol, plain 3x3 conv: dv = tb * g * mask and dres = ta * g * mask are scaled copies of g -- dgrad and
+            # wgrad read g with the per-frame coefficient tb, the residual's consumer with the scale ta; the mask exists (and is
+            # applied to g in place) only if the forward launch reported a clip
+            flag = getattr(ctx, "clip_flag", None)
+            if flag is not None:
+                check(lib.oniris_mpsum_mask(_p(g), _p(xo), g.numel(), cfg.clip, _p(flag), _stream()), "mpsum_mask")
+            dout, plain_coef = g, _const_vec(N, cfg.tb, dev)
+            if cfg.res_alias:
+                cfg.res_slot.put(g, cfg.ta)
+                cfg = _no_res_slot(cfg)
+            else:
+                dres = torch.empty_like(g)
+                check(lib.oniris_mpsum_bwd(_p(g), None, _p(dres), None, g.numel(), cfg.ta, cfg.tb, 0.0, _stream()), "mpsum_bwd")
         elif cfg.epi == "mpsum":
             dres, dout = torch.empty_like(g), torch.empty_like(g)
             check(lib.oniris_mpsum_bwd(_p(g), _p(xo), _p(dres), _p(dout), g.numel(), cfg.ta, cfg.tb, cfg.clip, _stream()),
@@ -809,19 +841,39 @@ class _ConvOp(torch.autograd.Function):
                 dx = torch.empty_like(x)
                 dadd = cfg.in_slot.take() if cfg.in_slot is not None else None       # (see GradSlot)
                 if dadd is not None:             # dx = dadd + dgrad: the mp_sum epilogue with ta = tb = 1, no clip
-                    _conv_launch(dout, None, pw2.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
+                    _conv_launch(dout, None, pw2.wb, None, dx, plain_coef, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
                                  pw2.taps, epi=_lib.EPI_MPSUM, res=dadd.contiguous(), ta=1.0, tb=1.0, clip=0.0)
                 else:
-                    _conv_launch(dout, None, pw2.wb, None, dx, None, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
+                    _conv_launch(dout, None, pw2.wb, None, dx, plain_coef, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
                                  pw2.taps)
             if pw2.param.requires_grad:
-                _wgrad_launch(x, dout, pw2, None, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
+                _wgrad_launch(x, dout, pw2, plain_coef, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
         if pw2.param.requires_grad or (gated and pw3.param.requires_grad):
             pw2.bank.request_finish()
         if cfg.res_slot is not None and dres is not None:
             cfg.res_slot.put(dres)                   # joins the other gradient of `res` inside that consumer's kernel
             dres = None
         return dx, None, None, dca, dcb, dcs, dres, None
+
+
+_const_cache = {}
+
+
+def _const_vec(n, value, dev):
+    """(n,) fp32 vector filled with `value` (a per-frame coefficient that is the same for every frame), cached."""
+    key = (n, float(value), str(dev))
+    if key not in _const_cache:
+        if len(_const_cache) > 64:
+            _const_cache.clear()
+        _const_cache[key] = torch.full((n,), float(value), dtype=torch.float32, device=dev)
+    return _const_cache[key]
+
+
+def _no_res_slot(cfg):
+    """A copy of `cfg` whose res_slot was served (the tail of _ConvOp.backward parks `dres` otherwise)."""
+    c = ConvCfg(cfg.pw2, cfg.pw3, cfg.B, cfg.T, cfg.epi, cfg.ta, cfg.tb, cfg.clip, cfg.need_grad, cfg.in_slot, None,
+                cfg.grad_private)
+    return c
 
 
 _sel_cache = {}
@@ -842,21 +894,25 @@ def gate_coefs(gate):
     return (1 - gate) * den, gate * den
 
 
-def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None, res_slot=None):
+def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None, res_slot=None, grad_private=False,
+         res_alias=False):
     """MPConv forward on packed weights.  Optional fused epilogues: res -> clip(ta*res + tb*conv(x));
-    cscale (N,Cout) fp32 -> silu(conv(x)*cscale)/0.596.  in_slot: GradSlot of x; res_slot: GradSlot that takes d res."""
+    cscale (N,Cout) fp32 -> silu(conv(x)*cscale)/0.596.  in_slot: GradSlot of x; res_slot: GradSlot that takes d res;
+    grad_private / res_alias: see ConvCfg."""
     epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
     cfg = ConvCfg(pw, None, epi=epi, ta=ta, tb=tb, clip=clip, need_grad=torch.is_grad_enabled(), in_slot=in_slot,
-                  res_slot=res_slot)
+                  res_slot=res_slot, grad_private=grad_private, res_alias=res_alias)
     return _ConvOp.apply(x, pw.param, None, None, None, cscale, res, cfg)
 
 
-def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, grad_private=False):
+def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, grad_private=False,
+                     res_slot=None, res_alias=False):
     """Training-mode MPCausal3DGatedConv.  gate: (B*2*T,) fp32 autograd tensor, or precomputed coefs=(ca, cb).
-    grad_private: see ConvCfg."""
+    grad_private / res_slot / res_alias: see ConvCfg."""
     ca, cb = coefs if coefs is not None else gate_coefs(gate)
     epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
-    cfg = ConvCfg(pw2, pw3, B, T, epi, ta, tb, clip, torch.is_grad_enabled(), grad_private=grad_private)
+    cfg = ConvCfg(pw2, pw3, B, T, epi, ta, tb, clip, torch.is_grad_enabled(), grad_private=grad_private, res_slot=res_slot,
+                  res_alias=res_alias)
     return _ConvOp.apply(x, pw2.param, pw3.param, ca, cb, cscale, res, cfg)
 
 
@@ -933,11 +989,11 @@ class GradSlot:
     encoder-side consumer -- the first op of the next block: pixel-norm / resample / 1x1 skip conv -- takes it and adds
     it inside its own backward kernel (`dadd` of oniris_act_bwd / `add` of oniris_resample / the mp_sum epilogue of the
     1x1 dgrad).  One slot per skip tensor and per forward pass."""
-    __slots__ = ("g",)
+    __slots__ = ("g", "scale")
     live = []            # the slots of the current forward pass (cleared by WeightBank.prepare, checked at the end of backward)
 
     def __init__(self):
-        self.g = None
+        self.g, self.scale = None, 1.0
         GradSlot.live.append(self)
 
     @classmethod
@@ -954,12 +1010,24 @@ class GradSlot:
                                "never ran (partial backward through the UNet?): they would have been dropped.  Run the "
                                "whole backward, or set ONIRIS_GRAD_SLOTS=0 to let autograd join these gradients")
 
-    def put(self, g):
-        self.g = g if self.g is None else self.g + g
+    def put(self, g, scale=1.0):
+        """scale != 1: the parked gradient is `scale * g` with g left as it is -- the residual gradient of an mp_sum epilogue is
+        ta times the gradient of its output, a scaled copy nobody needs to write (the taker folds the factor into its kernel:
+        take_scaled).  A second put materialises."""
+        if self.g is None:
+            self.g, self.scale = g, float(scale)
+        else:
+            self.g = (self.g if self.scale == 1.0 else self.g * self.scale) + (g if scale == 1.0 else g * scale)
+            self.scale = 1.0
 
     def take(self):
-        g, self.g = self.g, None
-        return g
+        g, sc, self.g, self.scale = self.g, self.scale, None, 1.0
+        return g if (g is None or sc == 1.0) else g * sc
+
+    def take_scaled(self):
+        """(g, scale) for a taker whose kernel applies the factor itself."""
+        g, sc, self.g, self.scale = self.g, self.scale, None, 1.0
+        return g, sc
 
 
 class _ActFn(torch.autograd.Function):
@@ -969,7 +1037,7 @@ class _ActFn(torch.autograd.Function):
     act_bwd, and in_slot then belongs to the un-resampled x."""
 
     @staticmethod
-    def forward(ctx, x, skip, w1, w2, norm, want_xo, in_slot=None, skip_slot=None, rs=0):
+    def forward(ctx, x, skip, w1, w2, norm, want_xo, in_slot=None, skip_slot=None, rs=0, xo_slot=None):
         _need_gpu(x)
         C1 = x.shape[-1]
         C2 = skip.shape[-1] if skip is not None else 0
@@ -996,7 +1064,9 @@ class _ActFn(torch.autograd.Function):
         check(lib.oniris_act_fwd(_p(x), _p(skip), _p(xo), _p(a), _p(sden), npix, C1, C2, w1, w2, int(norm), rs, Ho, Wo,
                                  _stream()), "act_fwd")
         ctx.meta = (C1, C2, w1, w2, norm, npix, (*oshape, C1), skip.shape if skip is not None else None, rs, tuple(x.shape))
-        ctx.slots = (in_slot, skip_slot)
+        ctx.slots = (in_slot, skip_slot, xo_slot)
+        ctx.set_materialize_grads(False)                 # (an output whose consumer parked its gradient in xo_slot arrives as None,
+                                                         #  not as a zero tensor that would then be ADDED to the parked one)
         # without norm/cat xo would just be x itself: reuse the input for the silu' evaluation
         ctx.save_for_backward(xo if xo is not None else x, sden)
         if alias:
@@ -1016,16 +1086,24 @@ class _ActFn(torch.autograd.Function):
         if da is None:
             da = torch.zeros(xo.shape, dtype=BF16, device=xo.device)
         da = da.contiguous()
+        in_slot, skip_slot, xo_slot = ctx.slots
+        dxo_scale = 1.0
+        if xo_slot is not None:                          # the gradient of xo parked by its consumer, possibly as (g, scale): the
+            parked, sc = xo_slot.take_scaled()           # residual gradient of an mp_sum epilogue = ta * (gradient of its output)
+            if parked is not None:
+                if dxo is None:
+                    dxo, dxo_scale = parked, sc
+                else:
+                    dxo = dxo + (parked if sc == 1.0 else parked * sc)
         dxo = dxo.contiguous() if dxo is not None else None
         dx = torch.empty(xshape, dtype=BF16, device=xo.device)
         dskip = torch.empty(sshape, dtype=BF16, device=xo.device) if C2 else None
-        in_slot, skip_slot = ctx.slots
         dadd = in_slot.take() if in_slot is not None else None
         if dadd is not None:
             dadd = dadd.contiguous()
             assert tuple(dadd.shape) == (tuple(xin_shape) if rs else tuple(dx.shape))
         check(lib.oniris_act_bwd(_p(da), _p(dxo), _p(xo), _p(sden), _p(dx), _p(dskip), _p(None if rs else dadd), npix, C1, C2,
-                                 w1, w2, int(norm), _stream()), "act_bwd")
+                                 w1, w2, int(norm), dxo_scale, _stream()), "act_bwd")
         if rs:                                           # adjoint of the resampling (+ the second gradient of the input)
             N_, Ho, Wo = xshape[0], xshape[1], xshape[2]
             dpre = torch.empty(xin_shape, dtype=BF16, device=xo.device)
@@ -1037,13 +1115,14 @@ class _ActFn(torch.autograd.Function):
         if skip_slot is not None and dskip is not None:
             skip_slot.put(dskip)                      # joins the encoder-side gradient inside that consumer's kernel
             dskip = None
-        return dx, dskip, None, None, None, None, None, None, None
+        return dx, dskip, None, None, None, None, None, None, None, None
 
 
-def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, skip_slot=None, resample="keep"):
-    """resample 'down' / 'up': x is resampled first, in the same launch (the reference's Block.forward, :63)."""
+def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, skip_slot=None, resample="keep", xo_slot=None):
+    """resample 'down' / 'up': x is resampled first, in the same launch (the reference's Block.forward, :63).
+    xo_slot: GradSlot in which a consumer of xo parks its gradient (GradSlot.put(g, scale)) instead of handing it to autograd."""
     rs = {"keep": 0, "down": 1, "up": 2}[resample]
-    return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo), in_slot, skip_slot, rs)
+    return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo), in_slot, skip_slot, rs, xo_slot)
 
 
 class _ResampleFn(torch.autograd.Function):

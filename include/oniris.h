@@ -303,7 +303,9 @@ int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, const void*
                            float tb, float clip,
                            int cscale_pitch /* floats between rows of cscale; 0 = C */,
                            const int32_t* clip_flag, float* coef_own_scaled, oniris_stream_t stream);
-/* clip_flag / coef_own_scaled (mode 2 only, both or neither; ABI 10): the ALIASING protocol.  dout = tb * g * mask is a scaled
+/* ABI 12: coef_own_scaled alone selects the protocol; clip_flag may be NULL when clip <= 0 (nothing to mask, ever), and dres may
+ * be NULL (the residual's consumer reads g with the scale ta: oniris_act_bwd's dxo_scale).
+ * clip_flag / coef_own_scaled (mode 2 only; ABI 10): the ALIASING protocol.  dout = tb * g * mask is a scaled
  * copy of the incoming gradient, so the launch does not write it: dgrad and weight gradient read g itself with the
  * coefficient vector coef_own_scaled[n] = tb * coef_own[n] (written here, [B*2*T]); `dout` is ignored (pass g).  When
  * *clip_flag != 0 (the forward clipped something: OnirisConvArgs.clip_flag) the mask is applied to g IN PLACE -- g must then
@@ -326,13 +328,20 @@ int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a, float* sd
 /*   resample != 0: x is resampled on the way in (Block.forward's first line, networks_edm2.py:63): 1 = 2x2 mean, 2 = nearest
  *   x2, rounded to bf16 like oniris_resample stores it; npix and Ho x Wo describe the OUTPUT grid.                      */
 int oniris_act_bwd(const void* da, const void* dxo, const void* xo, const float* sden, void* dx, void* dskip,
-                   const void* dadd, int64_t npix, int C1, int C2, float w1, float w2, int norm, oniris_stream_t stream);
+                   const void* dadd, int64_t npix, int C1, int C2, float w1, float w2, int norm,
+                   float dxo_scale /* ABI 12: dxo enters as dxo_scale * dxo (1: as before) -- the residual gradient of an mp_sum
+                                    * epilogue is ta times the gradient of its output: the caller hands that gradient itself */,
+                   oniris_stream_t stream);
 int oniris_emb_silu_bwd(const void* du, const void* y, const float* c, void* dy, float* dc, int N, int P, int C,
                         int c_pitch /* floats between rows of c; 0 = C */,
                         int dc_is_zero /* != 0: the caller hands in a zero-filled dc (no fill launch here) */,
                         oniris_stream_t stream);
-int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv, int64_t numel, float ta, float tb, float clip,
-                     oniris_stream_t stream);
+int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv /* ABI 12: may be NULL (only dres is wanted) */,
+                     int64_t numel, float ta, float tb, float clip, oniris_stream_t stream);
+/* ABI 12, plain convs with the mp_sum + clip epilogue under the aliasing protocol (see oniris_gconv_bwd_fused): dv and dres are
+ * scaled copies of g -- nothing is written, the consumers read g with tb / ta -- unless *clip_flag != 0 (OnirisConvArgs.clip_flag of
+ * the forward launch): then g is masked IN PLACE where |out| reached the clip.                                          */
+int oniris_mpsum_mask(void* g, const void* out, int64_t numel, float clip, const int32_t* clip_flag, oniris_stream_t stream);
 int oniris_resample(const void* in, void* out, const void* add, int64_t N, int H, int W, int C, int mode, float scale,
                     oniris_stream_t stream);
 

@@ -77,7 +77,7 @@ def install():
     ops.WeightBank.prepare = prepare
     ops.WeightBank.backward = backward
 
-    def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None, res_slot=None):
+    def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None, res_slot=None, grad_private=False, res_alias=False):
         y = _mix(x, pw.cout, [pw])
         if res is not None:
             y = (ta * res.float() + tb * y.float()).to(BF16)
@@ -85,7 +85,7 @@ def install():
             y = torch.nn.functional.silu(y.float() * cscale.float()[:, None, None, :]).to(BF16)
         return y
 
-    def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, grad_private=False):
+    def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, grad_private=False, res_slot=None, res_alias=False):
         ca, cb = coefs if coefs is not None else ops.gate_coefs(gate)
         N = x.shape[0]
         y = _mix(x, pw2.cout, [pw2, pw3]).float() * (ca.float() + cb.float()).reshape(N, 1, 1, 1)
@@ -95,7 +95,7 @@ def install():
             y = torch.nn.functional.silu(y * cscale.float()[:, None, None, :])
         return y.to(BF16)
 
-    def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, skip_slot=None, resample="keep"):
+    def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, skip_slot=None, resample="keep", xo_slot=None):
         x = ops_resample(x, resample)
         v = torch.cat([w1 * x.float(), w2 * skip.float()], dim=-1) if skip is not None else x.float()
         if norm:

@@ -150,7 +150,10 @@ def test_g6b_attention_small_heads():
 
 
 WEIGHT_GN_TOL = dict(enc=5e-2, dec=5e-2)      # (tightened to 2x the measured floor below)
-G7_GATE_BOUNDS = dict(enc=(1.0, 1.0), dec=(1.0, 1.0))      # (own-relative, relative to the largest): set from the measurement
+# (own-relative, relative to the block's largest gate gradient norm): 2x the values measured on the MI355X (round 5: enc 0.9 % /
+# 0.35 %; dec 7.3 % / 3.2 % -- conv_res1.max_gating of the decoder block, a gradient of 1e-3 that is the difference of two sums of
+# order 1 on a 4-frame fixture; on the full nets against the oracle every such gradient is within 1.8 %, SCALAR_GRAD_BOUNDS)
+G7_GATE_BOUNDS = dict(enc=(1.8e-2, 7e-3), dec=(0.15, 6.5e-2))
 
 
 def test_g7_blocks():
@@ -207,7 +210,10 @@ def build_precond(cfg, seed, sigma_data):
     return load_params(net, p)
 
 
-G8_SCALAR_BOUNDS = {(t_, m_): (1.0, 1.0) for t_ in ("small", "c1") for m_ in ("3d", "2d")}      # set from the measurement
+# (own-relative, relative to the largest scalar gradient norm of the net): 2x the values measured on the MI355X (round 5: 3.2 % /
+# 0.08 %, 2.1 % / 0.05 %, 3.5 % / 0.09 %, 4.7 % / 0.21 %; the worst are emb_gain's of blocks whose gradient is ~1 % of the largest)
+G8_SCALAR_BOUNDS = {("small", "3d"): (6.4e-2, 1.7e-3), ("small", "2d"): (4.2e-2, 1e-3), ("c1", "3d"): (7e-2, 1.8e-3),
+                    ("c1", "2d"): (9.5e-2, 4.3e-3)}
 
 
 @pytest.mark.parametrize("tag,cfg", [("small", SMALL_CFG), ("c1", C1_CFG)])

@@ -746,7 +746,7 @@ def test_conv_epilogues(gated, H, cout, clipped):
     # private: the caller vouches that nobody else reads the output's gradient (ops.ConvCfg.grad_private, what UNet.forward does):
     # the clip_flag aliasing protocol -- no masked copy; the gradient is masked IN PLACE when the forward clipped.  Without it
     # (the default: y.backward(g) with the caller's own g) the gradient tensor must come back untouched.
-    for epi, private in (("emb_silu", False), ("mpsum", False)) + ((("mpsum", True),) if gated else ()):
+    for epi, private in (("emb_silu", False), ("mpsum", False), ("mpsum", True)):
         p2, p3 = torch.nn.Parameter(w2.clone().to(DEV)), torch.nn.Parameter(w3.clone().to(DEV))
         bank, (pw2, pw3) = make_bank([p2, p3])
         bank.prepare(training=True)
@@ -760,7 +760,8 @@ def test_conv_epilogues(gated, H, cout, clipped):
         cs = c0.clone().to(DEV).requires_grad_(True)
         res = nhwc(r0).requires_grad_(True)
         kw = dict(cscale=cs) if epi == "emb_silu" else dict(res=res, ta=0.9, tb=0.4, clip=256.0)
-        y = ops.gated_conv_train(x, gate, pw2, pw3, B, T, grad_private=private, **kw) if gated else ops.conv(x, pw2, **kw)
+        y = (ops.gated_conv_train(x, gate, pw2, pw3, B, T, grad_private=private, **kw) if gated else
+             ops.conv(x, pw2, grad_private=private, **kw) if epi == "mpsum" else ops.conv(x, pw2, **kw))
         gy = nhwc(gy0)
         gy_before = gy.clone()
         y.backward(gy)
