@@ -402,8 +402,11 @@ __global__ __launch_bounds__(64 * NW, (NW >= 8) ? 2 : 1) void conv_glds_kernel(c
           const int f_ = q / (P::PH * P::PW), yy = (q / P::PW) % P::PH, xx = q % P::PW;
           const size_t px_ = (size_t)(cur.t0 + f_) * HWp + (cur.y0 + yy) * W + (cur.x0 + xx);
           const int co = cow + part * 8;
-          if (co < a.Cout && cur.t0 + f_ < T)
-            *(uint4*)(dst + (blk + px_) * a.Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
+          if (co < a.Cout && cur.t0 + f_ < T) {
+            const u32x4 v_ = *(const u32x4*)(ep + row * EROW + part * 16);
+            u32x4* o_ = (u32x4*)(dst + (blk + px_) * a.Cout + co);
+            if (d.nt) __builtin_nontemporal_store(v_, o_); else *o_ = v_;
+          }
         }
       };
 #pragma unroll
@@ -514,6 +517,8 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
   using P = typename Cfg::P;
   ConvDev d;
   d.a = a;
+  d.ksplit = 1; d.reduce = 0;
+  d.nt = (long long)a.B * a.S * a.T * a.H * a.W * a.Cout * 2 >= oniris_ew_nt_bytes();
   d.ncob = a.CoutP / Cfg::BN;
   d.ntx = a.W / P::PW; d.nty = a.H / P::PH; d.ntt = cdiv(a.T, P::FT);
   const long long ntiles = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;

@@ -31,6 +31,7 @@ struct ConvDev {
   int ntx, nty, ntt, ncob;
   int ksplit;            // > 1: the (chunk, phase) rounds of a tile are dealt to `ksplit` workgroups (conv_fwd_kernel)
   int reduce;            // 1: second launch of a split-K conv -- sum the slices' partials and run the epilogue
+  int nt;                // conv_glds_kernel: outputs go out with non-temporal stores (tensors beyond oniris_ew_nt_bytes())
 };
 
 template <int S, int TAPS, int CK, int NT, bool HAS_CTX, int PW, int NW = 4>

@@ -31,6 +31,7 @@ struct ConvStreamDev {
   OnirisConvArgs a;
   int ntx, nty, nseg, seglen;
   int dir;                 // +1: frames ascending (context = earlier frames: coff = -2, -1); -1: descending (coff = 2, 1)
+  int nt;                  // outputs are streamed with non-temporal stores (tensors beyond oniris_ew_nt_bytes(): nothing re-reads them from a cache)
 };
 
 template <bool ALIAS>      // ALIAS: the context frames are the slot-0 frames of x itself (forward); else a separate tensor (dgrad)
@@ -298,7 +299,11 @@ __global__ __launch_bounds__(256, 2) void conv_stream_kernel(const ConvStreamDev
     auto flush_row = [&](bf16* dst, size_t fblk, int it) __attribute__((always_inline)) {      // pixel row `it` of the tile
       const int id = it * 64 + lane, row = id >> 2, part = id & 3;
       const size_t px_ = (size_t)(y0 + 2 * pt + (row >> 4)) * W + x0 + (row & 15);
-      if (part * 8 < Cout) *(uint4*)(dst + (fblk + px_) * Cout + part * 8) = *(const uint4*)(ep + row * EROW + part * 16);
+      if (part * 8 < Cout) {
+        const u32x4 v_ = *(const u32x4*)(ep + row * EROW + part * 16);
+        u32x4* o_ = (u32x4*)(dst + (fblk + px_) * Cout + part * 8);
+        if (d.nt) __builtin_nontemporal_store(v_, o_); else *o_ = v_;
+      }
     };
     auto flush = [&](bf16* dst, size_t fblk) __attribute__((always_inline)) {
       flush_row(dst, fblk, 0);
@@ -392,6 +397,7 @@ static int launch_conv_stream(const OnirisConvArgs& a, hipStream_t stream) {
   int nseg = 512 / units;                  // two workgroups per CU; a segment re-copies two context halos at its head
   if (nseg > a.T / 8) nseg = a.T / 8;
   if (nseg < 1) nseg = 1;
+  d.nt = 2LL * a.B * a.T * a.H * a.W * a.Cout * 2 >= oniris_ew_nt_bytes();
   d.seglen = cdiv(a.T, nseg);
   d.nseg = cdiv(a.T, d.seglen);
   const bool alias = a.ctx == a.x && a.ctx_bstride == 2 * a.T && d.dir == 1;

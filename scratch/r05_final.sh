@@ -3,7 +3,7 @@
 set -x
 O=gpurun_out
 python -m pytest tests -m gpu -q > $O/r05_gputests_final.log 2>&1; echo rc=$? >> $O/r05_gputests_final.log
-/usr/bin/time -v python bench.py --steps 20 --warmup 5 > $O/r05_bench.json 2> $O/r05_bench.err
+( time python bench.py --steps 20 --warmup 5 > $O/r05_bench.json 2> $O/r05_bench.err ) 2> $O/r05_bench_time.txt
 python bench.py --batch 2 --steps 20 --warmup 5 --cpu-frames 0 --no-extra > $O/r05_bench_b2.json 2> $O/r05_bench_b2.err
 python bench.py --net cs --steps 8 --warmup 4 --no-profile > $O/r05_bench_cs.json 2> $O/r05_bench_cs.err
 python bench.py --net cs --frames 64 --steps 8 --warmup 4 --no-profile > $O/r05_bench_cs_t64.json 2> $O/r05_bench_cs_t64.err
@@ -21,4 +21,4 @@ python scratch/pmc_traffic.py $O/prof_f $O/prof_w $O/r05_pmc_traffic > /dev/null
 rm -rf $O/prof_f $O/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ro -o ro -- python3 bench.py --mode rollout --gen-frames 4 --batch 1 > $O/r05_prof_ro.log 2>&1
 cp "$(find $O/prof_ro -name '*kernel_stats.csv' | head -1)" $O/r05_rollout_kernel_stats.csv; rm -rf $O/prof_ro
-tail -3 $O/r05_gputests_final.log; grep -E "Elapsed|Maximum resident" $O/r05_bench.err
+tail -3 $O/r05_gputests_final.log; cat $O/r05_bench_time.txt

@@ -287,3 +287,68 @@ def test_learning_rate_schedule_values():
     assert abs(learning_rate_schedule(28e4) - 0.5e-2) < 1e-18
     assert learning_rate_schedule(10, 3e-3, 0, 0) == 3e-3
     assert learning_rate_schedule(16, 1e-2, 4, 4) == 1e-2 / math.sqrt(4.0)
+
+
+def test_gradslot_scaled_alias_semantics():
+    """ops.GradSlot (round 5): a consumer parks (g, scale) -- the residual gradient of an mp_sum epilogue is ta * g, a scaled copy
+    nobody writes; take_scaled() hands both to a taker whose kernel applies the factor, take() materialises, a second put adds."""
+    from autoregressive_diffusion_amd import ops
+    ops.GradSlot.live = []
+    g, h = torch.arange(6.0).reshape(2, 3), torch.ones(2, 3)
+    s = ops.GradSlot()
+    s.put(g, 0.5)
+    t, sc = s.take_scaled()
+    assert t is g and sc == 0.5 and s.g is None and s.scale == 1.0
+    s.put(g, 0.5)
+    assert torch.equal(s.take(), g * 0.5) and s.g is None
+    s.put(g, 0.5); s.put(h)
+    t, sc = s.take_scaled()
+    assert sc == 1.0 and torch.equal(t, g * 0.5 + h)
+    s.put(h)
+    assert s.take() is h
+    s.put(g, 2.0)
+    with pytest.raises(RuntimeError, match="parked"):
+        ops.GradSlot.check_all_taken()                        # a parked gradient nobody took = a partial backward: loud
+    assert ops.GradSlot.live == []
+
+
+def test_flatparams_only_subset_and_deepcopy_strips_runtime_state():
+    """parallel.FlatParams(only=...) re-homes just the given parameters (torch DDP around the UNet: the kernel-owned weights);
+    copy.deepcopy of this package's modules leaves the run-time state (weight bank handles, cached plans, inner DDP engine) behind."""
+    import copy
+    from autoregressive_diffusion_amd.parallel import FlatParams
+    from edm2.networks_edm2 import UNet
+    from edm2.conv import NormalizedWeight
+    unet = UNet(img_resolution=16, img_channels=4, label_dim=4, model_channels=8, channel_mult=[1, 2], num_blocks=1)
+    owned = [m.weight for m in unet.modules() if isinstance(m, NormalizedWeight)]
+    before = {n: p.detach().clone() for n, p in unet.named_parameters()}
+    flat = FlatParams(unet, only=owned)
+    assert len(flat.params) == len(owned) and {id(p) for p in flat.params} == {id(p) for p in owned}
+    base = flat.flat.data_ptr()
+    for n, p in unet.named_parameters():
+        assert torch.equal(p.detach(), before[n])
+        inside = base <= p.data_ptr() < base + 4 * flat.numel
+        assert inside == (id(p) in {id(q) for q in owned}), n
+    assert flat.check()
+    # run-time attachments disappear in a copy; the marker of a torch-DDP-wrapped original survives as "lost"
+    unet.__dict__["_oniris_bank"] = object()
+    unet.__dict__["_oniris_inner_ddp"] = object()
+    next(m for m in unet.modules() if isinstance(m, NormalizedWeight)).pw = object()
+    cp = copy.deepcopy(unet)
+    assert "_oniris_bank" not in cp.__dict__ and cp.__dict__["_oniris_inner_ddp"] == "lost"
+    assert all(m.pw is None for m in cp.modules() if isinstance(m, NormalizedWeight))
+    assert cp._ddp_inner() is None                                   # (no process group: evaluation / single-process use is fine)
+    for (n, p), (m, q) in zip(unet.named_parameters(), cp.named_parameters()):
+        assert n == m and torch.equal(p, q) and p.data_ptr() != q.data_ptr()
+
+
+def test_dkv_item_keys_follow_the_launch_size():
+    """ops._dkv_item_keys: 128-key items only when a workgroup's average load is well above the heaviest item (C2: B = 8, not B = 2)."""
+    from autoregressive_diffusion_amd import ops
+    ops._cu_count["cpu"] = 256
+    try:
+        assert ops._dkv_item_keys(64, 64, 2 * 4, "cpu") == 64
+        assert ops._dkv_item_keys(64, 64, 8 * 4, "cpu") == 128
+        assert ops._dkv_item_keys(32, 16, 2 * 8, "cpu") == 64           # Counter-Strike T = 32: 4 table blocks per pair
+    finally:
+        del ops._cu_count["cpu"]
