@@ -159,8 +159,11 @@ __global__ __launch_bounds__(512, 1) void conv1x1_glds_kernel(const ConvDev d) {
         for (int it = 0; it < 4; ++it) {
           const int id = it * 64 + lane, row = id >> 3, part = id & 7;
           const int co = cow + part * 8;
-          if (prow + row < M && co < Cout)
-            *(uint4*)(dst + (size_t)(prow + row) * Cout + co) = *(const uint4*)(ep + row * EROW + part * 16);
+          if (prow + row < M && co < Cout) {
+            const u32x4 v_ = *(const u32x4*)(ep + row * EROW + part * 16);
+            u32x4* o_ = (u32x4*)(dst + (size_t)(prow + row) * Cout + co);
+            if (d.nt) __builtin_nontemporal_store(v_, o_); else *o_ = v_;
+          }
         }
       };
       float v[16];
@@ -224,6 +227,7 @@ static int launch_conv1x1_glds(const OnirisConvArgs& a, hipStream_t stream) {
   d.ntt = (int)((M + C1Cfg::BM - 1) / C1Cfg::BM);
   d.ncob = cdiv(a.CoutP, C1Cfg::BN);
   d.ntx = d.nty = 1; d.ksplit = 1; d.reduce = 0;
+  d.nt = M * a.Cout * 2 >= oniris_ew_nt_bytes();
   const long long ntiles = (long long)d.ntt * d.ncob;
   const int ncu = oniris_persistent_wgs();       // one workgroup per CU (minus the CUs reserved for a gradient exchange in flight)
   const long long nblk = ntiles < ncu ? ntiles : ncu;

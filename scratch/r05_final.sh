@@ -10,6 +10,7 @@ python bench.py --net cs --frames 64 --steps 8 --warmup 4 --no-profile > $O/r05_
 python bench.py --mode rollout --gen-frames 256 --batch 1 > $O/r05_rollout_256.json 2> $O/r05_rollout_256.err
 ONIRIS_FORCE_DIST=1 python bench.py --steps 8 --warmup 4 --cpu-frames 0 --no-extra --no-profile > $O/r05_rccl_1rank.json 2> $O/r05_rccl_1rank.err
 ONIRIS_COMM_CUS=8 ONIRIS_DDP_EXCHANGE=mesh ONIRIS_DDP_BF16=1 ONIRIS_FORCE_DIST=1 python bench.py --steps 8 --warmup 4 --cpu-frames 0 --no-extra --no-profile > $O/r05_rccl_1rank_mesh_bf16_cus8.json 2> $O/r05_rccl_1rank_mesh_bf16_cus8.err
+ONIRIS_SHARE_GPU=1 python3 bench.py --gpus 2 --steps 4 --warmup 2 --cpu-frames 0 --no-profile --batch 2 > $O/r05_selflaunch2.json 2> $O/r05_selflaunch2.err
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ks -o ks -- python3 bench.py --steps 4 --warmup 2 --cpu-frames 0 --no-extra > $O/r05_prof_ks.log 2>&1
 cp "$(find $O/prof_ks -name '*kernel_stats.csv' | head -1)" $O/r05_kernel_stats.csv; rm -rf $O/prof_ks

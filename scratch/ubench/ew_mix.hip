@@ -47,6 +47,29 @@ __global__ __launch_bounds__(256) void k_mix(const bf16x8* __restrict__ a, const
   }
 }
 
+// the same with act_bwd's index arithmetic: gid -> (pixel, channel group) by a 64-bit division by the RUN-TIME group count
+template <bool NT, int DIVMODE>
+__global__ __launch_bounds__(256) void k_mix_div(const bf16x8* __restrict__ a, const bf16x8* __restrict__ b, const bf16x8* __restrict__ c,
+                                                 bf16x8* __restrict__ o, long long npix, int G, unsigned long long magic) {
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  long long pix; int cg;
+  if (DIVMODE == 0) { pix = gid / G; cg = (int)(gid % G); }
+  else { pix = (long long)(((unsigned long long)gid * magic) >> 40); cg = (int)(gid - pix * G); }     // magic = ceil(2^40 / G)
+  if (pix >= npix) return;
+  const size_t i = (size_t)pix * G + cg;
+  bf16x8 va, vb, vc;
+  if (NT) { va = __builtin_nontemporal_load(a + i); vb = __builtin_nontemporal_load(b + i); vc = __builtin_nontemporal_load(c + i); }
+  else { va = a[i]; vb = b[i]; vc = c[i]; }
+  bf16x8 r;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const float x = bf2f(vc[k]);
+    const float s = 1.f / (1.f + __expf(-x));
+    r[k] = f2bf(bf2f(va[k]) * (s * (1.f + x * (1.f - s))) * 1.6778523f + bf2f(vb[k]));
+  }
+  if (NT) __builtin_nontemporal_store(r, o + i); else o[i] = r;
+}
+
 template <bool NT>
 __global__ __launch_bounds__(256) void k_copy(const bf16x8* __restrict__ a, bf16x8* __restrict__ o, size_t n) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -76,6 +99,15 @@ int main() {
     printf("3R+1W  G=%d %s %s: %7.1f us  %.2f TB/s\n", G, NT ? "nt   " : "plain", MATH ? "silu'" : "add  ", us, 4.0 * bytes / us * 1e-6); }
   RUN(1, false, false) RUN(1, false, true) RUN(2, false, true) RUN(4, false, true)
   RUN(1, true, false) RUN(1, true, true) RUN(2, true, true) RUN(4, true, true)
+  for (int G : {4, 12}) {
+    const long long npix = (long long)(n / G);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    const unsigned long long magic = ((1ull << 40) + G - 1) / G;
+    float us = timeit([&] { hipLaunchKernelGGL((k_mix_div<true, 0>), dim3(grid), dim3(256), 0, 0, a, b, c, o, npix, G, magic); }, rep);
+    printf("3R+1W nt silu' + 64-bit div/mod by G=%2d: %7.1f us  %.2f TB/s\n", G, us, 4.0 * bytes / us * 1e-6);
+    us = timeit([&] { hipLaunchKernelGGL((k_mix_div<true, 1>), dim3(grid), dim3(256), 0, 0, a, b, c, o, npix, G, magic); }, rep);
+    printf("3R+1W nt silu' + multiply-shift   G=%2d: %7.1f us  %.2f TB/s\n", G, us, 4.0 * bytes / us * 1e-6);
+  }
   { const unsigned grid = (unsigned)((n + 255) / 256);
     float us = timeit([&] { hipLaunchKernelGGL(k_copy<false>, dim3(grid), dim3(256), 0, 0, a, o, n); }, rep);
     printf("copy 1R+1W plain: %7.1f us  %.2f TB/s\n", us, 2.0 * bytes / us * 1e-6);
