@@ -1,4 +1,4 @@
-// Attention heads of 8, 16 or 32 channels (Block(channels_per_head=...), reference networks_edm2.py:28; the reference's own
+// Attention heads of 8, 16, 24, ... 56 channels (every multiple of 8 below 64; round 4: 8 / 16 / 32) (Block(channels_per_head=...), reference networks_edm2.py:28; the reference's own
 // consistency tests build their nets with 16: edm2/consistency_test.py:39,61).
 //
 // The attention kernels of this library are written for 64-channel heads (every BASELINE configuration).  Other head
@@ -157,8 +157,12 @@ __global__ void rope_hd_kernel(const bf16* __restrict__ x, bf16* __restrict__ ou
   switch (D_) {                                              \
     case 8: { constexpr int D = 8; __VA_ARGS__; } break;     \
     case 16: { constexpr int D = 16; __VA_ARGS__; } break;   \
+    case 24: { constexpr int D = 24; __VA_ARGS__; } break;   \
     case 32: { constexpr int D = 32; __VA_ARGS__; } break;   \
-    default: oniris_set_error("attention head dimension %d: 8, 16, 32 (padded path) or 64", D_); return ONIRIS_EUNSUPPORTED; \
+    case 40: { constexpr int D = 40; __VA_ARGS__; } break;   \
+    case 48: { constexpr int D = 48; __VA_ARGS__; } break;   \
+    case 56: { constexpr int D = 56; __VA_ARGS__; } break;   \
+    default: oniris_set_error("attention head dimension %d: a multiple of 8 below 64 (padded path) or 64", D_); return ONIRIS_EUNSUPPORTED; \
   }
 
 extern "C" int oniris_qkv_norm_hd(const void* qkv, void* q, void* k, void* v, const float* cos_t, const float* sin_t,

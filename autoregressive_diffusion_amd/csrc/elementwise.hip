@@ -415,6 +415,90 @@ extern "C" int oniris_resample(const void* in, void* out, const void* add, int64
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// resample with a general separable filter (reference utils.py:94-107: f of even length L, normalised to sum 1, pad = (L-1)/2):
+//   mode 0 "down": depthwise conv2d with outer(f, f), stride 2, zero padding pad           (H, W = INPUT size)
+//   mode 1 "up":   depthwise conv_transpose2d with 4 * outer(f, f), stride 2, padding pad  (H, W = INPUT size)
+// `scale` multiplies the result, `add` (optional, shaped like out) is added: as in oniris_resample the adjoints are the other
+// mode with another scale (down^T = up * 0.25, up^T = down * 4).  One thread per (output pixel, 8 channels), fp32 sums, one
+// bf16 rounding.  [1, 1] gives exactly oniris_resample's 2x2 mean / nearest x2; the networks of the BASELINE configurations
+// use only that one (networks_edm2.py:26), so this pass is about completeness, not the roofline.
+struct ResampleTaps { float f[8]; int L; };
+
+__global__ void resample_filter_kernel(const bf16* __restrict__ in, bf16* __restrict__ out, const bf16* __restrict__ add,
+                                       long long nout8, int H, int W, int C, int mode, float scale, ResampleTaps tp) {
+  const int G = C >> 3, L = tp.L, pad = (L - 1) / 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nout8; i += (long long)gridDim.x * blockDim.x) {
+    const int cg = (int)(i % G);
+    long long p = i / G;
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = 0.f;
+    if (mode == 0) {
+      const int Wo = W >> 1, Ho = H >> 1;
+      const int xo = (int)(p % Wo); p /= Wo;
+      const int yo = (int)(p % Ho); const long long n = p / Ho;
+      for (int a_ = 0; a_ < L; ++a_) {
+        const int y = 2 * yo + a_ - pad;
+        if ((unsigned)y >= (unsigned)H) continue;
+        for (int b_ = 0; b_ < L; ++b_) {
+          const int x = 2 * xo + b_ - pad;
+          if ((unsigned)x >= (unsigned)W) continue;
+          const float w = tp.f[a_] * tp.f[b_];
+          const bf16x8 t = *(const bf16x8*)(in + ((n * H + y) * W + x) * C + cg * 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += w * bf2f(t[k]);
+        }
+      }
+    } else {
+      const int Wo = W << 1, Ho = H << 1;
+      const int X = (int)(p % Wo); p /= Wo;
+      const int Y = (int)(p % Ho); const long long n = p / Ho;
+      for (int a_ = (Y + pad) & 1; a_ < L; a_ += 2) {          // taps whose input row (Y + pad - a) / 2 is an integer
+        const int y = (Y + pad - a_) >> 1;
+        if (Y + pad - a_ < 0 || y >= H) continue;
+        for (int b_ = (X + pad) & 1; b_ < L; b_ += 2) {
+          const int x = (X + pad - b_) >> 1;
+          if (X + pad - b_ < 0 || x >= W) continue;
+          const float w = 4.f * tp.f[a_] * tp.f[b_];
+          const bf16x8 t = *(const bf16x8*)(in + ((n * H + y) * W + x) * C + cg * 8);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] += w * bf2f(t[k]);
+        }
+      }
+    }
+    bf16x8 o;
+    if (add) {
+      const bf16x8 d = *(const bf16x8*)(add + i * 8);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k] * scale + bf2f(d[k]));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) o[k] = f2bf(v[k] * scale);
+    }
+    *(bf16x8*)(out + i * 8) = o;
+  }
+}
+
+extern "C" int oniris_resample_filter(const void* in, void* out, const void* add, int64_t N, int H, int W, int C, int mode,
+                                      const float* taps, int ntaps, float scale, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  ONIRIS_CHECK_ARG(in && out && taps && N > 0 && H > 0 && W > 0 && C % 8 == 0 && (mode == 0 || mode == 1) &&
+                   (mode == 1 || (H % 2 == 0 && W % 2 == 0)), "resample_filter: bad arguments");
+  ONIRIS_CHECK_ARG(ntaps >= 2 && ntaps <= 8 && ntaps % 2 == 0, "resample_filter: an even number of taps, 2 .. 8 (got %d)", ntaps);
+  ResampleTaps tp;
+  for (int i = 0; i < 8; ++i) tp.f[i] = i < ntaps ? taps[i] : 0.f;
+  tp.L = ntaps;
+  const long long npix_out = (mode == 0) ? N * (H / 2) * (W / 2) : N * (H * 2LL) * (W * 2);
+  const long long n8 = npix_out * (C / 8);
+  long long nb = (n8 + 255) / 256;
+  if (nb > 16384) nb = 16384;
+  hipLaunchKernelGGL(resample_filter_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out,
+                     (const bf16*)add, n8, H, W, C, mode, scale, tp);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // DART training input / loss (edm2/loss.py:17-47 + Precond.forward, networks_edm2.py:278-297) without the ~25
 // activation-sized fp32 passes of the eager formulation.  Slot n = (b, s, t), s = 0 clean | 1 noised (S = 1: 2-D
 // steps); x[n] = images[b,t] + sigma[b, s*T+t] * noise[b, s*T+t]  (NCHW fp32 inputs, never materialised).

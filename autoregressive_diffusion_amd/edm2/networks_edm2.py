@@ -21,7 +21,9 @@ class Block(nn.Module):
                  resample_filter=[1, 1], attention=False, channels_per_head=64, dropout=0, res_balance=0.3,
                  attn_balance=0.3, clip_act=256):
         super().__init__()
-        assert list(resample_filter) == [1, 1], "only the [1,1] resampling filter of the reference configs"
+        # [1, 1] (every configuration of the reference, :26) runs inside the fused activation kernel; any other even-length filter
+        # (utils.py:94-107) goes through its own pass, oniris_resample_filter
+        self._taps = ops.resample_taps(resample_filter)
         self.out_channels, self.in_channels = out_channels, in_channels
         self.flavor, self.resample_filter, self.resample_mode = flavor, resample_filter, resample_mode
         self.num_heads = out_channels // channels_per_head if attention else 0
@@ -51,8 +53,8 @@ class Block(nn.Module):
         # adds the other consumer's gradient inside its own backward kernel, the mp_cat parks the skip gradient for it
         # the resampling (reference :63) runs inside the block's first activation kernel when that is the next op
         rs = self.resample_mode
-        if rs != "keep" and (skip is not None or (self.flavor == "enc" and self.conv_skip is not None)):
-            x, in_slot, rs = ops.resample(x, rs, in_slot), None, "keep"
+        if rs != "keep" and (self._taps is not None or skip is not None or (self.flavor == "enc" and self.conv_skip is not None)):
+            x, in_slot, rs = ops.resample(x, rs, in_slot, self._taps), None, "keep"
         # xs: the activation's xo is the residual of conv_res1 (no 1x1 skip conv in between): that conv parks the residual gradient
         # as (gradient of its output, ta) and the activation's backward kernel applies the factor -- ta * g is never written
         xs = ops.GradSlot() if (private_out and ops.ALIAS2 and self.training and torch.is_grad_enabled()

@@ -92,17 +92,26 @@ def mp_cat(a, b, dim=1, t=0.5):
 
 
 def resample(x, f=[1, 1], mode="keep"):
-    """(N, C, H, W): 'down' = 2x2 mean, 'up' = every pixel repeated 2x2 -- the reference's separable filter [1, 1]
-    (utils.py:94-107), the only one its networks use (networks_edm2.py:22); other filters are refused."""
+    """(N, C, H, W): 'down' / 'up' by 2 with the separable filter f (reference utils.py:94-107: even length, normalised; the
+    networks use [1, 1]: 2x2 mean / every pixel repeated 2x2).  Host-side helper on plain tensors: two 1-D depthwise passes
+    (rows, then columns) -- the strided ones for 'down', the transposed ones with 2 f per axis for 'up'."""
     if mode == "keep":
         return x
-    if [float(v) for v in f] != [1.0, 1.0]:
-        raise NotImplementedError("resample: only the [1, 1] filter of the reference configurations")
-    if mode == "down":
-        return torch.nn.functional.avg_pool2d(x, 2)
-    if mode != "up":
+    taps = torch.as_tensor([float(v) for v in f], dtype=x.dtype, device=x.device)
+    if taps.numel() % 2 != 0 or taps.numel() < 2:
+        raise ValueError("resample: the filter needs an even number of taps")
+    taps = taps / taps.sum()
+    if mode not in ("down", "up"):
         raise ValueError(f"resample: unknown mode {mode!r}")
-    return x.repeat_interleave(2, dim=-2).repeat_interleave(2, dim=-1)
+    c, L = x.shape[1], taps.numel()
+    pad = (L - 1) // 2
+    col = taps.reshape(1, 1, L, 1).expand(c, 1, L, 1).contiguous()
+    row = taps.reshape(1, 1, 1, L).expand(c, 1, 1, L).contiguous()
+    if mode == "down":
+        y = torch.nn.functional.conv2d(x, col, groups=c, stride=(2, 1), padding=(pad, 0))
+        return torch.nn.functional.conv2d(y, row, groups=c, stride=(1, 2), padding=(0, pad))
+    y = torch.nn.functional.conv_transpose2d(x, 2 * col, groups=c, stride=(2, 1), padding=(pad, 0))
+    return torch.nn.functional.conv_transpose2d(y, 2 * row, groups=c, stride=(1, 2), padding=(0, pad))
 
 
 def GaussianLoss(mean, logvar, target, eps=1e-4):

@@ -1125,15 +1125,37 @@ def act(x, skip=None, w1=1.0, w2=1.0, norm=False, want_xo=False, in_slot=None, s
     return _ActFn.apply(x, skip, float(w1), float(w2), bool(norm), bool(want_xo), in_slot, skip_slot, rs, xo_slot)
 
 
+def resample_taps(f):
+    """The normalised 1-D taps of a resampling filter (reference utils.py:94-100: even length, divided by its sum), or None for
+    the [1, 1] filter every BASELINE configuration uses (networks_edm2.py:26) -- that one runs inside the fused kernels."""
+    f = [float(v) for v in f]
+    if len(f) < 2 or len(f) > 8 or len(f) % 2 != 0:
+        raise NotImplementedError(f"resample filter {f}: an even number of taps, 2 .. 8")
+    tot = sum(f)
+    if tot == 0:
+        raise ValueError(f"resample filter {f} sums to zero")
+    t = tuple(v / tot for v in f)
+    return None if t == (0.5, 0.5) else t
+
+
+def _resample_launch(src, dst, add, N, H, W, C, mode, scale, taps):
+    if taps is None:
+        check(lib.oniris_resample(_p(src), _p(dst), _p(add), N, H, W, C, mode, scale, _stream()), "resample")
+    else:
+        arr = (ctypes.c_float * len(taps))(*taps)
+        check(lib.oniris_resample_filter(_p(src), _p(dst), _p(add), N, H, W, C, mode, arr, len(taps), scale, _stream()),
+              "resample_filter")
+
+
 class _ResampleFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, mode, in_slot=None):
+    def forward(ctx, x, mode, in_slot=None, taps=None):
         _need_gpu(x)
         N, H, W, C = x.shape
         x = x.contiguous()
         out = torch.empty((N, H // 2, W // 2, C) if mode == 0 else (N, H * 2, W * 2, C), dtype=BF16, device=x.device)
-        check(lib.oniris_resample(_p(x), _p(out), None, N, H, W, C, mode, 1.0, _stream()), "resample")
-        ctx.mode, ctx.slot = mode, in_slot
+        _resample_launch(x, out, None, N, H, W, C, mode, 1.0, taps)
+        ctx.mode, ctx.slot, ctx.taps = mode, in_slot, taps
         return out
 
     @staticmethod
@@ -1143,22 +1165,22 @@ class _ResampleFn(torch.autograd.Function):
         dadd = ctx.slot.take() if ctx.slot is not None else None        # (see GradSlot)
         if dadd is not None:
             dadd = dadd.contiguous()
-        if ctx.mode == 0:      # adjoint of the 2x2 mean: nearest x2 scaled by 1/4
+        if ctx.mode == 0:      # adjoint of the strided filter: the transposed one (weights 4 f f^T) scaled by 1/4
             dx = torch.empty((N, H * 2, W * 2, C), dtype=BF16, device=g.device)
             assert dadd is None or dadd.shape == dx.shape
-            check(lib.oniris_resample(_p(g), _p(dx), _p(dadd), N, H, W, C, 1, 0.25, _stream()), "resample")
-        else:                  # adjoint of nearest x2: 2x2 sum = 4 * mean
+            _resample_launch(g, dx, dadd, N, H, W, C, 1, 0.25, ctx.taps)
+        else:                  # adjoint of the transposed filter: the strided one scaled by 4
             dx = torch.empty((N, H // 2, W // 2, C), dtype=BF16, device=g.device)
             assert dadd is None or dadd.shape == dx.shape
-            check(lib.oniris_resample(_p(g), _p(dx), _p(dadd), N, H, W, C, 0, 4.0, _stream()), "resample")
-        return dx, None, None
+            _resample_launch(g, dx, dadd, N, H, W, C, 0, 4.0, ctx.taps)
+        return dx, None, None, None
 
 
-def resample(x, mode, in_slot=None):
-    """mode 'keep' | 'down' (2x2 mean) | 'up' (nearest x2)   (utils.py:94-107 with f=[1,1])."""
+def resample(x, mode, in_slot=None, taps=None):
+    """mode 'keep' | 'down' | 'up' (utils.py:94-107); taps: resample_taps(f) -- None = the [1, 1] filter (2x2 mean / nearest x2)."""
     if mode == "keep":
         return x
-    return _ResampleFn.apply(x, 0 if mode == "down" else 1, in_slot)
+    return _ResampleFn.apply(x, 0 if mode == "down" else 1, in_slot, taps)
 
 
 class _SplitCols(torch.autograd.Function):
@@ -1626,13 +1648,14 @@ class _AttentionFn(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None
 
 
-HEAD_DIMS_PADDED = (8, 16, 32)        # served through the 64-channel kernels on zero-padded heads (csrc/attention_hd.hip)
+HEAD_DIMS_PADDED = (8, 16, 24, 32, 40, 48, 56)     # served through the 64-channel kernels on zero-padded heads (csrc/attention_hd.hip)
 
 
 def _head_dim(C, heads):
     d = C // max(heads, 1)
     if heads <= 0 or C != heads * d or (d != 64 and d not in HEAD_DIMS_PADDED):
-        raise NotImplementedError(f"attention head dimension {C}/{heads}: 64, or 8 / 16 / 32 through the padded path")
+        raise NotImplementedError(f"attention head dimension {C}/{heads}: 64, or a multiple of 8 below 64 through the padded path "
+                                  "(heads wider than 64 channels would need attention kernels of their own)")
     return d
 
 

@@ -344,6 +344,12 @@ int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void* dv /* ABI
 int oniris_mpsum_mask(void* g, const void* out, int64_t numel, float clip, const int32_t* clip_flag, oniris_stream_t stream);
 int oniris_resample(const void* in, void* out, const void* add, int64_t N, int H, int W, int C, int mode, float scale,
                     oniris_stream_t stream);
+/* ABI 12: the same with a general separable filter (utils.py:94-107: `taps` [host] = the 1-D filter f NORMALISED to sum 1, an even
+ * number of taps 2 .. 8, padding (ntaps - 1) / 2): mode 0 = depthwise conv2d with outer(f, f), stride 2; mode 1 = depthwise
+ * conv_transpose2d with 4 * outer(f, f), stride 2.  taps = {0.5, 0.5} is oniris_resample.  Block(resample_filter=...),
+ * networks_edm2.py:26,66.                                                                                               */
+int oniris_resample_filter(const void* in, void* out, const void* add, int64_t N, int H, int W, int C, int mode,
+                           const float* taps /* [host] */, int ntaps, float scale, oniris_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * VideoAttention / FrameAttention (edm2/attention/attention_modules.py:30-82, 105-119; RoPe.py:43-68).

@@ -124,12 +124,22 @@ def mp_cat(a, b, t=0.5):
     return torch.cat([a * (C / math.sqrt(Na) * (1 - t)), b * (C / math.sqrt(Nb) * t)], dim=1)
 
 
-def resample(x, mode):
+def resample(x, mode, f=(1, 1)):
+    """utils.py:94-107: 'down' = depthwise conv2d with outer(f, f) / sum^2, stride 2, padding (len - 1) // 2; 'up' = depthwise
+    conv_transpose2d with 4 x that, stride 2."""
     if mode == "keep":
         return x
-    if mode == "down":                                   # depthwise [1,1]x[1,1]/4, stride 2  == 2x2 mean
-        return F.avg_pool2d(x, 2)
-    return x.repeat_interleave(2, -1).repeat_interleave(2, -2)   # transposed conv with 4*[.25] == nearest x2
+    if tuple(float(v) for v in f) == (1.0, 1.0):
+        if mode == "down":                               # depthwise [1,1]x[1,1]/4, stride 2  == 2x2 mean
+            return F.avg_pool2d(x, 2)
+        return x.repeat_interleave(2, -1).repeat_interleave(2, -2)   # transposed conv with 4*[.25] == nearest x2
+    t = torch.tensor([float(v) for v in f], dtype=x.dtype)
+    t = t / t.sum()
+    k2 = torch.outer(t, t)[None, None].repeat(x.shape[1], 1, 1, 1)
+    pad = (len(f) - 1) // 2
+    if mode == "down":
+        return F.conv2d(x, k2, groups=x.shape[1], stride=2, padding=pad)
+    return F.conv_transpose2d(x, 4 * k2, groups=x.shape[1], stride=2, padding=pad)
 
 
 def mp_fourier(x, freqs, phases):
@@ -373,7 +383,7 @@ def block_forward(p, prefix, e, x, emb, B, c_noise, cache, update_cache, just_2d
                   res_balance=0.3, clip_act=256, new_p=None):
     if cache is None:
         cache = {}
-    x = resample(x, e["mode"])
+    x = resample(x, e["mode"], e.get("filter", (1, 1)))
     skipw = prefix + "conv_skip.weight.weight"
     if e["flavor"] == "enc":
         if e["cin"] != e["cout"]:

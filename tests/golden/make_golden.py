@@ -383,6 +383,41 @@ def g7():
     save("g7_blocks", **out)
 
 
+# ------------------------------------------------------------------ G13 resampling filters other than [1, 1]
+def g13():
+    """`resample(x, f, mode)` of the reference (edm2/utils.py:94-107) for f = [1, 3, 3, 1] and [1, 2, 3, 3, 2, 1] (values and input
+    gradients), and one encoder Block with resample_mode='down', resample_filter=[1, 3, 3, 1] (networks_edm2.py:26,66): output
+    and input gradient.  No BASELINE configuration uses such a filter; the fixture pins the generalisation."""
+    from edm2.utils import resample
+    out = {}
+    g = torch.Generator().manual_seed(130)
+    for tag, f in (("f4", [1, 3, 3, 1]), ("f6", [1, 2, 3, 3, 2, 1])):
+        out[f"{tag}_f"] = np.float32(f)
+        for mode, shape in (("down", (3, 8, 12, 16)), ("up", (3, 8, 6, 4))):
+            x = torch.randn(*shape, generator=g, requires_grad=True)
+            y = resample(x, f=f, mode=mode)
+            gy = torch.randn(y.shape, generator=g)
+            (y * gy).sum().backward()
+            out.update({f"{tag}_{mode}_x": x, f"{tag}_{mode}_y": y, f"{tag}_{mode}_gy": gy, f"{tag}_{mode}_gx": x.grad})
+    cemb, cin, cout, H, T, B = 32, 32, 32, 16, 2, 1
+    shapes = {"emb_gain": (), "emb_linear.weight.weight": (cout, cemb)}
+    shapes.update(paramgen._conv_keys("conv_res0.", cout, cout))
+    shapes.update(paramgen._conv_keys("conv_res1.", cout, cout))
+    p = paramgen.prenormalise(paramgen.fill(shapes, 131))
+    blk = Block(cin, cout, cemb, flavor="enc", resample_mode="down", resample_filter=[1, 3, 3, 1])
+    blk.load_state_dict({k: v.clone() for k, v in p.items()}, strict=True)
+    N = B * 2 * T
+    x = torch.randn(N, cin, H, H, generator=g, requires_grad=True)
+    emb = torch.randn(N, cemb, generator=g, requires_grad=True)
+    cn = torch.randn(B, 2 * T, generator=g) * 0.5
+    blk.train()
+    y, _ = blk(x, emb, B, cn)
+    gy = torch.randn(y.shape, generator=g)
+    (y * gy).sum().backward()
+    out.update(blk_seed=np.int64(131), blk_x=x, blk_emb=emb, blk_cn=cn, blk_y=y, blk_gy=gy, blk_gx=x.grad, blk_gemb=emb.grad)
+    save("g13_resample_filter", **out)
+
+
 SMALL_CFG = dict(img_resolution=32, img_channels=4, label_dim=4, model_channels=16, channel_mult=[1, 4, 4],
                  num_blocks=1, video_attn_resolutions=[8], frame_attn_resolutions=[16])
 C1_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=16, channel_mult=[1, 2, 4, 8],
@@ -610,6 +645,6 @@ def g12():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g6b", "g7", "g8", "g9", "g9b", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g5", "g6", "g6b", "g7", "g8", "g9", "g9b", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

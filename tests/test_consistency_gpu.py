@@ -29,7 +29,8 @@ def _bt(x, b):
     return x.reshape(b, -1, *x.shape[1:])
 
 
-HEAD_CHANNELS = (16, 64)          # consistency_test.py:39,61 (4 * IMG_CHANNELS over 4 heads); networks_edm2.py:28
+HEAD_CHANNELS = (16, 48, 64)      # consistency_test.py:39,61 (4 * IMG_CHANNELS over 4 heads); networks_edm2.py:28; 48: a width that
+                                  # is neither a power of two nor a BASELINE value (every multiple of 8 up to 64 is served, round 5)
 
 
 @pytest.fixture(scope="module", params=HEAD_CHANNELS, ids=lambda c: f"head{c}")

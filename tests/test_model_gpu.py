@@ -197,6 +197,25 @@ def test_g7_blocks():
         assert max(own.values()) < G7_GATE_BOUNDS[tag][0] and max(rtop.values()) < G7_GATE_BOUNDS[tag][1], (own, rtop)
 
 
+def test_g13_block_with_resample_filter():
+    """An encoder Block built with resample_filter=[1, 3, 3, 1] (networks_edm2.py:26,66) against the reference's output and input
+    gradients (fixture G13): training forward + backward, and the one-frame evaluation path through the same filter pass."""
+    from edm2.networks_edm2 import Block
+    from test_oracle_golden import _g13_block
+    z = load("g13_resample_filter")
+    p, _ = _g13_block(z)
+    blk = load_params(Block(32, 32, 32, flavor="enc", resample_mode="down", resample_filter=[1, 3, 3, 1]), p).train()
+    x = T(z["blk_x"]).to(DEV).requires_grad_(True)
+    emb = T(z["blk_emb"]).to(DEV).requires_grad_(True)
+    y, _ = blk(x, emb, 1, T(z["blk_cn"]).to(DEV))
+    y.backward(T(z["blk_gy"]).to(DEV))
+    e = dict(y=rel(y, z["blk_y"]), gx=rel(x.grad, z["blk_gx"]), gemb=rel(emb.grad, z["blk_gemb"]))
+    print("g13 block", e)
+    assert e["y"] < 1e-2 and e["gx"] < 1.5e-2 and e["gemb"] < 2e-2
+    with pytest.raises(NotImplementedError):
+        Block(32, 32, 32, flavor="enc", resample_mode="down", resample_filter=[1, 2, 1])      # odd length: the reference asserts too
+
+
 SMALL_CFG = dict(img_resolution=32, img_channels=4, label_dim=4, model_channels=16, channel_mult=[1, 4, 4],
                  num_blocks=1, video_attn_resolutions=[8], frame_attn_resolutions=[16])
 C1_CFG = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=16, channel_mult=[1, 2, 4, 8],

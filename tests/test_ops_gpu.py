@@ -694,6 +694,42 @@ def test_resample_fused():
         assert rel(nchw(y), yr) < 5e-3 and rel(nchw(x.grad), xr.grad) < 5e-3
 
 
+@pytest.mark.parametrize("f", [[1, 1], [1, 3, 3, 1], [1, 2, 3, 3, 2, 1], [2, 5]])
+def test_resample_general_filter(f):
+    """oniris_resample_filter (Block(resample_filter=...), reference utils.py:94-107) against the oracle's conv2d /
+    conv_transpose2d form, forward and adjoint, with a parked second gradient joining in the backward kernel; [1, 1] must
+    reproduce the fused 2x2-mean / nearest-x2 kernel bit for bit."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(10 + len(f))
+    taps = ops.resample_taps(f)
+    assert (taps is None) == (f == [1, 1])
+    x0 = bfr(torch.randn(3, 32, 12, 16))
+    for mode in ("down", "up"):
+        x = nhwc(x0).requires_grad_(True)
+        slot = ops.GradSlot()
+        y = ops.resample(x, mode, slot, taps)
+        g0 = bfr(torch.randn(nchw(y).shape))
+        extra = bfr(torch.randn(x0.shape))
+        slot.put(nhwc(extra))
+        y.backward(nhwc(g0))
+        xr = x0.clone().requires_grad_(True)
+        yr = O.resample(xr, mode, f)
+        (yr * g0).sum().backward()
+        e = (rel(nchw(y), yr), rel(nchw(x.grad), xr.grad + extra))
+        print("resample", f, mode, e)
+        assert max(e) < 5e-3
+        if f == [1, 1]:                                       # the general kernel on the [1, 1] taps == the dedicated one
+            from autoregressive_diffusion_amd._lib import lib, check
+            import ctypes
+            out = torch.empty_like(y)
+            arr = (ctypes.c_float * 2)(0.5, 0.5)
+            N, H, W, C = x.shape
+            check(lib.oniris_resample_filter(ops._p(x.detach()), ops._p(out), None, N, H, W, C, 0 if mode == "down" else 1, arr, 2, 1.0,
+                                             ops._stream()), "resample_filter")
+            assert torch.equal(out, y.detach())
+    ops.GradSlot.live = []
+
+
 def test_clip_flags_survive_a_second_forward_before_backward():
     """the forward's "did the clip change anything" flag is read by the backward.  A second grad-enabled forward
     before that backward (two micro-batches summed into one loss; a train-mode evaluation in between) rewinds and refills the

@@ -326,3 +326,38 @@ def test_g6b_attention_small_heads():
     close(y, z["f_y"], rtol=5e-5)
     (y * T(z["f_gy"])).sum().backward()
     close(x.grad, z["f_gx"], rtol=1e-4); close(p["f.attn_qkv.weight.weight"].grad, z["f_g_qkv"], rtol=2e-4)
+
+
+def test_g13_resample_filters():
+    """Resampling filters other than [1, 1] (utils.py:94-107; Block(resample_filter=...), networks_edm2.py:26,66): the oracle's
+    general form and the package's host-side `edm2.utils.resample` against values and gradients produced by the reference, and
+    one encoder Block built with [1, 3, 3, 1]."""
+    import edm2.utils as U
+    z = load("g13_resample_filter")
+    for tag in ("f4", "f6"):
+        f = [float(v) for v in z[tag + "_f"]]
+        for mode in ("down", "up"):
+            for fn in (lambda x: O.resample(x, mode, f), lambda x: U.resample(x, f, mode)):
+                x = T(z[f"{tag}_{mode}_x"]).requires_grad_(True)
+                y = fn(x)
+                close(y, z[f"{tag}_{mode}_y"], rtol=2e-5, what=f"{tag} {mode} y")
+                (y * T(z[f"{tag}_{mode}_gy"])).sum().backward()
+                close(x.grad, z[f"{tag}_{mode}_gx"], rtol=2e-5, what=f"{tag} {mode} gx")
+    p, e = _g13_block(z)
+    p = {"b." + k: v.requires_grad_(v.is_floating_point()) for k, v in p.items()}
+    x, emb = T(z["blk_x"]).requires_grad_(True), T(z["blk_emb"]).requires_grad_(True)
+    y, _ = O.block_forward(p, "b.", e, x, emb, 1, T(z["blk_cn"]), None, False, False, True)
+    close(y, z["blk_y"], rtol=1e-4, what="block y")
+    (y * T(z["blk_gy"])).sum().backward()
+    close(x.grad, z["blk_gx"], rtol=3e-4, what="block gx")
+    close(emb.grad, z["blk_gemb"], rtol=3e-4, what="block gemb")
+
+
+def _g13_block(z):
+    cemb, cout = 32, 32
+    shapes = {"emb_gain": (), "emb_linear.weight.weight": (cout, cemb)}
+    shapes.update(paramgen._conv_keys("conv_res0.", cout, cout))
+    shapes.update(paramgen._conv_keys("conv_res1.", cout, cout))
+    p = paramgen.prenormalise(paramgen.fill(shapes, int(z["blk_seed"])))
+    e = dict(kind="block", name="blk", cin=32, cout=32, flavor="enc", mode="down", attention=None, heads=0, filter=(1, 3, 3, 1))
+    return p, e

@@ -514,7 +514,8 @@ def test_qkv_norm_rope_bf16_faithful(B, T, H, m):
     assert max(e) <= TIGHT and eb <= TIGHT
 
 
-@pytest.mark.parametrize("B,T,H,m,d", [(2, 4, 8, 4, 16), (1, 8, 8, 2, 32), (1, 4, 16, 4, 8)])
+@pytest.mark.parametrize("B,T,H,m,d", [(2, 4, 8, 4, 16), (1, 8, 8, 2, 32), (1, 4, 16, 4, 8), (1, 4, 8, 2, 48), (1, 4, 8, 2, 24),
+                                       (1, 2, 8, 1, 56), (1, 2, 8, 3, 40)])
 def test_qkv_norm_hd_bf16_faithful(B, T, H, m, d):
     """The same pass for heads of 8 / 16 / 32 channels (Block(channels_per_head=), networks_edm2.py:28; the reference's tests use
     16): per-head norm over d channels, rotary embedding with its partner d/2 channels away, q scaled by log2(e)/sqrt(d), heads
