@@ -39,7 +39,8 @@ class ConvArgs(C.Structure):
                 ("ta", c_float), ("tb", c_float), ("clip", c_float), ("ctx_out", c_void_p),
                 ("big_tile", c_int32), ("escale_pitch", c_int32),
                 ("splitk_ws", c_void_p), ("splitk_ws_bytes", C.c_size_t), ("clip_flag", c_void_p),
-                ("ctx_prod", c_void_p), ("ctx_prod_mode", c_int32)]
+                ("ctx_prod", c_void_p), ("ctx_prod_mode", c_int32), ("x_split", c_int32), ("x2", c_void_p), ("act_out", c_void_p),
+                ("cat_w1", c_float), ("cat_w2", c_float)]
 
 
 class WgradArgs(C.Structure):

@@ -16,6 +16,7 @@ extern "C" int oniris_conv_fwd(const OnirisConvArgs* args, oniris_stream_t strea
                    "conv_fwd: bad padded sizes CoutP=%d CinP=%d", a.CoutP, a.CinP);
   ONIRIS_CHECK_ARG(a.epi != ONIRIS_EPI_MPSUM || a.res, "conv_fwd: EPI_MPSUM needs res");
   ONIRIS_CHECK_ARG(a.epi != ONIRIS_EPI_EMB_SILU || (a.escale && a.out2), "conv_fwd: EPI_EMB_SILU needs escale/out2");
+  ONIRIS_CHECK_ARG(a.x2 == nullptr || (a.taps == 1 && a.ctx == nullptr), "conv_fwd: x2 (concatenated input) is a 1x1, context-free option");
   const bool has_ctx = a.ctx != nullptr;
   ONIRIS_CHECK_ARG(!has_ctx || (a.w_ctx && a.taps == 9), "conv_fwd: context path needs w_ctx and taps == 9");
   // clip_flag is answered by the LDS-DMA / streaming 3x3 kernels of the training layouts only (conv_dispatch_s2ctx, _s1); every

@@ -21,6 +21,14 @@ int conv_dispatch_s1(const OnirisConvArgs& a, hipStream_t st) {
   return conv3x3_pick<1, false>(a, st);
 }
 int conv_dispatch_1x1(const OnirisConvArgs& a, hipStream_t st) {
+  if (a.x2) {                                       // two-source input + activation side output: the register-staged kernel only
+    if (a.x_split <= 0 || a.x_split >= a.Cin || a.x_split % 8 != 0 || a.Cin % 8 != 0 || a.S != 1 ||
+        (a.big_tile >= 3 && conv1x1_glds_ok(a))) {
+      oniris_set_error("conv_fwd: x2 / act_out (concatenated input) is served by the register-staged 1x1 kernel only "
+                       "(x_split a multiple of 8 inside (0, Cin), fewer than 8192 positions)");
+      return ONIRIS_EUNSUPPORTED;
+    }
+  }
   if (a.big_tile >= 3 && conv1x1_glds_ok(a)) return launch_conv1x1_glds(a, st);     // persistent LDS-DMA GEMM
   if (a.CoutP % 64 == 0) return launch_conv_fwd<1, 1, 64, 2, false, 16>(a, st);
   // 96 output channels (the 32 -> 96 dgrad of the 64x64-level skip conv): one workgroup per pixel tile instead of three

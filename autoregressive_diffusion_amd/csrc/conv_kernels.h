@@ -185,8 +185,18 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
         if (e < TOTA) {
           const int row = e / PARTS;
           const int s = row / NPOS, q = q0 + (row % NPOS);
-          if (q < T * HWp && cok)
-            ra[i] = *(const u32x4*)(xg + ((size_t)(b * S + s) * T * HWp + q) * Cin + c0 + part8);
+          if (q < T * HWp && cok) {
+            const size_t pos = (size_t)(b * S + s) * T * HWp + q;
+            if (a.x2 == nullptr) {
+              ra[i] = *(const u32x4*)(xg + pos * Cin + c0 + part8);
+            } else {
+              // two-source input (OnirisConvArgs.x2): the decoder's mp_cat; the raw piece is loaded here, scaled / rounded /
+              // activated when it is written to LDS (store_phase): the load stays in flight under the MFMAs of the phase before
+              const int c = c0 + part8, C1 = a.x_split;
+              ra[i] = (c < C1) ? *(const u32x4*)(xg + pos * C1 + c)
+                               : *(const u32x4*)((const bf16*)a.x2 + pos * (Cin - C1) + (c - C1));
+            }
+          }
         }
       }
     }
@@ -202,8 +212,38 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
       }
     }
   };
-  auto store_phase = [&](int ph) __attribute__((always_inline)) {
+  auto store_phase = [&](int ph, int ch) __attribute__((always_inline)) {
     const int tot = (ph == 0) ? TOTA : TOTC;
+    if constexpr (TAPS == 1) {
+      if (a.x2 != nullptr) {
+        // xo = bf16(w * source) is what the MFMAs consume; its mp_silu goes out to act_out from the workgroups of the first
+        // output-channel block (the rounding conventions of oniris_act_fwd: the activation sees the ROUNDED xo)
+        const int c = ch * CK + part8;
+        const float w = (c < a.x_split) ? a.cat_w1 : a.cat_w2;
+#pragma unroll
+        for (int i = 0; i < NIA; ++i) {
+          const int e = tid + i * NTHR;
+          if (e < TOTA) {
+            const int row = e / PARTS;
+            const int s = row / NPOS, q = q0 + (row % NPOS);
+            const bf16x8 in = __builtin_bit_cast(bf16x8, ra[i]);
+            bf16x8 o;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) o[k] = f2bf(bf2f(in[k]) * w);
+            ra[i] = __builtin_bit_cast(u32x4, o);
+            if (co0 == 0 && a.act_out && q < T * HWp && c < Cin) {
+              bf16x8 av;
+#pragma unroll
+              for (int k = 0; k < 8; ++k) {
+                const float z = bf2f(o[k]);
+                av[k] = f2bf(z * sigmoid_fast(z) * (1.0f / 0.596f));
+              }
+              *(bf16x8*)((bf16*)a.act_out + ((size_t)(b * S + s) * T * HWp + q) * Cin + c) = av;
+            }
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < NIA; ++i) {
       const int e = tid + i * NTHR;
@@ -256,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
 #pragma unroll 1
   for (int itp = it0; itp < nphase; ++itp) {
     const int ph = itp % NPH;
-    store_phase(ph);
+    store_phase(ph, itp / NPH);
     __syncthreads();
     if (itp + 1 < nphase) load_phase((itp + 1) / NPH, (itp + 1) % NPH);
     // ------------------------------------------------------------------ MFMA over taps x k-steps

@@ -57,12 +57,19 @@ class Block(nn.Module):
             x, in_slot, rs = ops.resample(x, rs, in_slot, self._taps), None, "keep"
         # xs: the activation's xo is the residual of conv_res1 (no 1x1 skip conv in between): that conv parks the residual gradient
         # as (gradient of its output, ta) and the activation's backward kernel applies the factor -- ta * g is never written
+        skip_conv_done = False
         xs = ops.GradSlot() if (private_out and ops.ALIAS2 and self.training and torch.is_grad_enabled()
                                 and not (self.flavor == "dec" and self.conv_skip is not None)) else None
         if self.flavor == "enc":
             if self.conv_skip is not None:
                 x, in_slot = self.conv_skip._cl(x, in_slot=in_slot), None
             x, a = ops.act(x, norm=True, in_slot=in_slot, resample=rs, xo_slot=xs)     # x <- pixel norm(x); a = mp_silu(x)
+        elif (skip is not None and self.conv_skip is not None and not self.training
+              and ops.conv_cat_act_ok(x, skip, self.conv_skip.weight.pw)):
+            # evaluation (one generated frame: every launch is ~5 us of latency around almost no work): mp_cat, mp_silu and the
+            # 1x1 skip conv of the concatenation in ONE launch; the concatenated tensor itself is never written
+            x, a = ops.conv_cat_act(x, skip, cat_w[0], cat_w[1], self.conv_skip.weight.pw)
+            skip_conv_done = True
         elif skip is not None:
             x, a = ops.act(x, skip, cat_w[0], cat_w[1], want_xo=True, in_slot=in_slot, skip_slot=skip_slot, xo_slot=xs)   # x <- mp_cat(x, skip); a = mp_silu(x)
         else:
@@ -74,7 +81,7 @@ class Block(nn.Module):
                                                    just_2d, cscale=c)    # y = mp_silu(conv(a) * c)
         if self.training and self.dropout != 0:
             y = F.dropout(y, p=self.dropout)
-        if self.flavor == "dec" and self.conv_skip is not None:
+        if self.flavor == "dec" and self.conv_skip is not None and not skip_conv_done:
             x = self.conv_skip._cl(x)
         t = self.res_balance
         den = 1.0 / math.sqrt((1 - t) ** 2 + t ** 2)

@@ -517,7 +517,8 @@ CLIP_FLAG = int(_os.environ.get("ONIRIS_CLIP_FLAG", "1"))    # 0: the mp_sum bac
 
 def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP, Cout, CoutP, taps,
                  ctx_bstride=0, ctx_T=0, coff=(0, 0), ctx_fill=0.0, epi=0, res=None, escale=None, emb_gain=None,
-                 out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None, clip_flag=None, ctx_prod=None, ctx_prod_mode=0):
+                 out2=None, ta=0.0, tb=0.0, clip=0.0, ctx_out=None, clip_flag=None, ctx_prod=None, ctx_prod_mode=0,
+                 x2=None, act_out=None, x_split=0, cat_w=(1.0, 1.0)):
     if KernelProfile.enabled:
         flops = 2.0 * B * S * T * H * W * Cout * Cin * taps
         if ctx is not None:
@@ -570,6 +571,8 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
     a.ta, a.tb, a.clip, a.ctx_out = ta, tb, clip, _p(ctx_out)
     a.clip_flag = _p(clip_flag)
     a.ctx_prod, a.ctx_prod_mode = _p(ctx_prod), ctx_prod_mode
+    if x2 is not None:
+        a.x2, a.act_out, a.x_split, a.cat_w1, a.cat_w2 = _p(x2), _p(act_out), x_split, cat_w[0], cat_w[1]
     a.big_tile = BIG_TILE
     if SPLITK and B * S * T * H * W <= 64 * 256 and ctx_prod_mode == 0:      # few tiles (one rollout frame): lend the split-K workspace
         ws = _splitk_workspace(x.device)
@@ -914,6 +917,34 @@ def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0
     cfg = ConvCfg(pw2, pw3, B, T, epi, ta, tb, clip, torch.is_grad_enabled(), grad_private=grad_private, res_slot=res_slot,
                   res_alias=res_alias)
     return _ConvOp.apply(x, pw2.param, pw3.param, ca, cb, cscale, res, cfg)
+
+
+CAT_ACT_FUSED = int(_os.environ.get("ONIRIS_CAT_ACT_FUSED", "1"))      # 0: the decoder's mp_cat + mp_silu and its 1x1 skip conv as two launches (A/B)
+
+
+def conv_cat_act_ok(x, skip, pw):
+    """True when oniris_conv_fwd's two-source form (OnirisConvArgs.x2) serves this evaluation-sized 1x1 conv: the register-staged
+    kernel takes it (mirrors conv_dispatch_1x1 / conv1x1_glds_ok in csrc)."""
+    N, H, W, C1 = x.shape
+    Cin = C1 + skip.shape[-1]
+    glds = BIG_TILE >= 3 and Cin % 64 == 0 and pw.CinP == Cin and Cin <= 1024 and N * H * W >= 8192
+    return bool(CAT_ACT_FUSED and x.is_cuda and not torch.is_grad_enabled() and pw.taps == 1 and pw.cin == Cin and C1 % 8 == 0
+                and Cin % 8 == 0 and not glds and x.is_contiguous() and skip.is_contiguous())
+
+
+@torch.no_grad()
+def conv_cat_act(x, skip, w1, w2, pw):
+    """Evaluation only (the sampler's one-frame UNet calls): (conv1x1(xo, W), a) with xo = mp_cat(x, skip) = [w1 x, w2 skip] rounded
+    to bf16 and a = mp_silu(xo), in ONE launch -- xo itself is never written (reference networks_edm2.py:230 mp_cat, :73 mp_silu,
+    :85 conv_skip: the head of a decoder Block).  Bit-identical to ops.act(x, skip, w1, w2, want_xo=True) followed by ops.conv."""
+    N, H, W, C1 = x.shape
+    Cin = C1 + skip.shape[-1]
+    Co = roundup(pw.cout, 8)
+    out = torch.empty((N, H, W, Co), dtype=BF16, device=x.device)
+    a = torch.empty((N, H, W, Cin), dtype=BF16, device=x.device)
+    _conv_launch(x, None, pw.wf, None, out, None, None, 1, 1, N, H, W, Cin, pw.CinP, Co, pw.CoutP, 1,
+                 x2=skip, act_out=a, x_split=C1, cat_w=(float(w1), float(w2)))
+    return out, a
 
 
 KEEP_CTX_PRODUCT = int(_os.environ.get("ONIRIS_KEEP_CTX_PRODUCT", "1"))     # A/B knob: 0 = every evaluation recomputes y3

@@ -251,6 +251,17 @@ typedef struct OnirisConvArgs {
    * A launch with ctx_prod_mode != 0 that the one-frame kernel cannot serve fails with ONIRIS_EUNSUPPORTED.        */
   float* ctx_prod;
   int32_t ctx_prod_mode;
+  /* Optional (ABI 12; 1x1 convs through the register-staged kernel only: evaluation-sized launches): the input is the
+   * magnitude-preserving CONCATENATION of two tensors, formed on the way in -- channels [0, x_split) come from x ([pos][x_split])
+   * times cat_w1, channels [x_split, Cin) from x2 ([pos][Cin - x_split]) times cat_w2, each product rounded to bf16 (utils.py:128-134:
+   * what oniris_act_fwd stores as xo) -- and act_out [pos][Cin] receives mp_silu of that value (utils.py:112: silu / 0.596, of the
+   * ROUNDED xo).  The decoder Block of an evaluation (networks_edm2.py:230 mp_cat, :73 mp_silu, :85 conv_skip): one launch
+   * instead of the activation pass + the 1x1 conv, 13 of an evaluation's 141.  x2 == NULL: off.  A launch with x2 that the
+   * LDS-DMA 1x1 kernel would take (>= 8192 positions) fails with ONIRIS_EUNSUPPORTED: the caller keeps the two launches.       */
+  int32_t x_split;
+  const void* x2;
+  void* act_out;
+  float cat_w1, cat_w2;
 } OnirisConvArgs;
 
 int oniris_conv_fwd(const OnirisConvArgs* args /* [host] */, oniris_stream_t stream);

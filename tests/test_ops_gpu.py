@@ -694,6 +694,30 @@ def test_resample_fused():
         assert rel(nchw(y), yr) < 5e-3 and rel(nchw(x.grad), xr.grad) < 5e-3
 
 
+@pytest.mark.parametrize("N,H,C1,C2,cout", [(1, 64, 32, 32, 32), (1, 16, 128, 64, 128), (2, 8, 256, 256, 256), (1, 32, 64, 32, 64),
+                                            (3, 8, 128, 256, 256)])
+def test_conv_cat_act_matches_act_then_conv(N, H, C1, C2, cout):
+    """OnirisConvArgs.x2 / act_out (round 5): the head of a decoder Block in an evaluation -- mp_cat, mp_silu and the 1x1 skip
+    conv of the concatenation -- as ONE launch, bit-identical to oniris_act_fwd followed by the 1x1 conv (also through the
+    split-K pair of launches the one-frame sizes take)."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(N + H + C1)
+    p = torch.nn.Parameter(O.normalize(O.normalize(torch.randn(cout, C1 + C2, 1, 1))).to(DEV))
+    bank, (pw,) = make_bank([p])
+    bank.prepare(training=False)
+    x = nhwc(bfr(torch.randn(N, C1, H, H) * 1.5))
+    skip = nhwc(bfr(torch.randn(N, C2, H, H)))
+    w1, w2 = 0.83, 1.21
+    with torch.no_grad():
+        assert ops.conv_cat_act_ok(x, skip, pw)
+        y, a = ops.conv_cat_act(x, skip, w1, w2, pw)
+        xo, a_ref = ops.act(x, skip, w1, w2, want_xo=True)
+        y_ref = ops.conv(xo, pw)
+    assert torch.equal(a, a_ref), "mp_silu(mp_cat) differs from the activation kernel's"
+    assert torch.equal(y, y_ref), "1x1 conv of the concatenation differs from the two-launch form"
+    assert float(y.float().abs().mean()) > 0.1
+
+
 @pytest.mark.parametrize("f", [[1, 1], [1, 3, 3, 1], [1, 2, 3, 3, 2, 1], [2, 5]])
 def test_resample_general_filter(f):
     """oniris_resample_filter (Block(resample_filter=...), reference utils.py:94-107) against the oracle's conv2d /
