@@ -9,6 +9,11 @@ from .. import ops
 FUSED = int(os.environ.get("ONIRIS_FUSED_LOSS", "1"))      # 0: the eager formulation through Precond.forward
 
 
+def _core(unet):
+    """The UNet behind torch's DistributedDataParallel wrapper (attribute access only: calls keep going through the wrapper)."""
+    return unet.module if isinstance(unet, torch.nn.parallel.DistributedDataParallel) else unet
+
+
 class EDM2Loss:
     def __init__(self, P_mean=0.5, P_std=2., sigma_data=1., context_noise_reduction=0.1):
         assert 0 <= context_noise_reduction <= 1
@@ -37,8 +42,10 @@ class EDM2Loss:
             sgm = sigma.float().contiguous()
             xcl = ops.dart_input(images, noise, sgm, S, net.sigma_data)
             c_noise = sgm.log() / 4                                             # Precond.forward (networks_edm2.py:290)
+            # (net.unet may be torch's DistributedDataParallel around the UNet, cs_train.py:54: the call goes THROUGH the wrapper --
+            # its reducer and the inner engine for the kernel-owned weights see this forward --, out_gain is the module's own)
             Fcl, _ = net.unet.forward(xcl, c_noise, conditioning, None, False, just_2d, _cl_io=(B, S * T))
-            mse = ops.dart_loss(Fcl, net.unet.out_gain, images, noise, sgm, S, net.sigma_data)
+            mse = ops.dart_loss(Fcl, _core(net.unet).out_gain, images, noise, sgm, S, net.sigma_data)
             # lambda(sigma) weighting, / fitted mean loss, both means and net.noise_weight.add_data (:37-46) in one launch:
             # the (sigma, loss, position) history is appended on the device, whether or not the caller syncs
             nw = net.noise_weight
@@ -59,7 +66,7 @@ class EDM2Loss:
 
     @staticmethod
     def _fusable(net, images, noise, sigma):
-        unet = getattr(net, "unet", None)
+        unet = _core(getattr(net, "unet", None))
         return (images.is_cuda and images.dtype == torch.float32 and noise.dtype == torch.float32 and images.is_contiguous()
                 and noise.is_contiguous() and getattr(unet, "_oniris_cl_io", False) and images.shape[2] <= 8
                 and getattr(unet, "img_channels", 99) == images.shape[2] and not images.requires_grad)

@@ -16,6 +16,11 @@ from .conv import MPConv, MPCausal3DGatedConv, Gating, weights_ready, batched_ga
 from .attention import FrameAttention, VideoAttention
 
 
+def unwrap_ddp(m):
+    """The module behind torch's DistributedDataParallel (cs_train.py:54 hands the WRAPPER to Precond); anything else as it is."""
+    return m.module if isinstance(m, torch.nn.parallel.DistributedDataParallel) else m
+
+
 class Block(nn.Module):
     def __init__(self, in_channels, out_channels, emb_channels, flavor="enc", resample_mode="keep",
                  resample_filter=[1, 1], attention=False, channels_per_head=64, dropout=0, res_balance=0.3,
@@ -290,6 +295,17 @@ class UNet(BetterModule):
             cls[id(p)] = 2
         return cls
 
+    def _ddp_fused_parameters(self):
+        """Autograd-visible parameters whose gradients the fused passes of this package deliver (BetterModule.
+        _ddp_params_and_buffers_to_ignore): gates of every gated conv, emb_gain of every Block, out_gain."""
+        ps = [self.out_gain]
+        for m in self.modules():
+            if isinstance(m, MPCausal3DGatedConv):
+                ps += list(m.gating.parameters())
+            elif isinstance(m, Block):
+                ps.append(m.emb_gain)
+        return ps
+
     def _oniris_overlap_stages(self, max_stages=6, head_frac=0.06):
         """[((side, block name), [parameters])] for OnirisDDP's early gradient exchanges, in the order the stages become
         final during backward.  The kernel-owned weights (their .grad is written by weight_bwd, not by autograd) of every
@@ -448,6 +464,10 @@ class Precond(BetterModule):
         self.unet, self.use_fp16, self.sigma_data = unet, use_fp16, sigma_data
         self.noise_weight = MultiNoiseLoss()
 
+    def _ddp_fused_parameters(self):
+        core = getattr(self.unet, "module", self.unet)
+        return core._ddp_fused_parameters() if hasattr(core, "_ddp_fused_parameters") else []
+
     _fp32_warned = False
 
     @classmethod
@@ -477,8 +497,9 @@ class Precond(BetterModule):
             cache = {}
         cache["shape"] = x.shape
         x = x.to(torch.float32)
+        core = unwrap_ddp(self.unet)       # (torch's DistributedDataParallel hides the UNet's attributes; the CALL still goes through it)
         if (not torch.is_grad_enabled() and x.is_cuda and x.is_contiguous() and x.shape[2] <= 8 and sigma.shape == x.shape[:2]
-                and getattr(self.unet, "_oniris_cl_io", False) and getattr(self.unet, "img_channels", -1) == x.shape[2]):
+                and getattr(core, "_oniris_cl_io", False) and getattr(core, "img_channels", -1) == x.shape[2]):
             # eval (the sampler's 31 evaluations per frame): the sigma-preconditioning around the UNet as two HIP passes
             # instead of ~25 tiny torch launches -- c_in * x packed channels-last with the ones channel, and
             # D = c_skip * x + c_out * out_gain * F read straight from the raw channels-last output
@@ -486,7 +507,7 @@ class Precond(BetterModule):
             xcl, c_noise = ops.dart_input(x, None, sg, 1, self.sigma_data, want_c_noise=True)
             Fcl, cache = self.unet.forward(xcl, c_noise, conditioning, cache, update_cache, just_2d,
                                            _cl_io=tuple(x.shape[:2]))
-            return ops.precond_out(Fcl, x, sg, self.unet.out_gain, self.sigma_data), cache
+            return ops.precond_out(Fcl, x, sg, core.out_gain, self.sigma_data), cache
         sigma = sigma.to(torch.float32)[:, :, None, None, None]
         sd = self.sigma_data
         c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)

@@ -297,6 +297,15 @@ class BetterModule(nn.Module):
         owned = [m.weight for m in self.modules() if isinstance(m, NormalizedWeight) and m.weight.requires_grad]
         if not owned:
             raise AttributeError("_ddp_params_and_buffers_to_ignore")
+        # ... and with them every parameter whose gradient this package's fused passes deliver (the gates of the gated convs and
+        # emb_gain: gathered / delivered as packs of the flat buffers; out_gain: applied by the fused loss OUTSIDE the wrapper's
+        # forward, where torch's reducer would mark it unused and then see its gradient arrive).  torch's reducer keeps what is left
+        # -- for the UNet the four parameters of `out_res`, which the reference evaluates and never uses (networks_edm2.py:197) --
+        # and it must keep at least one parameter: otherwise only the kernel-owned weights are taken.
+        takers = self._ddp_fused_parameters() if hasattr(self, "_ddp_fused_parameters") else []
+        rest = {id(p) for p in owned} | {id(p) for p in takers}
+        if any(p.requires_grad and id(p) not in rest for p in self.parameters()):
+            owned = owned + [p for p in takers if p.requires_grad]
         outer = frame.f_locals.get("self")
         inner = self.__dict__.get("_oniris_inner_ddp")
         if inner is None or isinstance(inner, str) or inner._torch_ddp is None or inner._torch_ddp() is not outer:
@@ -309,7 +318,10 @@ class BetterModule(nn.Module):
                 raise RuntimeError(f"building the gradient exchange for torch DDP failed: {e!r}") from e   # such attribute")
             self.__dict__["_oniris_inner_ddp"] = inner
         ids = {id(p) for p in inner.flat.params}
-        return [n for n, p in self.named_parameters() if id(p) in ids]
+        names = [n for n, p in self.named_parameters() if id(p) in ids]
+        # (torch's reducer tests f"{module_name}.{param_name}" against this list, which for a parameter of the ROOT module is
+        # ".name", while its broadcast and its parameter filter test the plain "name": a root-level parameter goes in twice)
+        return names + ["." + n for n in names if "." not in n]
 
     def _ddp_inner(self):
         """The inner OnirisDDP when torch's DistributedDataParallel wraps this module (None otherwise).  A COPY of a wrapped

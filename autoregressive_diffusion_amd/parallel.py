@@ -200,6 +200,17 @@ class FlatParams:
         self.grad.zero_()
         self._got.clear()                  # (direct packs that deliver a gradient in this cycle: ParamPack.deliver)
         self._foreign = True
+        # The kernel-owned weights get their flat slices back as .grad RIGHT AWAY: weight_bwd then writes into the buffer that is
+        # exchanged (no 185 MB of fresh zero tensors per cycle, no copy into the slices afterwards) and the WeightBank's descriptor
+        # table keeps its pointers (no rebuild + upload per step).  Which of them really received a gradient is known at the end of
+        # the cycle (PackedWeight.touched, host side): adopt() hands the others back as None, so that the foreign optimizer skips
+        # them as it does in the reference.
+        for p, o in zip(self.params, self.offsets):
+            m = self._owner.get(id(p))
+            if m is not None and p.grad is None:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+                if m.pw is not None:
+                    m.pw.touched = False
 
     def adopt(self, lo=None, hi=None):
         """Foreign cycle only: the gradients that live outside the flat buffer move into their slices of [lo, hi) (everything by
@@ -223,6 +234,10 @@ class FlatParams:
             if g.data_ptr() != base + 4 * o:
                 src.append(g); dst.append(view)
                 p.grad = view
+            elif lo is None and hi is None:
+                m = self._owner.get(id(p))         # (final adopt of a backward: a kernel-owned weight no wgrad launch targeted in
+                if m is not None and m.pw is not None and not m.pw.touched:       # this cycle has no gradient)
+                    p.grad = None
         if src:
             with torch.no_grad():
                 torch._foreach_copy_(dst, src)

@@ -278,15 +278,36 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
         if hasattr(m, "emb_gain"):
             torch.nn.init.constant_(m.emb_gain, 0.3)
     torch.nn.init.constant_(unet.out_gain, 1.0)
-    flat = FlatParams(unet, lazy_small=True)
-    # exchange form / transport: ONIRIS_DDP_EXCHANGE=allreduce|mesh, ONIRIS_DDP_BF16=1 (parallel.OnirisDDP; default: fp32 all-reduce per stage)
-    wd.beat("OnirisDDP construction (parameter / buffer broadcast)")
-    model = OnirisDDP(unet, flat=flat, force_collectives=force_dist, auto_wait=False) if multi else unet      # (wait() is placed and timed below)
-    net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
-    opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
-    # optimizer side as in the reference loops: clip_grad_norm_(0.1) (gym_train.py:105 only) + AdamW +
-    # PowerFunctionEMA(stds 0.05 / 0.10).update (gym_train.py:108, cs_train.py:121) -- one fused pass
-    ema = FlatEMA(flat, stds=(0.050, 0.100))
+    torch_loop = getattr(args, "wrapper", "oniris") == "torch" and not light
+    if torch_loop:
+        # --wrapper torch: the reference's loop AS WRITTEN (cs_train.py:53-54,76-78,105-121; gym_train.py:105-108): torch's own
+        # DistributedDataParallel around the UNet (multi-rank / ONIRIS_FORCE_DIST runs), torch.optim.AdamW over precond.parameters(),
+        # clip_grad_norm_, two deep-copied EMA trackers updated parameter by parameter (phema.py:104-108), the loss with its host
+        # round trip.  An extra measurement of the drop-in path, NOT the headline (which uses OnirisDDP + the fused optimizer).
+        import copy
+        from torch.nn.parallel import DistributedDataParallel as TorchDDP
+        from autoregressive_diffusion_amd.parallel import power_function_beta
+        flat = None
+        wd.beat("torch DistributedDataParallel construction")
+        model = (TorchDDP(unet, device_ids=[dev.index], output_device=dev.index, find_unused_parameters=True) if multi else unet)
+        if multi and force_dist and world == 1:
+            unet.__dict__["_oniris_inner_ddp"].force_collectives = True
+        net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
+        opt = torch.optim.AdamW(net.parameters(), lr=1e-2, eps=1e-8)
+        opt.zero_grad()
+        ema_stds = (0.050, 0.100)
+        ema_copies = [copy.deepcopy(net) for _ in ema_stds]
+        ema = None
+    else:
+        flat = FlatParams(unet, lazy_small=True)
+        # exchange form / transport: ONIRIS_DDP_EXCHANGE=allreduce|mesh, ONIRIS_DDP_BF16=1 (parallel.OnirisDDP; default: fp32 all-reduce per stage)
+        wd.beat("OnirisDDP construction (parameter / buffer broadcast)")
+        model = OnirisDDP(unet, flat=flat, force_collectives=force_dist, auto_wait=False) if multi else unet      # (wait() is placed and timed below)
+        net = Precond(model, use_fp16=True, sigma_data=1.0).to(dev).train()
+        opt = FlatAdamW(flat, lr=1e-2, eps=1e-8)
+        # optimizer side as in the reference loops: clip_grad_norm_(0.1) (gym_train.py:105 only) + AdamW +
+        # PowerFunctionEMA(stds 0.05 / 0.10).update (gym_train.py:108, cs_train.py:121) -- one fused pass
+        ema = FlatEMA(flat, stds=(0.050, 0.100))
     max_norm = None if cs else 0.1
     nimg = [0]
     loss_fn = (EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1) if cs else   # cs_train.py:75
@@ -333,10 +354,28 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
         else:
             model.wait()
 
+    def torch_step(just_2d):
+        """One micro-step of the reference loops with accumulation_steps = 1, line by line."""
+        loss, _unweighted = loss_fn(net, latents, actions, just_2d=just_2d)      # (sync: the reference's .cpu().item(), loss.py:41)
+        loss.backward()
+        if max_norm is not None:
+            torch.nn.utils.clip_grad_norm_(net.parameters(), max_norm)           # gym_train.py:105
+        opt.step()
+        opt.zero_grad()
+        nimg[0] += world * B
+        with torch.no_grad():                                                    # phema.py:104-108
+            for std, cp in zip(ema_stds, ema_copies):
+                beta = power_function_beta(std, nimg[0], world * B)
+                for p_net, p_ema in zip(net.parameters(), cp.parameters()):
+                    p_ema.lerp_(p_net, 1 - beta)
+        return loss
+
     def step(i):
         just_2d = (i % 4 == 0)                                   # gym_train.py:96
         if _only:                                                # profiling aid: ONIRIS_ONLY_MODE=2d|3d (not the metric)
             just_2d = _only == "2d"
+        if torch_loop:
+            return torch_step(just_2d)
         if accum > 1:
             return accum_step(just_2d)
         loss = fwd_bwd(just_2d)
@@ -535,7 +574,10 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "rccl_world": rccl_world, "devices": sorted(set(devices)), "device_of_rank": devices,
             "backend": (dist.get_backend() if multi else None),
-            "ddp": ({"exchange": model.exchange, "grad_dtype": str(model.grad_dtype or "fp32"), "stages": len(flat.stages),
+            "ddp": ({"wrapper": "torch.nn.parallel.DistributedDataParallel + inner OnirisDDP for the kernel-owned weights",
+                     "kernel_owned_parameters": len(unet.__dict__["_oniris_inner_ddp"].flat.params),
+                     "stages": len(unet.__dict__["_oniris_inner_ddp"].flat.stages)} if (multi and torch_loop) else
+                    {"exchange": model.exchange, "grad_dtype": str(model.grad_dtype or "fp32"), "stages": len(flat.stages),
                      "stage_mb": [round((hi - lo) * 4 / 2 ** 20, 1) for _, lo, hi in flat.stages],
                      "head_mb": round((flat.head[1] - flat.head[0]) * 4 / 2 ** 20, 1),
                      "exposed_comm_ms_per_step": exposed,
@@ -552,6 +594,8 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
                                    f"3:1 mix of 3-D/2-D steps", "global_batch": world * B, "seq_len": T,
                        "parallelism": f"dp{world}", "hip_graph": False,
                        **({"accum_NOT_THE_HEADLINE": accum, "lr": opt.param_groups[0]["lr"]} if accum > 1 else {}),
+                       **({"wrapper_NOT_THE_HEADLINE": "torch: the reference loop as written (torch DDP when multi-rank, torch.optim.AdamW, "
+                                                       "clip_grad_norm_, deep-copied EMA trackers, synced loss)"} if torch_loop else {}),
                        **({"shared_gpu_gloo_NOT_A_MEASUREMENT": True} if share else {}),
                        **({"only_mode_NOT_THE_METRIC": _only} if _only else {}),
                        **{k: round(v, 2) for k, v in per_mode.items()}},
@@ -587,6 +631,11 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--watchdog", type=float, default=300.0,
                     help="multi-rank runs: seconds without progress after which a rank exits 124 naming its stage (0 = off)")
+    ap.add_argument("--wrapper", choices=["oniris", "torch"], default="oniris",
+                    help="oniris = OnirisDDP + the fused optimizer / EMA pass (the headline); torch = the reference's loop as written: "
+                         "torch DistributedDataParallel around the UNet (when there is a process group), torch.optim.AdamW, "
+                         "clip_grad_norm_, two deep-copied EMA trackers, the loss with its host round trip -- an extra measurement of "
+                         "the drop-in path (cs_train.py / gym_train.py with no changed line)")
     ap.add_argument("--accum", type=int, default=1,
                     help="gradient accumulation as in the reference loops (gym_train.py:96-112, cs_train.py:105-127): the optimizer "
                          "(+ clip, EMA, learning-rate schedule) runs every K-th micro-step, the K-1 others run their backward "

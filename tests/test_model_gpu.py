@@ -1005,7 +1005,9 @@ def _ddp_torch_optimizer_worker(q):
                 precond.unet = unet = TorchDDP(unet, device_ids=[0], output_device=0, find_unused_parameters=True)
                 inner = unet.module.__dict__["_oniris_inner_ddp"]
                 inner.force_collectives = True             # (a one-rank group: issue the collectives anyway)
-                assert len(unet.parameters_to_ignore) == len(inner.flat.params) > 50
+                # (+ 1: torch's second spelling of the root-level out_gain, see BetterModule._ddp_params_and_buffers_to_ignore)
+                assert len({n.lstrip(".") for n in unet.parameters_to_ignore}) == len(inner.flat.params) > 50
+                assert not ({id(p) for p in unet._build_params_for_reducer()[0]} & {id(p) for p in inner.flat.params})
             optimizer = torch.optim.AdamW(precond.parameters(), lr=1e-2, eps=1e-4)
             optimizer.zero_grad()
             loss_fn = EDM2Loss(P_mean=0.9, P_std=1.0, sigma_data=1.0, context_noise_reduction=0.1)
