@@ -319,6 +319,12 @@ class BetterModule(nn.Module):
             self.__dict__["_oniris_inner_ddp"] = inner
         ids = {id(p) for p in inner.flat.params}
         names = [n for n, p in self.named_parameters() if id(p) in ids]
+        # The buffers of these nets are constants (MPFourier's frequencies / phases, the rotary embedding's inv_freq / scale):
+        # the inner engine broadcast rank 0's once at construction, as OnirisDDP does.  torch DDP would broadcast them again
+        # in EVERY forward (broadcast_buffers=True is its default and what cs_train.py:54 gets) -- an in-place rewrite that
+        # bumps their version counters, on which the rotary tables are cached (ops.rope_tables): 8 table rebuilds with host
+        # round trips per step, ~20 ms of the 84 ms step measured under the wrapper (profiles/r05_torchloop.txt).
+        names += [n for n, b in self.named_buffers() if b is not None]
         # (torch's reducer tests f"{module_name}.{param_name}" against this list, which for a parameter of the ROOT module is
         # ".name", while its broadcast and its parameter filter test the plain "name": a root-level parameter goes in twice)
         return names + ["." + n for n in names if "." not in n]

@@ -155,7 +155,8 @@ def attn_schedule(weights, n_pairs, device, n_wg=None):
 class PackedWeight:
     """Handle of one weight inside a WeightBank (what the conv wrappers consume)."""
     __slots__ = ("param", "cout", "cin", "taps", "kt", "CoutP", "CinP", "CoutPb", "CinPb", "perm3", "gain",
-                 "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched", "embcache", "gaincache")
+                 "wf", "wb", "dwp", "dws", "bank", "nsplit_cap", "nsplit", "group", "goff", "members", "touched", "embcache", "gaincache",
+                 "gview", "fresh", "hit")
 
 
 def _nsplit_cap(cin, cout, taps, gated_pair=False):
@@ -240,6 +241,8 @@ class WeightBank:
         w.wf = w.wb = w.dwp = w.dws = w.nsplit = None
         w.group, w.goff, w.members = None, 0, None
         w.touched = False              # a weight-gradient launch targeted this weight since the last optimizer step
+        w.hit = False                  # ... in the running backward pass
+        w.gview, w.fresh = None, False # released gradients: see WeightBank._reassign
         # split-K slabs of the weight-gradient kernel: same bound as launch_wgrad() in csrc/conv_wgrad.hip
         w.nsplit_cap = _nsplit_cap(w.cin, w.cout, w.taps, gated_pair)
         w.bank = self
@@ -266,7 +269,7 @@ class WeightBank:
         g.CinP, g.CoutPb = roundup(g.cin, 64), roundup(g.cin, 32)
         g.perm3, g.gain, g.param, g.bank = False, 1.0, members[0].param, self
         g.wf = g.wb = g.dwp = g.dws = g.nsplit = None
-        g.touched = False
+        g.touched = g.hit = False
         g.nsplit_cap = _nsplit_cap(g.cin, g.cout, 1)
         self.groups.append(g)
         self._dev_table = None
@@ -311,8 +314,6 @@ class WeightBank:
                 # once; ~2 GB per step in fp32 for the gym net, written by the wgrad kernels and read back by weight_bwd)
                 w.dwp = torch.empty(w.nsplit_cap * w.taps * w.CoutP * w.CinP, dtype=BF16, device=device)
                 w.dws = torch.empty(w.taps * w.CoutP * w.CinP, dtype=torch.float32, device=device)
-            if p.requires_grad and p.grad is None:
-                p.grad = torch.zeros_like(p)
             d = descs[i]
             d.w = p.data_ptr()
             d.grad = p.grad.data_ptr() if p.grad is not None else None
@@ -334,24 +335,69 @@ class WeightBank:
         self._dev_table = torch.from_numpy(raw).to(device)
         self._sig = self._signature()
 
-    def _ensure(self):
+    def _reassign(self, released):
+        """Gradients somebody released (`torch.optim.AdamW(...).zero_grad()` -- set_to_none=True is torch's default and what the
+        reference's loops call, gym_train.py:72,108) get a zeroed tensor again, as autograd would create one for a parameter of
+        its own.  They come out of ONE pooled buffer with a fixed slice per weight: a step of the reference loop then costs one
+        fill instead of 184 allocations + fills, and the slices keep their addresses, so the descriptor table on the device
+        stays valid (no rebuild + upload per step).  Handing a slice out again is only sound while nobody else still looks at
+        it -- a loop that kept `g = p.grad` across zero_grad() expects `g` to stay what it was: the pool is used while its
+        storage has no holder but the bank (checked: storage use count + reference counts of the slices), fresh tensors otherwise.
+        A weight whose gradient was created here and that no weight-gradient launch targets in the backward pass that follows
+        gets None back at the end of that pass (`_finish`): the reference leaves such parameters without a gradient (emb_time,
+        networks_edm2.py:205-207) and torch.optim skips them."""
+        trainable = [w for w, _ in self.items if w.param.requires_grad]
+        dev = self.items[0][0].param.device
+        pool = getattr(self, "_gpool", None)
+        if pool is None or pool.device != dev or self._gpool_n != len(trainable):
+            total = sum(w.param.numel() for w in trainable)
+            pool = self._gpool = torch.zeros(total, dtype=torch.float32, device=dev)
+            o = 0
+            for w in trainable:
+                n = w.param.numel()
+                w.gview = pool[o:o + n].view_as(w.param)
+                o += n
+            self._gpool_n = len(trainable)
+            self._gpool_uses = None
+        uses = torch._C._storage_Use_Count(pool.untyped_storage()._cdata)
+        if self._gpool_uses is None:
+            self._gpool_uses = uses
+        pooled = uses == self._gpool_uses and all(_sys.getrefcount(w.gview) == 2 for w in released)   # (2: the slot + the argument)
+        if pooled:
+            if len(released) == len(trainable):
+                pool.zero_()
+            else:
+                torch._foreach_zero_([w.gview for w in released])
+        for w in released:
+            w.param.grad = w.gview if pooled else torch.zeros_like(w.param)
+            w.fresh = True
+
+    def _ensure(self, assign=True):
+        """assign=False (an evaluation under no_grad): released gradients stay released."""
         p0 = self.items[0][0].param
         _need_gpu(p0)
-        sig, ok = [], self._dev_table is not None
+        sig, ok, released = [], self._dev_table is not None, None
         for w, _ in self.items:                        # ONE pass (this runs at the start of every step, on the critical
             p = w.param                                # path of the host: ~150 us for the 184 weights of the gym net)
             g = p.grad
             if g is None:
-                ok = ok and not p.requires_grad
-                sig.append((p.data_ptr(), 0))
-            else:
-                sig.append((p.data_ptr(), g.data_ptr()))
+                if p.requires_grad and assign:
+                    if released is None:
+                        released = []
+                    released.append(w)
+                else:
+                    sig.append((p.data_ptr(), 0))
+                    continue
+            sig.append((p.data_ptr(), g.data_ptr() if g is not None else -1))
+        if released is not None:
+            self._reassign(released)
+            sig = self._signature()
         if not ok or self._sig != tuple(sig):
             self._build(p0.device)
 
     def prepare(self, training):
         """Forced weight normalisation (training: written back to the parameters) + bf16 packing; one launch."""
-        self._ensure()
+        self._ensure(assign=torch.is_grad_enabled())
         if training or torch.is_grad_enabled():        # (a no_grad evaluation -- the rollout -- never takes from the arena)
             self.zero_arena.reset(self.items[0][0].param.device)   # the previous step's backward is done with its accumulators
             self._flags = None                         # (clip flags: a fresh tensor per forward, see take_flag)
@@ -408,6 +454,12 @@ class WeightBank:
             return
         self._finish_queued = False
         self.backward()
+        for w, _ in self.items:            # (gradients the bank created for this pass and nothing was added to: _reassign)
+            if w.fresh:
+                if not w.hit:
+                    w.param.grad = None
+                w.fresh = False
+            w.hit = False
         for h in self.post_backward_hooks:
             h()
         GradSlot.check_all_taken()
@@ -417,6 +469,7 @@ class WeightBank:
 # convolution
 
 import os as _os
+import sys as _sys
 FUSED_ROPE = int(_os.environ.get("ONIRIS_FUSED_ROPE", "1"))        # 0: qkv normalisation and the two rotations as three launches (A/B, tests)
 ATTN_DKV_CHUNKS = int(_os.environ.get("ONIRIS_DKV_CHUNKS", "4"))   # dK/dV query-list chunks (OnirisAttnArgs.dkv_chunks)
 ATTN_DKV_MIN_L = 2048                                              # ... one chunk per this many tokens at most
@@ -596,10 +649,10 @@ def _splitk_workspace(device):
 def _wgrad_args(x, dy, pw, scale, B, T, H, W, Cin, CinP, Cout, CoutP, taps, xb_stride, x_T, coff, fill, tap0=0):
     """pw: PackedWeight whose slabs receive the partial sums (taps [tap0, tap0+taps) of its pw.taps-deep slabs)."""
     a = _lib.WgradArgs()
-    pw.touched = True
+    pw.touched = pw.hit = True
     if pw.members is not None:
         for m_ in pw.members:
-            m_.touched = True
+            m_.touched = m_.hit = True
     a.x, a.dy, a.dwp, a.scale = _p(x), _p(dy), _p(pw.dwp), _p(scale)
     a.nsplit_cap, a.taps_total, a.tap0, a.nsplit_out = pw.nsplit_cap, pw.taps, tap0, _p(pw.nsplit)
     a.B, a.T, a.H, a.W, a.Cin, a.CinP, a.Cout, a.CoutP, a.taps = B, T, H, W, Cin, CinP, Cout, CoutP, taps

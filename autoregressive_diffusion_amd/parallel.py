@@ -378,8 +378,7 @@ class OnirisDDP(nn.Module):
         # keep different noise / time embeddings under shared weights)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1:
             dist.broadcast(self.flat.flat, src=0, group=self.process_group)
-            if torch_ddp is None:                        # (inner mode: torch DDP broadcasts the buffers and its own parameters)
-                self._broadcast_buffers()
+            self._broadcast_buffers()                    # (inner mode too: the buffers are named in torch DDP's ignore list)
         if self.exchange == "mesh" and self._active():
             world, rank = dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
             segs = [self.flat.head] + [(lo, hi) for _, lo, hi in self.flat.stages]

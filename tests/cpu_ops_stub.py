@@ -27,10 +27,10 @@ class _Owned(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         for pw in ctx.pws:
-            pw.touched = True
+            pw.touched = pw.hit = True
             if pw.members is not None:
                 for m in pw.members:
-                    m.touched = True
+                    m.touched = m.hit = True
         ctx.pws[0].bank.request_finish()
         return g, None
 

@@ -849,6 +849,59 @@ def test_zero_grad_set_to_none_between_forward_and_backward():
     assert rel(got[k], want[k]) < 2e-2 and rel(got["unet.dec.8x8_in0.conv_res1.weight.weight"], want["unet.dec.8x8_in0.conv_res1.weight.weight"]) < 2e-2
 
 
+def test_released_gradients_come_back_from_one_pool():
+    """The reference loop as written (gym_train.py:72,104-108: torch.optim.AdamW, zero_grad() with torch's set_to_none=True, no
+    wrapper): the gradients of the kernel-owned weights come back from one pooled buffer -- same addresses every cycle, the
+    descriptor table on the device is not rebuilt -- as long as nobody kept a released gradient; a kept one is left alone.
+    Weights nothing reaches (emb_time, networks_edm2.py:205-207) end a backward with .grad = None like in the reference,
+    and an evaluation under no_grad creates no gradients."""
+    from edm2.loss import EDM2Loss
+    g = torch.Generator().manual_seed(83)
+    images = torch.randn(1, 4, 4, 32, 32, generator=g).to(DEV)
+    labels = torch.randint(0, 4, (1, 4), generator=g).to(DEV)
+    net = build_precond(SMALL_CFG, 61, 1.0).train()
+    topt = torch.optim.AdamW(net.parameters(), lr=1e-3)
+    loss_fn = EDM2Loss(sigma_data=1.0)
+    own = net.unet.enc["32x32_conv"].last_frame_conv.weight
+    emb_time = net.unet.emb_time.weight.weight
+
+    def cycle(seed=0):
+        topt.zero_grad()
+        torch.manual_seed(seed)
+        loss, _ = loss_fn(net, images, labels)
+        loss.backward()
+    cycle()
+    bank = own.pw.bank
+    table, ptr = bank._dev_table.data_ptr(), own.weight.grad.data_ptr()
+    first = own.weight.grad.clone()
+    assert emb_time.grad is None and float(first.abs().max()) > 0
+    cycle()
+    assert bank._dev_table.data_ptr() == table and own.weight.grad.data_ptr() == ptr and emb_time.grad is None
+    assert rel(own.weight.grad, first) < 0.15           # (zeroed in between: not the sum of two cycles)
+    # accumulation without zero_grad in between: gradients add up, emb_time stays without one
+    torch.manual_seed(0)
+    loss, _ = loss_fn(net, images, labels)
+    loss.backward()
+    assert rel(own.weight.grad, 2 * first) < 0.15 and emb_time.grad is None and own.weight.grad.data_ptr() == ptr
+    # somebody keeps a gradient across zero_grad(): it must stay what it was
+    kept = own.weight.grad
+    snapshot = kept.clone()
+    cycle()
+    assert own.weight.grad is not kept and own.weight.grad.data_ptr() != ptr and torch.equal(kept, snapshot)
+    assert rel(own.weight.grad, first) < 0.15
+    del kept
+    cycle()                                              # ... and once it is gone the pool serves again
+    assert own.weight.grad.data_ptr() == ptr and rel(own.weight.grad, first) < 0.15
+    # an evaluation (no_grad) after zero_grad() leaves the gradients released
+    topt.zero_grad()
+    with torch.no_grad():
+        net.eval()(images[:, :2], torch.ones(1, 2, device=DEV), labels[:, :2])
+    assert all(p.grad is None for p in net.parameters())
+    net.train()
+    cycle()
+    assert own.weight.grad.data_ptr() == ptr and rel(own.weight.grad, first) < 0.15
+
+
 def test_kept_context_product_follows_cache_and_weights():
     """The context product a gated conv keeps beside its cached pair (OnirisConvArgs.ctx_prod, conv.py `_cl`) must be used while
     pair AND weights are the ones it was computed from, and only then: repeated one-frame evaluations against one cache are
@@ -1006,7 +1059,10 @@ def _ddp_torch_optimizer_worker(q):
                 inner = unet.module.__dict__["_oniris_inner_ddp"]
                 inner.force_collectives = True             # (a one-rank group: issue the collectives anyway)
                 # (+ 1: torch's second spelling of the root-level out_gain, see BetterModule._ddp_params_and_buffers_to_ignore)
-                assert len({n.lstrip(".") for n in unet.parameters_to_ignore}) == len(inner.flat.params) > 50
+                pnames = {n for n, _ in unet.module.named_parameters()}
+                assert len({n.lstrip(".") for n in unet.parameters_to_ignore} & pnames) == len(inner.flat.params) > 50
+                # (the constant buffers too: broadcast once by the inner engine, not rewritten in every forward)
+                assert all(n in unet.parameters_to_ignore for n, _ in unet.module.named_buffers()) and not unet.modules_buffers
                 assert not ({id(p) for p in unet._build_params_for_reducer()[0]} & {id(p) for p in inner.flat.params})
             optimizer = torch.optim.AdamW(precond.parameters(), lr=1e-2, eps=1e-4)
             optimizer.zero_grad()
@@ -1048,6 +1104,7 @@ def test_ddp_with_torch_optimizer_on_the_unet():
         (pp, pn), (dp, dn) = res[1][base], res[1][wrapped]
         pp, dp = ({k: torch.from_numpy(v) for k, v in d.items()} for d in (pp, dp))
         assert pn == dn, (pn, dn)
+        assert all("unet.emb_time.weight.weight" in ns and "unet.out_res.mult" in ns for ns in pn)     # (as in the reference)
         worst = max(rel(dp[k], pp[k]) for k in pp if pp[k].numel() > 64)
         moved = max(rel(pp[k], build_precond(SMALL_CFG, 67, 1.0).state_dict()[k].float().cpu()) for k in list(pp)[:40] if pp[k].numel() > 64)
         print(what, "+ torch.optim.AdamW vs the un-wrapped loop: worst parameter rel L2", worst, "(the loop moved them by", moved, ")")
