@@ -564,6 +564,7 @@ def _s2ctx_family(T, H, W, Cin, CinP, CoutP, ctx_T, coff, ctx_fill):
     return "staged"
 
 
+PROFILE_SHAPES = int(_os.environ.get("ONIRIS_PROFILE_SHAPES", "0"))   # KernelProfile keys of the conv launches carry their shape (scratch/r05_conv_shapes.py)
 ALIAS2 = int(_os.environ.get("ONIRIS_ALIAS2", "1"))          # 0: round-4 extent of the aliasing protocol only (A/B: no residual alias, no plain-conv alias)
 CLIP_FLAG = int(_os.environ.get("ONIRIS_CLIP_FLAG", "1"))    # 0: the mp_sum backward always reads the clipped output and writes a masked gradient copy (A/B, tests)
 
@@ -595,6 +596,8 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
             key = "conv1x1_glds_kernel"
         else:
             key = f"conv_fwd_kernel<S={S},TAPS={taps},CK={32 if taps == 9 else 64},NT={nt},CTX={int(ctx is not None)},PW={_patch_w(W)}>"
+        if PROFILE_SHAPES:
+            key += f" [{H}x{W} {Cin}->{Cout} epi={epi}{' res' if res is not None else ''}{' out2' if out2 is not None else ''}{' y3' if ctx_out is not None else ''}{' dgrad' if coff[0] > 0 else ''}]"
         KernelProfile.enabled = False
         try:
             e0, e1 = _timed_launch(lambda: _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, Cin, CinP,

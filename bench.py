@@ -497,6 +497,11 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
                            bound=("hbm" if v["bytes"] / HBM_ACHIEVABLE > v["flops"] / MFMA_BF16_PEAK else "mfma"),
                            gbytes_s=(round(v["bytes"] / (v["ms"] * 1e-3) / 1e9) if v["bytes"] else None))
                    for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])[:16]}
+        if os.environ.get("ONIRIS_PROFILE_SHAPES"):      # per launch shape (keys carry it: ops.PROFILE_SHAPES), the three 3-D steps
+            print("3-D steps of the profiled cycle, per conv launch shape: launches, ms, roof (= sum of t_min / time), algorithmic TB/s, TFLOP/s", file=sys.stderr)
+            for k, v in sorted(agg3.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"  {k:100s} {v['launches']:4d} {v['ms']:8.3f} ms  roof {v['t_min'] / (v['ms'] * 1e-3):5.3f}  "
+                      f"{v['bytes'] / (v['ms'] * 1e-3) / 1e12:5.2f} TB/s {v['flops'] / (v['ms'] * 1e-3) / 1e12:7.1f} TF", file=sys.stderr)
         attn = {k: v for k, v in agg.items() if k.startswith("attn_fwd") and "MODE=2" in k}      # VideoAttention forward
         dom, v = max(((k, v) for k, v in agg.items() if not k.startswith("attn_")), key=lambda kv: kv[1]["ms"])
         achieved = v["flops"] / (v["ms"] * 1e-3)
