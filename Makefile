@@ -42,6 +42,8 @@ clean:
 
 # experiment builds of the gated-conv translation unit with other -D settings (VNAME / VDEF), e.g.
 #   make variant VNAME=m816 VDEF="-DGLDS_MID_OWN=8 -DGLDS_MID_CTX=16"   -> autoregressive_diffusion_amd/liboniris_hip_m816.so
+#   make variant VSRC=conv_wgrad VNAME=wro0 VDEF="-DWGRAD_ROWORDER=0"     (another translation unit: VSRC, default conv_fwd_s2ctx)
+VSRC ?= conv_fwd_s2ctx
 variant: $(OBJS)
-	$(HIPCC) $(HIPFLAGS) $(VDEF) -c $(CSRC)/conv_fwd_s2ctx.hip -o build/conv_fwd_s2ctx_$(VNAME).o
-	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o autoregressive_diffusion_amd/liboniris_hip_$(VNAME).so build/conv_fwd_s2ctx_$(VNAME).o $(filter-out build/conv_fwd_s2ctx.hip.o,$(OBJS))
+	$(HIPCC) $(HIPFLAGS) $(VDEF) -c $(CSRC)/$(VSRC).hip -o build/$(VSRC)_$(VNAME).o
+	$(HIPCC) --offload-arch=gfx950 -shared -fPIC -o autoregressive_diffusion_amd/liboniris_hip_$(VNAME).so build/$(VSRC)_$(VNAME).o $(filter-out build/$(VSRC).hip.o,$(OBJS))

@@ -275,7 +275,16 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
   }
   // ~1-2 workgroups per CU in total; the split-K columns are dealt to the groups in proportion to their position
   // tiles (every column owns one slab of ITS group's weight)
-  const int gx_all = ((CT * IT == 4) ? 256 : 512) / gy > ng ? ((CT * IT == 4) ? 256 : 512) / gy : ng;
+#ifndef WGRAD_NG
+// K-groups of 4 waves per workgroup of the LDS-DMA kernel.  1 (round 5): two independent 4-wave workgroups per CU instead of one workgroup of
+// two K-groups -- the same waves, registers and LDS per CU, but no common barrier: the groups drift apart, and one's copy issue, waits and
+// fragment prologue run under the other's MFMAs (a K-group pair in lockstep had both of a SIMD's waves in the same part of the tile loop at
+// any time).  Same-box A/B at B = 8: <2,2,*,16> 25.4 -> 22.4 ms per cycle (roof 0.41 -> 0.47), <2,2,*,8> 9.3 -> 8.5 ms, bench +1.3 %
+// (profiles/r05_ab_wgrad_groups.txt); costs twice the split-K slabs of the 64x64-channel form (ops._nsplit_cap).
+#define WGRAD_NG 1
+#endif
+  const int gx_budget = (CT * IT == 4) ? ((use_glds && WGRAD_NG == 1) ? 512 : 256) : 512;
+  const int gx_all = gx_budget / gy > ng ? gx_budget / gy : ng;
   int gx_tot = 0;
   for (int g = 0; g < ng; ++g) {
     int gx = (int)((long long)gx_all * d.ntiles[g] / (tot > 0 ? tot : 1));
@@ -288,7 +297,10 @@ static int launch_wgrad(const OnirisWgradArgs* args, int ng, hipStream_t stream)
   for (int g = ng; g <= WGRAD_MAXG; ++g) d.gstart[g] = gx_tot;      // empty groups
   if constexpr (TAPS == 9 && (PW == 16 || PW == 8)) {
     if (use_glds) {
-      constexpr int NG = 2;
+#ifndef WGRAD_NG1
+#define WGRAD_NG1 1                          // ... of the 32x32-channel tile form (+0.15 %)
+#endif
+      constexpr int NG = (CT * IT == 4) ? WGRAD_NG : WGRAD_NG1;
       auto kern = conv_wgrad_glds_kernel<CT, IT, NG, PW>;
       oniris_launch(kern, dim3(gx_tot, gy), dim3(256 * NG), stream, d);
       ONIRIS_LAUNCH_CHECK();

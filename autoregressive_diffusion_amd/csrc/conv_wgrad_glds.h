@@ -9,18 +9,23 @@
 //     tile origin / frame / fill choice is the uniform soffset / resource;
 //   * the 16-byte pieces of a row are XOR-swizzled (piece ^ 4*bit1(row)) on the SOURCE side, which makes the four
 //     rows a transposing read touches land on disjoint banks without padding;
-//   * a workgroup has NG = 2 K-groups of 4 waves (two waves per SIMD: 144 AGPR + < 110 VGPR), each with its own two
-//     LDS buffers (2 x 2 x 38.5 KB), one barrier per tile; the groups' partial sums meet in LDS at the end, so the
-//     slab count stays one per workgroup;
+//   * a workgroup has NG K-groups of 4 waves (two waves per SIMD: 144 accumulator + < 100 other registers), each with its
+//     own two LDS buffers (2 x 38.5 KB per group), one barrier per tile; NG = 2: the groups' partial sums meet in LDS at the
+//     end and the slab count stays one per workgroup; NG = 1 (what ships since round 5, WGRAD_NG in conv_wgrad.hip): two
+//     independent workgroups per CU that do not share a barrier -- see profiles/r05_ab_wgrad_groups.txt;
 //   * the per-frame dy coefficient is applied to the A fragment in registers (same bf16 rounding as before).
 #pragma once
 #include "lds_dma.h"
 
 // PW = 16: 8 x 16 pixel tiles of one frame (128 positions); PW = 8: one whole 8x8 frame (64 positions: four buffers of
 // a 128-position tile of two frames would need 166 KB of LDS)
+#ifndef WGRAD_ROWORDER
+#define WGRAD_ROWORDER 1                     // 0: every (k-step, tap) reads its own x fragment (the round-2..4 loop; A/B: make variant)
+#endif
 template <int CT, int IT, int NG, int PW = 16>
-__global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const WgradDev d) {
+__global__ __launch_bounds__(256 * NG, 2) void conv_wgrad_glds_kernel(const WgradDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool ROWORDER = WGRAD_ROWORDER != 0;
   constexpr int NPOS = (PW == 16) ? 128 : 64, NKT = NPOS / 16;         // positions and 16-position k-steps per tile
   using P = Patch<PW, NPOS>;
   constexpr int FT = P::FT, HHW = P::HH * P::HW;
@@ -214,6 +219,49 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
         const int rimm = (PW == 16) ? (ksc + ky) * P::HW : 100 * (ksc >> 2) + 20 * (ksc & 3) + 10 * ky;
         bfm[fb] = trf(buf + xa[kx][par] + rimm * XROWB, XROWB);
       };
+      if constexpr (NKS == 1 && ROWORDER) {
+        // HALO-ROW ORDER (a wave that owns every k-step of its 32x32 tile).  The x fragment of (k-step ks, tap (ky, kx)) depends on
+        // u = ks + ky (PW 16: halo row u) resp. u = 2 ks + ky (PW 8: halo rows u, u + 1) and kx only: walking (u, kx) instead of
+        // (ks, tap) reads each of the 30 (27) distinct fragments ONCE and feeds it to up to three MFMAs -- 76 (70) transposing LDS
+        // reads per tile and wave instead of 160 (88), in a loop whose two waves per SIMD issue 2.2 LDS reads per MFMA against
+        // ~1 the LDS pipe can serve.  Per tap the k-steps are still added in ascending order: the partial sums are bit-identical.
+        constexpr int NU = (PW == 16) ? NK + 2 : 2 * NK + 1, NB = NU * 3, AW = (PW == 16) ? 4 : 2;
+        bf16x8 aw[AW];
+        auto ld_aw = [&](int ks) __attribute__((always_inline)) { ld_a(0, ks); aw[ks % AW] = af[0]; };
+        auto ld_bu = [&](int fb, int j) __attribute__((always_inline)) {
+          const int u = j / 3, kx = j % 3;
+          const int par = u & 1;
+          const int rimm = (PW == 16) ? u * P::HW : 10 * u;
+          bfm[fb] = trf(buf + xa[kx][par] + rimm * XROWB, XROWB);
+        };
+        ld_aw(0);
+#pragma unroll
+        for (int j = 0; j < LA; ++j) ld_bu(j, j);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * LA, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          const int u = j / 3, kx = j % 3;
+          int nrd = 0, nmf = 0;
+          if (j + LA < NB) { ld_bu((j + LA) & 3, j + LA); nrd += 2; }
+          // the dy fragment of k-step ks is first used at u = ks (PW 16) / u = 2 ks (PW 8): requested one u earlier, into the slot
+          // of the k-step whose last use (ky = 2) lies behind
+          const int ksn = (PW == 16) ? u + 1 : (u + 1) / 2;
+          if (kx == 0 && ksn < NK && ((PW == 16) || (u & 1))) { ld_aw(ksn); nrd += 2; }
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky) {
+            const int num = u - ky, ks = (PW == 16) ? num : num / 2;
+            if (num >= 0 && ks < NK && ((PW == 16) || (num & 1) == 0)) {
+              acc[ky * 3 + kx] = mfma32(aw[ks % AW], bfm[j & 3], acc[ky * 3 + kx]);
+              ++nmf;
+            }
+          }
+          if (nrd == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);          // (the builtin takes literals)
+          else if (nrd == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+          if (nmf == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          else if (nmf == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          else __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+        }
+      } else {
       ld_a(0, 0);
 #pragma unroll
       for (int j = 0; j < LA; ++j) ld_b(j, j);
@@ -232,6 +280,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_wgrad_glds_kernel(const Wgr
           else __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+      }
       }
     }
     tile = ntile;

@@ -10,7 +10,7 @@
 #include "lds_dma.h"
 
 template <int NG>
-__global__ __launch_bounds__(256 * NG, NG) void wgrad1x1_glds_kernel(const WgradDev d) {
+__global__ __launch_bounds__(256 * NG, 2) void wgrad1x1_glds_kernel(const WgradDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int KT = 64, ROWB = 256, TILEB = KT * ROWB, BUFB = 2 * TILEB;       // dy tile | x tile
   __shared__ __attribute__((aligned(16))) unsigned char smem[NG * 2 * BUFB];
@@ -156,7 +156,10 @@ static inline bool wgrad1x1_glds_ok(const OnirisWgradArgs& a) {
 }
 
 static int launch_wgrad1x1_glds(const OnirisWgradArgs& a, hipStream_t stream) {
-  constexpr int NG = 2;
+#ifndef WGRAD1X1_NG
+#define WGRAD1X1_NG 2                        // K-groups per workgroup (1: two 4-wave workgroups per CU; A/B)
+#endif
+  constexpr int NG = WGRAD1X1_NG;
   WgradDev d;
   memset(&d, 0, sizeof(d));
   d.a[0] = a;
@@ -164,7 +167,7 @@ static int launch_wgrad1x1_glds(const OnirisWgradArgs& a, hipStream_t stream) {
   const int gy = d.ncib * cdiv(a.Cout, 128);
   const long long m = (long long)a.B * a.T * a.H * a.W;
   const int ntiles = (int)((m + 63) / 64);
-  int gx = 256 / gy;                                        // one workgroup per CU in total; one slab per column
+  int gx = (256 * 2 / NG) / gy;                             // 8 waves per CU in total; one slab per column
   if (gx > a.nsplit_cap) gx = a.nsplit_cap;
   if (gx * NG > ntiles) gx = (ntiles + NG - 1) / NG;
   if (gx < 1) gx = 1;

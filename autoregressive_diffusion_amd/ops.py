@@ -166,7 +166,7 @@ def _nsplit_cap(cin, cout, taps, gated_pair=False):
     gradient launch_wgrad_stream() can take."""
     tile = 2 if (cin > 32 and cout > 32) else 1
     gy = -(-roundup(cin, 16) // (32 * tile)) * -(-roundup(cout, 8) // (32 * tile))
-    cap = max(1, (256 if tile == 2 else 512) // gy)
+    cap = max(1, 512 // gy)       # (two 4-wave workgroups per CU for both tile forms since round 5: WGRAD_NG = 1 in csrc/conv_wgrad.hip)
     if tile == 1 and taps >= 9 and gated_pair:
         cap = 512       # launch_wgrad_stream() (csrc/conv_wgrad_stream.h): one slab per (sequence, 8x16-pixel tile, segment)
     if taps == 1 and cin >= 64 and cout >= 64:
@@ -674,7 +674,7 @@ def _wgrad_launch_group(arglist):
             key = "conv_wgrad_stream_kernel"                                      # mirrors wgrad_stream_ok() / launch_wgrad_stream()
         elif WGRAD_VARIANT >= 0 and all(a.taps == 9 and ((a.W % 16 == 0 and a.H % 8 == 0) or (a.W == 8 and a.H == 8))
                                       and a.fill in (0.0, 1.0) for a in arglist):     # mirrors wgrad_glds_ok() in csrc
-            key = f"conv_wgrad_glds_kernel<CT={tile},IT={tile},NG=2,PW={_patch_w(a0.W)}>"
+            key = f"conv_wgrad_glds_kernel<CT={tile},IT={tile},NG=1,PW={_patch_w(a0.W)}>"
         elif (WGRAD_VARIANT >= 0 and len(arglist) == 1 and a0.taps == 1 and a0.Cin >= 64 and a0.Cout >= 64 and not a0.scale
               and a0.coff == 0):                                               # mirrors wgrad1x1_glds_ok()
             key = "wgrad1x1_glds_kernel<NG=2>"
