@@ -33,9 +33,15 @@ struct WgradStreamDev {
   float fill;
 };
 
-__global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradStreamDev d) {
+// PH = 8: 8x16-pixel tiles, one 8-wave workgroup per CU (rounds 4-5).  PH = 4: 4x16-pixel tiles, 4 waves (dW2 of slot 0 / slot 1, dW3[0],
+// dW3[1]: every wave the whole tile), 66 KB of LDS: TWO independent workgroups per CU that do not share a barrier (the lesson of
+// conv_wgrad_glds_kernel's K-groups, profiles/r05_ab_wgrad_groups.txt); +20 % halo rows, twice the slabs.
+template <int PH>
+__global__ __launch_bounds__(64 * PH, 2) void conv_wgrad_stream_kernel(const WgradStreamDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int TAPS = 9, HW_ = 18, HALO = 180, XB = HALO * 64, DB = 128 * 64;
+  static_assert(PH == 8 || PH == 4, "tile heights");
+  constexpr int NTHR = 64 * PH, NPOS = PH * 16;
+  constexpr int TAPS = 9, HW_ = 18, HALO = (PH + 2) * HW_, XB = HALO * 64, DB = NPOS * 64;
   constexpr int XS0 = 0, XS1 = 4 * XB, DY0 = 6 * XB;               // x[s0] ring (4) | x[s1] (2) | dy (2 x 3)
   constexpr int LDS_BYTES = 6 * XB + 6 * DB;
   static_assert(LDS_BYTES <= 160 * 1024 && 5 * 3 * 16 * 64 * 4 <= LDS_BYTES, "LDS budget");
@@ -48,13 +54,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradSt
   int u = blockIdx.x;
   const int seg = u % d.nseg; u /= d.nseg;
   const int x0 = (u % d.ntx) * 16; u /= d.ntx;
-  const int y0 = (u % d.nty) * 8;
+  const int y0 = (u % d.nty) * PH;
   const int b = u / d.nty;
   const int t0 = seg * d.seglen, t1 = min(T, t0 + d.seglen);
 
   // ---- roles
-  const int role = (wave < 4) ? 0 : (wave < 6 ? 1 : 2);            // own | ctx t-2 | ctx t-1
-  const int slot = (wave < 4) ? (wave >> 1) : 0, half = wave & 1;
+  const int role = (PH == 8) ? ((wave < 4) ? 0 : (wave < 6 ? 1 : 2)) : ((wave < 2) ? 0 : wave - 1);     // own | ctx t-2 | ctx t-1
+  const int slot = (PH == 8) ? ((wave < 4) ? (wave >> 1) : 0) : ((wave < 2) ? wave : 0), half = (PH == 8) ? (wave & 1) : 0;
 
   f32x16 acc[TAPS];
 #pragma unroll
@@ -64,16 +70,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradSt
 
   // ---- DMA descriptors (per lane, frame-invariant)
   constexpr int OOB = (int)0x80000000;
-  int dvoff;                                                       // dy tile: 512 pieces = one per thread
+  int dvoff;                                                       // dy tile: NPOS * 4 pieces = one per thread
   {
     const int row = tid >> 2, gp = tid & 3, co = co0 + gp * 8;
     dvoff = (co < Cout) ? (((row >> 4) * W + (row & 15)) * Cout + co) * 2 : OOB;
   }
-  int xvoff[2];                                                    // halo: 720 pieces
+  int xvoff[2];                                                    // halo: 720 (432) pieces
   bool xok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int e = i * 512 + tid, row = e >> 2, gp = e & 3, ci = ci0 + gp * 8;
+    const int e = i * NTHR + tid, row = e >> 2, gp = e & 3, ci = ci0 + gp * 8;
     const int hy = row / HW_, hx = row % HW_;
     xok[i] = e < HALO * 4 && ci < Cin && (unsigned)(y0 + hy - 1) < (unsigned)H && (unsigned)(x0 + hx - 1) < (unsigned)W;
     xvoff[i] = xok[i] ? (((y0 + hy - 1) * W + (x0 + hx - 1)) * Cin + ci) * 2 : OOB;
@@ -91,10 +97,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradSt
     if (f >= 0) {
       const int so = (((b * 2 + s) * T + f) * HWp * Cin) * 2;
       dma16(rs_x, xvoff[0], so, dst + wdst);
-      if (wave < 4) { if (512 + tid < HALO * 4) dma16(rs_x, xvoff[1], so, dst + wdst + 8192); }
+      if (wave < (HALO * 4 - NTHR + 63) / 64) { if (NTHR + tid < HALO * 4) dma16(rs_x, xvoff[1], so, dst + wdst + NTHR * 16); }
     } else {
       dma16(rs_f, xok[0] ? fillsel : OOB, 0, dst + wdst);
-      if (wave < 4) { if (512 + tid < HALO * 4) dma16(rs_f, xok[1] ? fillsel : OOB, 0, dst + wdst + 8192); }
+      if (wave < (HALO * 4 - NTHR + 63) / 64) { if (NTHR + tid < HALO * 4) dma16(rs_f, xok[1] ? fillsel : OOB, 0, dst + wdst + NTHR * 16); }
     }
   };
   auto issue_frame = [&](int f) __attribute__((always_inline)) {    // everything frame f brings: 2 halos + 3 dy tiles
@@ -163,6 +169,38 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradSt
       const int j = st / TAPS, tap = st % TAPS, ky = tap / 3, kx = tap % 3;
       bfm[fb] = trf(bbuf + xa[kx] + (j + ky) * HW_ * 64);
     };
+#ifndef WGRAD_STREAM_ROWORDER
+#define WGRAD_STREAM_ROWORDER 1            // 0: every (pixel row, tap) reads its own x fragment (round 4's loop; A/B)
+#endif
+    if constexpr (WGRAD_STREAM_ROWORDER != 0) {
+      // halo-row order (see conv_wgrad_glds.h): the x fragment of (pixel row j, tap (ky, kx)) depends on u = j + ky and kx only --
+      // 18 distinct fragments per frame and wave instead of 36 reads; per tap the rows are still added in ascending order
+      constexpr int NU = NK + 2, NB = NU * 3;
+      bf16x8 aw[4];
+      auto ld_aw = [&](int j) __attribute__((always_inline)) { ld_a(0, j); aw[j & 3] = af[0]; };
+      auto ld_bu = [&](int fb, int i) __attribute__((always_inline)) { bfm[fb] = trf(bbuf + xa[i % 3] + (i / 3) * HW_ * 64); };
+      ld_aw(0);
+#pragma unroll
+      for (int i = 0; i < LA; ++i) ld_bu(i, i);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 + 2 * LA, 0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int u = i / 3, kx = i % 3;
+        int nrd = 0, nmf = 0;
+        if (i + LA < NB) { ld_bu((i + LA) & 3, i + LA); nrd += 2; }
+        if (kx == 0 && u + 1 < NK) { ld_aw(u + 1); nrd += 2; }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          const int j = u - ky;
+          if (j >= 0 && j < NK) { acc[ky * 3 + kx] = mfma32(aw[j & 3], bfm[i & 3], acc[ky * 3 + kx]); ++nmf; }
+        }
+        if (nrd == 2) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        else if (nrd == 4) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+        if (nmf == 1) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        else if (nmf == 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        else __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+      }
+    } else {
     ld_a(0, 0);
 #pragma unroll
     for (int j = 0; j < LA; ++j) ld_b(j, j);
@@ -182,6 +220,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradSt
       }
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
     }
+    }
   }
 
   // ---- the waves that worked on the same weight meet in LDS (three taps per round), then waves 0 / 4 / 6 write the slabs
@@ -189,7 +228,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradSt
     if (d.nsplit2) *d.nsplit2 = gridDim.x;
     if (d.nsplit3) *d.nsplit3 = gridDim.x;
   }
-  const int nl = (wave == 1) ? 0 : (wave == 2) ? 1 : (wave == 3) ? 2 : (wave == 5) ? 3 : (wave == 7) ? 4 : -1;
+  const int nl = (PH == 8) ? ((wave == 1) ? 0 : (wave == 2) ? 1 : (wave == 3) ? 2 : (wave == 5) ? 3 : (wave == 7) ? 4 : -1)
+                           : ((wave == 1) ? 0 : -1);             // PH 4: only dW2 has two partial sums (the slots)
   float* red = (float*)smem;                                     // [5][3][16][64]
 #pragma unroll
   for (int r3 = 0; r3 < 3; ++r3) {
@@ -202,7 +242,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_stream_kernel(const WgradSt
     }
     __syncthreads();
     if (nl < 0) {
-      const int first = (wave == 0) ? 0 : (wave == 4) ? 3 : 4, cnt = (wave == 0) ? 3 : 1;
+      const int first = (PH == 8) ? ((wave == 0) ? 0 : (wave == 4) ? 3 : 4) : 0;
+      const int cnt = (PH == 8) ? ((wave == 0) ? 3 : 1) : ((wave == 0) ? 1 : 0);
 #pragma unroll
       for (int k = 0; k < 3; ++k)
 #pragma unroll
@@ -254,20 +295,27 @@ static int launch_wgrad_stream(const OnirisWgradArgs* a, hipStream_t stream) {
   d.x = o.x; d.dout = o.dy; d.dy3 = c0.dy; d.scale = o.scale;
   d.dwp2 = o.dwp; d.dwp3 = c0.dwp; d.nsplit2 = o.nsplit_out; d.nsplit3 = c0.nsplit_out;
   d.B = c0.B; d.T = c0.T; d.H = o.H; d.W = o.W; d.Cin = o.Cin; d.CinP = o.CinP; d.Cout = o.Cout; d.CoutP = o.CoutP;
-  d.ntx = o.W / 16; d.nty = o.H / 8; d.ncib = cdiv(o.Cin, 32);
+#ifndef WGRAD_STREAM_PH
+#define WGRAD_STREAM_PH 4                  // 8: always the 8x16-pixel form (A/B: make variant VSRC=conv_wgrad VDEF=-DWGRAD_STREAM_PH=8)
+#endif
+  d.ntx = o.W / 16; d.ncib = cdiv(o.Cin, 32);
   d.fill = c0.fill;
   const int ncob = cdiv(o.Cout, 32), gy = d.ncib * ncob;
-  const int units = d.B * d.ntx * d.nty;
   const int cap = o.nsplit_cap < c0.nsplit_cap ? o.nsplit_cap : c0.nsplit_cap;
+  // 4x16-pixel tiles (two 4-wave workgroups per CU) where the weights own enough slabs, 8x16 otherwise
+  int ph = (WGRAD_STREAM_PH == 4 && d.B * d.ntx * (o.H / 4) <= cap) ? 4 : 8;
+  d.nty = o.H / ph;
+  const int units = d.B * d.ntx * d.nty;
   if (units > cap) return 1;                                        // more slabs than the weights own: the tile kernel takes it
-  // about one workgroup per CU: cut the sequences into segments of >= 8 frames (a segment re-copies two halos at its head)
-  int nseg = (256 / gy) / units;
+  // about one (two) workgroup(s) per CU: cut the sequences into segments of >= 8 frames (a segment re-copies two halos at its head)
+  int nseg = ((ph == 4 ? 512 : 256) / gy) / units;
   if (nseg > d.T / 8) nseg = d.T / 8;
   if (nseg * units > cap) nseg = cap / units;
   if (nseg < 1) nseg = 1;
   d.seglen = cdiv(d.T, nseg);
   d.nseg = cdiv(d.T, d.seglen);
-  oniris_launch(conv_wgrad_stream_kernel, dim3(units * d.nseg, gy), dim3(512), stream, d);
+  if (ph == 4) oniris_launch(conv_wgrad_stream_kernel<4>, dim3(units * d.nseg, gy), dim3(256), stream, d);
+  else oniris_launch(conv_wgrad_stream_kernel<8>, dim3(units * d.nseg, gy), dim3(512), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
