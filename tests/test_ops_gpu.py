@@ -141,7 +141,9 @@ def test_conv_plain(N, H, cin, cout, k):
                                             (2, 64, 64, 32, 32),
                                             # the streaming kernels of the 32-channel level (conv_stream.h / conv_wgrad_stream.h):
                                             # ragged Cout, several segments per sequence with a ragged last one, one frame
-                                            (2, 5, 32, 32, 8), (1, 19, 16, 32, 32), (4, 1, 16, 32, 24), (1, 64, 32, 32, 32)])
+                                            (2, 5, 32, 32, 8), (1, 19, 16, 32, 32), (4, 1, 16, 32, 24), (1, 64, 32, 32, 32),
+                                            # ... and its 8x16-pixel form (B * 4 * 16 tiles of 4x16 pixels > the 512 slabs of a weight)
+                                            (9, 2, 64, 32, 24)])
 def test_gated_conv_train(B, T, H, cin, cout):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(3)

@@ -374,7 +374,9 @@ def _ternary(shape, density, gen):
 
 @pytest.mark.parametrize("B,T,H,cin,cout,dens", [(1, 2, 8, 32, 32, 0.25), (2, 8, 64, 32, 32, 0.05), (2, 4, 16, 128, 128, 0.12),
                                                  (2, 4, 8, 256, 256, 0.2), (1, 6, 32, 64, 64, 0.08), (1, 3, 16, 96, 160, 0.15),
-                                                 (2, 16, 64, 32, 32, 0.04), (2, 4, 4, 512, 512, 0.3), (1, 3, 8, 1024, 512, 0.25)])
+                                                 (2, 16, 64, 32, 32, 0.04), (2, 4, 4, 512, 512, 0.3), (1, 3, 8, 1024, 512, 0.25),
+                                                 # more 4x16-pixel tiles than the weights own slabs: the streaming kernel's 8x16-pixel form
+                                                 (9, 2, 64, 32, 32, 0.04)])
 def test_gated_conv_weight_gradient_integer_exact(B, T, H, cin, cout, dens):
     """Weight gradient of the gated conv -- own 3x3 weight over both slots, the two context taps over the clean frames, split-K
     slabs in bf16, slab reduction + normalisation backward in weight_bwd -- on sparse ternary activations and gradients with
