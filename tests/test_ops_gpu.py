@@ -103,7 +103,11 @@ def test_weight_perm3():
                                             # ragged last position tile, Cout not a multiple of the 128-channel tile
                                             (15, 24, 64, 192, 1), (9, 32, 128, 136, 1), (8, 32, 192, 64, 1), (2, 64, 256, 768, 1),
                                             # even frame counts on Cin % 32 == 0: the LDS-DMA kernel without context phases
-                                            (4, 8, 32, 128, 3), (2, 32, 32, 32, 3), (10, 16, 64, 96, 3)])
+                                            (4, 8, 32, 128, 3), (2, 32, 32, 32, 3), (10, 16, 64, 96, 3),
+                                            # 32 -> <= 32 channels with >= 512 tiles of 8x16 pixels: the plain streaming kernel
+                                            # (conv_plain_stream.h; forward and data gradient): segments with a ragged last one,
+                                            # an odd frame count, ragged Cout
+                                            (20, 64, 32, 32, 3), (70, 32, 32, 8, 3), (33, 64, 32, 24, 3)])
 def test_conv_plain(N, H, cin, cout, k):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(2)
@@ -795,7 +799,9 @@ def test_clip_flags_survive_a_second_forward_before_backward():
 # H = 16: the LDS-DMA tile kernel's epilogues (cout = 64) and the streaming kernel's (cout = 32); clipped = False: the +-256 clip
 # is armed but never reached -- the usual case, in which the backward pre-pass reads no mask (OnirisConvArgs.clip_flag)
 @pytest.mark.parametrize("gated,H,cout,clipped", [(False, 8, 64, True), (True, 8, 64, True), (True, 16, 64, True),
-                                                  (True, 16, 64, False), (True, 16, 32, True), (True, 16, 32, False)])
+                                                  (True, 16, 64, False), (True, 16, 32, True), (True, 16, 32, False),
+                                                  # the plain streaming kernel's epilogues (8 frames of 128x128 pixels = 1024 tiles)
+                                                  (False, 128, 32, True), (False, 128, 32, False), (False, 128, 24, True)])
 def test_conv_epilogues(gated, H, cout, clipped):
     """conv + (x c, mp_silu) and conv + (mp_sum with residual, clip) epilogues, forward and backward."""
     from autoregressive_diffusion_amd import ops
