@@ -7,7 +7,7 @@
 // run on the persistent LDS-DMA kernel as "two slots of T/2 frames, no context phases".
 int conv_dispatch_s1(const OnirisConvArgs& a, hipStream_t st) {
   // 32 -> <= 32 channels on 16-pixel-wide images (the 64x64 level in the 2-D steps): frames streamed past register-resident weights
-  if (a.big_tile >= 4 && !(a.big_tile & 32) && conv_plain_stream_ok(a)) return launch_conv_plain_stream(a, st);
+  if (a.big_tile >= 4 && !(a.big_tile & 128) && conv_plain_stream_ok(a)) return launch_conv_plain_stream(a, st);
   if (a.big_tile >= 3) {
     OnirisConvArgs b = a;
     b.S = 2; b.T = a.T / 2;

@@ -587,7 +587,7 @@ def _conv_launch(x, ctx, w_own, w_ctx, out, coef_own, coef_ctx, B, S, T, H, W, C
         elif (BIG_TILE >= 3 and S == 2 and ctx is not None and taps == 9 and Cin % 32 == 0 and H == 8 and W == 8
               and CoutP % 64 == 0 and ctx_fill in (0.0, 1.0)):
             key = "conv_glds_kernel<NT=1,PW=8,NW=8,MT=1,WC=2,CTX=1>"
-        elif (BIG_TILE >= 4 and not (BIG_TILE & 32) and S == 1 and ctx is None and taps == 9 and Cin == 32 and CinP == 64 and CoutP == 32
+        elif (BIG_TILE >= 4 and not (BIG_TILE & 128) and S == 1 and ctx is None and taps == 9 and Cin == 32 and CinP == 64 and CoutP == 32
               and W % 16 == 0 and H % 8 == 0 and x2 is None and B * T * (H // 8) * (W // 16) >= 512):   # conv_plain_stream_ok()
             key = "conv_plain_stream_kernel"
         elif (BIG_TILE >= 3 and S == 1 and ctx is None and taps == 9 and Cin % 32 == 0 and T % 2 == 0

@@ -225,7 +225,7 @@ typedef struct OnirisConvArgs {
   int32_t big_tile;       /* variant: 0 = 4-wave register-staged kernels, 1/2 = 8-wave ones where they fill the chip /
                            * always, >= 3 = persistent LDS-DMA kernel (csrc/conv_glds.h) wherever the shape allows,   *
                            * >= 4 = + the streaming kernels of the 32-channel level (conv_stream.h, conv_plain_stream.h); *
-                           * diagnostic bits: 16 = no conv_eval1_kernel, 32 = no conv_plain_stream_kernel              */
+                           * diagnostic bits: 16 = no conv_eval1_kernel, 32 = copy issue of conv_glds at the phase start, 128 = no conv_plain_stream_kernel            */
   int32_t escale_pitch;   /* floats between consecutive rows of escale (0 = Cout): a UNet's emb-scales are column
                            * blocks of ONE [B*S*T][sum Cout] GEMM output, read in place                            */
   /* Optional split-K workspace (caller-allocated, reusable by consecutive launches on one stream): when given and

@@ -1,9 +1,9 @@
 #!/bin/bash
-# plain streaming kernel on (default) / off (ONIRIS_BIG_TILE=36: bit 5 sends those launches back to the tile kernel)
+# plain streaming kernel on (default) / off (ONIRIS_BIG_TILE=132: bit 7 sends those launches back to the tile kernel)
 O=gpurun_out
 python -m pytest tests/test_ops_gpu.py -m gpu -q -x -k "test_conv_plain or test_conv_epilogues or clip_flags" 2>&1 | tail -15
 for rep in 1 2; do
-for bt in 36 4; do
+for bt in 132 4; do
   ONIRIS_BIG_TILE=$bt python bench.py --steps 12 --warmup 4 --cpu-frames 0 --no-extra > $O/ab5_${bt}_$rep.json 2>/dev/null
   python - $bt $rep <<'PY'
 import json, sys
