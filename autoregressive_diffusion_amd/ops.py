@@ -359,10 +359,11 @@ class WeightBank:
                 o += n
             self._gpool_n = len(trainable)
             self._gpool_uses = None
-        uses = torch._C._storage_Use_Count(pool.untyped_storage()._cdata)
+        use_count = getattr(torch._C, "_storage_Use_Count", None)       # (a private torch call: without it, no pooling)
+        uses = use_count(pool.untyped_storage()._cdata) if use_count is not None else -1
         if self._gpool_uses is None:
             self._gpool_uses = uses
-        pooled = uses == self._gpool_uses and all(_sys.getrefcount(w.gview) == 2 for w in released)   # (2: the slot + the argument)
+        pooled = uses >= 0 and uses == self._gpool_uses and all(_sys.getrefcount(w.gview) == 2 for w in released)   # (2: the slot + the argument)
         if pooled:
             if len(released) == len(trainable):
                 pool.zero_()
