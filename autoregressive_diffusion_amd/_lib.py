@@ -89,7 +89,7 @@ _SIGS = {
                                       c_float, c_void_p]),
     "oniris_sqnorm": (c_int, [c_void_p, c_size_t, c_void_p, c_void_p]),
     "oniris_dart_input": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
-                                  c_float, c_void_p, c_void_p]),
+                                  c_float, c_void_p, c_int, c_void_p]),
     "oniris_dart_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
                                  c_int, c_int, c_float, c_void_p]),
     "oniris_dart_loss_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

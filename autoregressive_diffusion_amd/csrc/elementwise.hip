@@ -507,7 +507,7 @@ extern "C" int oniris_resample_filter(const void* in, void* out, const void* add
 //   dart_loss_bwd: dF (bf16, zero for the clean slots) and per-frame partial sums of d out_gain
 __global__ __launch_bounds__(256) void dart_input_kernel(const float* __restrict__ img, const float* __restrict__ noise,
                                                          const float* __restrict__ sigma, bf16* __restrict__ xcl, int S,
-                                                         int T, int C, int HW, float sd, float* __restrict__ c_noise_out) {
+                                                         int T, int C, int HW, float sd, float* __restrict__ c_noise_out, int cpad) {
   const int n = blockIdx.y, b = n / (S * T), st = n % (S * T), t = st % T;
   const float sg = sigma[b * S * T + st];
   if (c_noise_out && blockIdx.x == 0 && threadIdx.x == 0) c_noise_out[n] = logf(sg) / 4.f;     // c_noise (networks_edm2.py:291)
@@ -527,9 +527,10 @@ __global__ __launch_bounds__(256) void dart_input_kernel(const float* __restrict
       else if (c == C) v = 1.f;
       o[c] = f2bf(v);
     }
-    uint4* dst = (uint4*)(xcl + ((size_t)n * HW + p) * 16);
+    uint4* dst = (uint4*)(xcl + ((size_t)n * HW + p) * cpad);
     dst[0] = *(const uint4*)&o[0];
     dst[1] = *(const uint4*)&o[8];
+    for (int c8 = 2; c8 < cpad / 8; ++c8) dst[c8] = make_uint4(0u, 0u, 0u, 0u);     // (cpad = 32: the widths the streaming kernels take)
   }
 }
 
@@ -583,15 +584,16 @@ __global__ __launch_bounds__(1024) void dart_loss_kernel(const bf16* __restrict_
 }
 
 extern "C" int oniris_dart_input(const float* images, const float* noise, const float* sigma, void* xcl, int B, int S,
-                                 int T, int C, int H, int W, float sigma_data, float* c_noise_out, oniris_stream_t stream_) {
+                                 int T, int C, int H, int W, float sigma_data, float* c_noise_out, int cpad, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(images && sigma && xcl && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 && C < 16 && H > 0 && W > 0,
                    "dart_input: bad arguments");
+  ONIRIS_CHECK_ARG(cpad >= 16 && cpad % 8 == 0 && cpad <= 64, "dart_input: cpad must be 16 ... 64 and a multiple of 8 (got %d)", cpad);
   const int HW = H * W;
   int gx = cdiv(HW, 256);
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(dart_input_kernel, dim3(gx, B * S * T), dim3(256), 0, stream, images, noise, sigma, (bf16*)xcl, S, T, C,
-                     HW, sigma_data, c_noise_out);
+                     HW, sigma_data, c_noise_out, cpad);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -32,7 +32,7 @@ extern "C" int oniris_profile_disarm(void) {          // 1: the pair was still a
   oniris_prof_ev[0] = oniris_prof_ev[1] = nullptr;
   return armed;
 }
-extern "C" int oniris_abi_version(void) { return 12; }
+extern "C" int oniris_abi_version(void) { return 13; }
 
 long long oniris_ew_nt_bytes(void) {
   static long long v = -1;

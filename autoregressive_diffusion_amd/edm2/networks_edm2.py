@@ -189,7 +189,7 @@ class UNet(BetterModule):
         return out
 
     def _forward(self, x, c_noise, conditioning=None, cache=None, update_cache=False, just_2d=False, _cl_io=None):
-        """_cl_io = (B, tt): `x` is already the packed UNet input (B*tt, H, W, 16) bf16 with the ones channel
+        """_cl_io = (B, tt): `x` is already the packed UNet input (B*tt, H, W, ops.IN_PAD) bf16 with the ones channel
         (ops.dart_input) and the raw channels-last output (B*tt, H, W, 8k) bf16 is returned WITHOUT out_gain -- the
         fused DART loss applies it (ops.dart_loss).  Default: the reference signature (:191)."""
         if cache is None:
@@ -218,12 +218,12 @@ class UNet(BetterModule):
                                       self.label_dim)
             else:
                 emb = ops._prelude_ref("embedding")(self, cn, conditioning)
-            # input: (B,t,C,H,W) -> channels-last with the extra all-ones channel (:221), padded to 16 channels
+            # input: (B,t,C,H,W) -> channels-last with the extra all-ones channel (:221), padded to ops.IN_PAD channels
             N = B * tt
             if _cl_io is None:
                 xc = x.reshape(N, *x.shape[2:])
                 xc = torch.cat([xc, torch.ones_like(xc[:, :1])], dim=1)
-                xcl = to_cl(xc, pad_to=-(-xc.shape[1] // 16) * 16)
+                xcl = to_cl(xc, pad_to=max(ops.IN_PAD, -(-xc.shape[1] // 16) * 16))
             else:
                 xcl = x
             if not just_2d:

@@ -2042,15 +2042,21 @@ def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
 # ------------------------------------------------------------------------------------------------------------------
 # optimizer
 
+# Channels of the packed UNet input (image channels + the ones channel, zero-padded).  32 (round 5): the stem conv and its weight
+# gradient then have the 32-channel shape the streaming kernels take (conv_stream.h, conv_plain_stream.h, conv_wgrad_stream.h, and
+# conv_eval1.h in the sampler) instead of the register-staged kernels' 16 -- twice the input bytes, at 2-3x their rate.  16: A/B.
+IN_PAD = int(_os.environ.get("ONIRIS_IN_PAD", "32"))
+
+
 def dart_input(images, noise, sigma, S, sigma_data, want_c_noise=False):
     """Packed UNet input of a DART training step (oniris_dart_input): images (B,T,C,H,W), noise (B,S*T,C,H,W), sigma
-    (B,S*T) fp32 -> (B*S*T, H, W, 16) bf16 = c_in * (images + sigma*noise) with the ones channel.
+    (B,S*T) fp32 -> (B*S*T, H, W, IN_PAD) bf16 = c_in * (images + sigma*noise) with the ones channel, zeros behind it.
     want_c_noise: also return c_noise = log(sigma)/4 like sigma (networks_edm2.py:291), from the same launch."""
     _need_gpu(images, noise, sigma)                 # (noise None: c_in * images, Precond's input side in eval)
     B, T, C, H, W = images.shape
-    xcl = torch.empty((B * S * T, H, W, 16), dtype=BF16, device=images.device)
+    xcl = torch.empty((B * S * T, H, W, IN_PAD), dtype=BF16, device=images.device)
     cn = torch.empty((B, S * T), dtype=torch.float32, device=images.device) if want_c_noise else None
-    check(lib.oniris_dart_input(_p(images), _p(noise), _p(sigma), _p(xcl), B, S, T, C, H, W, float(sigma_data), _p(cn),
+    check(lib.oniris_dart_input(_p(images), _p(noise), _p(sigma), _p(xcl), B, S, T, C, H, W, float(sigma_data), _p(cn), IN_PAD,
                                 _stream()), "dart_input")
     return (xcl, cn) if want_c_noise else xcl
 

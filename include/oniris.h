@@ -23,7 +23,8 @@ extern "C" {
 typedef void* oniris_stream_t;
 
 const char* oniris_last_error(void);
-int oniris_abi_version(void);   /* 12.  11 -> 12: oniris_set_cu_reserve; 10 -> 11: OnirisConvArgs.ctx_prod / ctx_prod_mode (appended fields); 9 -> 10: OnirisConvArgs.clip_flag,
+int oniris_abi_version(void);   /* 13.  12 -> 13: oniris_dart_input(+ cpad: the packed input is 32 channels wide in the product, so that the stem conv runs on the
+                                 * streaming kernels of the 32-channel level); 11 -> 12: oniris_set_cu_reserve; 10 -> 11: OnirisConvArgs.ctx_prod / ctx_prod_mode (appended fields); 9 -> 10: OnirisConvArgs.clip_flag,
                                  * oniris_gconv_bwd_fused(+ clip_flag, coef_own_scaled), oniris_qkv_norm_hd / _hd_bwd / oniris_rope_hd       */
 /* Measurement aid: arm a pair of HIP events (hipEvent_t created with timing); the next MFMA conv / weight-gradient /
  * scheduled attention-forward kernel this THREAD launches records its own begin and end into them (hipExtLaunchKernel:
@@ -95,12 +96,13 @@ int oniris_weight_bwd(const OnirisWeightDesc* descs, int ndesc, int total_rows, 
  * instead of ~25 activation-sized fp32 elementwise launches.  images [B][T][C][H][W], noise [B][S*T][C][H][W], sigma
  * [B][S*T] fp32; slot n = (b, s, t), s = 0 clean | 1 noised (S = 1 in 2-D steps); x[n] = images[b,t] + sigma*noise is
  * never materialised.
- *   dart_input:    xcl bf16 [B*S*T][H][W][16] = c_in * x, channel C = 1 (ones channel), the rest 0          (C < 16)
+ *   dart_input:    xcl bf16 [B*S*T][H][W][cpad] = c_in * x, channel C = 1 (ones channel), the rest 0        (C < 16)
  *   dart_loss:     losses[b][t] = mean_{c,h,w} (c_skip*x + c_out*out_gain*F - images)^2 of the noised half; F = the
  *                  UNet's channels-last output bf16 [B*S*T][H][W][8], out_gain a device scalar             (C <= 8)
  *   dart_loss_bwd: dF (bf16, zero for clean slots) and dgain_part[b][t] (sum them for d out_gain) from dlosses[b][t] */
 int oniris_dart_input(const float* images, const float* noise, const float* sigma, void* xcl, int B, int S, int T, int C,
-                      int H, int W, float sigma_data, float* c_noise_out, oniris_stream_t stream);
+                      int H, int W, float sigma_data, float* c_noise_out, int cpad /* ABI 13: channels of xcl (16 ... 64, % 8) */,
+                      oniris_stream_t stream);
 /*   c_noise_out (may be NULL): [B*S*T] fp32 = log(sigma) / 4, the UNet's noise conditioning (networks_edm2.py:291), written by
  *   the same launch (the sampler's evaluations save two tiny launches each)                                           */
 int oniris_dart_loss(const void* F, const float* images, const float* noise, const float* sigma, const float* out_gain,

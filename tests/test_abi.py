@@ -17,7 +17,7 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(_lib.EXPORTED), (declared ^ set(_lib.EXPORTED))
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.oniris_abi_version() == 12
+    assert _lib.lib.oniris_abi_version() == 13
 
 
 def test_mask_tables_against_golden():
