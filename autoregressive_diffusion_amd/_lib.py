@@ -76,6 +76,9 @@ _SIGS = {
     "oniris_profile_arm": (c_int, [c_void_p, c_void_p]),
     "oniris_profile_disarm": (c_int, []),
     "oniris_set_cu_reserve": (c_int, [c_int]),
+    "oniris_set_ew_nt_bytes": (c_int64, [c_int64]),
+    "oniris_census": (c_int, [c_int]),
+    "oniris_census_read": (c_int64, [C.c_char_p, c_int64]),
     "oniris_train_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_infer_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),
     "oniris_mask_transpose": (c_int, [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -1232,9 +1232,9 @@ static int attn_prepare(const OnirisAttnArgs* args, AttnDev& d, const char* who)
 
 #define ATTN_DISPATCH(KERN, GRID)                                                                     \
   switch (d.a.mask_mode) {                                                                            \
-    case 0: hipLaunchKernelGGL(KERN<0>, GRID, dim3(256), 0, stream, d); break;                        \
-    case 1: hipLaunchKernelGGL(KERN<1>, GRID, dim3(256), 0, stream, d); break;                        \
-    default: hipLaunchKernelGGL(KERN<2>, GRID, dim3(256), 0, stream, d); break;                       \
+    case 0: ONIRIS_KLAUNCH(KERN<0>, GRID, dim3(256), 0, stream, d); break;                        \
+    case 1: ONIRIS_KLAUNCH(KERN<1>, GRID, dim3(256), 0, stream, d); break;                        \
+    default: ONIRIS_KLAUNCH(KERN<2>, GRID, dim3(256), 0, stream, d); break;                       \
   }
 
 extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t stream_) {
@@ -1267,23 +1267,23 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
     ONIRIS_CHECK_ARG(d.a.mask_mode == 0 && d.a.split_ws && d.a.kv_splits <= 256,
                      "attn_fwd: kv_splits serves the dense (mask_mode 0) kernel and needs split_ws");
     const dim3 gs(cdiv(d.a.Lq, 128) * d.a.kv_splits, d.a.heads, d.a.B);
-    hipLaunchKernelGGL((attn_fwd_kernel<0, 1>), gs, dim3(256), 0, stream, d);
+    ONIRIS_KLAUNCH((attn_fwd_kernel<0, 1>), gs, dim3(256), 0, stream, d);
     ONIRIS_LAUNCH_CHECK();
     const long long nthr = (long long)d.a.B * d.a.heads * d.a.Lq * 8;
-    hipLaunchKernelGGL(attn_split_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+    ONIRIS_KLAUNCH(attn_split_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                        (const float*)d.a.split_ws, (bf16*)d.a.out, d.a.lse, d.a.kv_splits, d.a.B, d.a.heads, d.a.Lq, d.a.C);
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }
   const dim3 grid(cdiv(d.a.Lq, split ? 64 : 128), d.a.heads, d.a.B);
   if (split) {
-    if (d.a.mask_mode == 1) hipLaunchKernelGGL((attn_fwd_kernel<1, 2>), grid, dim3(256), 0, stream, d);
-    else hipLaunchKernelGGL((attn_fwd_kernel<2, 2>), grid, dim3(256), 0, stream, d);
+    if (d.a.mask_mode == 1) ONIRIS_KLAUNCH((attn_fwd_kernel<1, 2>), grid, dim3(256), 0, stream, d);
+    else ONIRIS_KLAUNCH((attn_fwd_kernel<2, 2>), grid, dim3(256), 0, stream, d);
   } else {
     switch (d.a.mask_mode) {
-      case 0: hipLaunchKernelGGL((attn_fwd_kernel<0, 1>), grid, dim3(256), 0, stream, d); break;
-      case 1: hipLaunchKernelGGL((attn_fwd_kernel<1, 1>), grid, dim3(256), 0, stream, d); break;
-      default: hipLaunchKernelGGL((attn_fwd_kernel<2, 1>), grid, dim3(256), 0, stream, d); break;
+      case 0: ONIRIS_KLAUNCH((attn_fwd_kernel<0, 1>), grid, dim3(256), 0, stream, d); break;
+      case 1: ONIRIS_KLAUNCH((attn_fwd_kernel<1, 1>), grid, dim3(256), 0, stream, d); break;
+      default: ONIRIS_KLAUNCH((attn_fwd_kernel<2, 1>), grid, dim3(256), 0, stream, d); break;
     }
   }
   ONIRIS_LAUNCH_CHECK();
@@ -1310,13 +1310,13 @@ extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t st
   const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048;
   const dim3 grid(cdiv(d.a.Lq, split ? 64 : 128), d.a.heads, d.a.B);
   if (split) {
-    if (d.a.mask_mode == 1) hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 2>), grid, dim3(256), 0, stream, d);
-    else hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 2>), grid, dim3(256), 0, stream, d);
+    if (d.a.mask_mode == 1) ONIRIS_KLAUNCH((attn_bwd_dq_kernel<1, 2>), grid, dim3(256), 0, stream, d);
+    else ONIRIS_KLAUNCH((attn_bwd_dq_kernel<2, 2>), grid, dim3(256), 0, stream, d);
   } else {
     switch (d.a.mask_mode) {
-      case 0: hipLaunchKernelGGL((attn_bwd_dq_kernel<0, 1>), grid, dim3(256), 0, stream, d); break;
-      case 1: hipLaunchKernelGGL((attn_bwd_dq_kernel<1, 1>), grid, dim3(256), 0, stream, d); break;
-      default: hipLaunchKernelGGL((attn_bwd_dq_kernel<2, 1>), grid, dim3(256), 0, stream, d); break;
+      case 0: ONIRIS_KLAUNCH((attn_bwd_dq_kernel<0, 1>), grid, dim3(256), 0, stream, d); break;
+      case 1: ONIRIS_KLAUNCH((attn_bwd_dq_kernel<1, 1>), grid, dim3(256), 0, stream, d); break;
+      default: ONIRIS_KLAUNCH((attn_bwd_dq_kernel<2, 1>), grid, dim3(256), 0, stream, d); break;
     }
   }
   ONIRIS_LAUNCH_CHECK();
@@ -1358,7 +1358,7 @@ extern "C" int oniris_attn_bwd_dkv(const OnirisAttnArgs* args, oniris_stream_t s
   ONIRIS_LAUNCH_CHECK();
   if (nch > 1) {
     const size_t n8 = (size_t)d.a.B * d.a.Lk * d.a.C / 8;
-    hipLaunchKernelGGL(attn_dkv_reduce_kernel, dim3((unsigned)((2 * n8 + 255) / 256)), dim3(256), 0, stream,
+    ONIRIS_KLAUNCH(attn_dkv_reduce_kernel, dim3((unsigned)((2 * n8 + 255) / 256)), dim3(256), 0, stream,
                        (const float*)d.a.dkv_part, (bf16*)d.a.dk, (bf16*)d.a.dv, n8, nch);
     ONIRIS_LAUNCH_CHECK();
   }
@@ -1371,7 +1371,7 @@ extern "C" int oniris_qkv_norm_rope(const void* qkv, void* q, void* k, void* v, 
   ONIRIS_CHECK_ARG(qkv && q && k && v && cos_t && sin_t && scale_t && n_tokens > 0 && C > 0 && C % 64 == 0 && P > 0 && pos_mod > 0,
                    "qkv_norm_rope: bad arguments");
   const long long nvec = (long long)n_tokens * 3 * C / 64;
-  hipLaunchKernelGGL(qkv_norm_rope_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
+  ONIRIS_KLAUNCH(qkv_norm_rope_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
                      (bf16*)q, (bf16*)k, (bf16*)v, cos_t, sin_t, scale_t, nvec, C, P, pos_mod);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -1386,7 +1386,7 @@ extern "C" int oniris_qkv_norm_rope_eval(const void* qkv, void* q, void* k, void
                    kv_tokens_per_batch > 0 && n_tokens % kv_tokens_per_batch == 0 && n_tokens % 8 == 0 &&
                    kv_batch_stride >= (kv_token_offset + kv_tokens_per_batch) * C, "qkv_norm_rope_eval: bad arguments");
   const long long nvec = (long long)n_tokens * (3 * C / 64);
-  hipLaunchKernelGGL(qkv_norm_rope_eval_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
+  ONIRIS_KLAUNCH(qkv_norm_rope_eval_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)qkv, (bf16*)q, (bf16*)k, (bf16*)v, (bf16*)kr, cos_t, sin_t, scale_t, nvec, C,
                      (long long)kv_tokens_per_batch, (long long)kv_batch_stride, (long long)kv_token_offset, pos);
   ONIRIS_LAUNCH_CHECK();
@@ -1406,7 +1406,7 @@ extern "C" int oniris_qkv_eval(const void* x, const void* w, void* q, void* k, v
                    "qkv_eval: bad KV ring geometry");
   const dim3 grid((unsigned)((n_tokens + 127) / 128), (unsigned)(3 * C / 64));
 #define QKV_EVAL_LAUNCH(KC_)                                                                                              \
-  hipLaunchKernelGGL(qkv_eval_kernel<KC_>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)w, (bf16*)q, (bf16*)k,  \
+  ONIRIS_KLAUNCH(qkv_eval_kernel<KC_>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)w, (bf16*)q, (bf16*)k,  \
                      (bf16*)v, (bf16*)kr, cos_t, sin_t, scale_t, (long long)n_tokens, C, CinP,                             \
                      (long long)kv_tokens_per_batch, (long long)kv_batch_stride, (long long)kv_token_offset, pos)
   if (C % 256 == 0) QKV_EVAL_LAUNCH(256);
@@ -1424,7 +1424,7 @@ extern "C" int oniris_qkv_norm_rope_bwd(const void* qkv, const void* dq, const v
   ONIRIS_CHECK_ARG(qkv && dq && dk && dv && dqkv && cos_t && sin_t && scale_t && n_tokens > 0 && C > 0 && C % 64 == 0 && P > 0 &&
                    pos_mod > 0, "qkv_norm_rope_bwd: bad arguments");
   const long long nvec = (long long)n_tokens * 3 * C / 64;
-  hipLaunchKernelGGL(qkv_norm_rope_bwd_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
+  ONIRIS_KLAUNCH(qkv_norm_rope_bwd_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
                      (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (bf16*)dqkv, cos_t, sin_t, scale_t, nvec, C, P, pos_mod);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -1440,7 +1440,7 @@ extern "C" int oniris_qkv_norm(const void* qkv, void* q, void* k, void* v, int64
                    "qkv_norm: bad KV ring description");
   const long long nvec = (long long)n_tokens * 3 * C / 64;
   const long long nthr = nvec * 8;
-  hipLaunchKernelGGL(qkv_norm_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
+  ONIRIS_KLAUNCH(qkv_norm_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream, (const bf16*)qkv,
                      (bf16*)q, (bf16*)k, (bf16*)v, nvec, C, (long long)kv_tokens_per_batch, (long long)kv_batch_stride,
                      (long long)kv_token_offset);
   ONIRIS_LAUNCH_CHECK();
@@ -1453,7 +1453,7 @@ extern "C" int oniris_qkv_norm_bwd(const void* qkv, const void* dq, const void* 
   ONIRIS_CHECK_ARG(qkv && dq && dk && dv && dqkv && n_tokens > 0 && C > 0 && C % 64 == 0, "qkv_norm_bwd: bad arguments");
   const long long nvec = (long long)n_tokens * 3 * C / 64;
   const long long nthr = nvec * 8;
-  hipLaunchKernelGGL(qkv_norm_bwd_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
+  ONIRIS_KLAUNCH(qkv_norm_bwd_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)qkv, (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (bf16*)dqkv, nvec, C);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -1471,7 +1471,7 @@ extern "C" int oniris_rope(const void* x, void* xr, void* xt, const float* cos_t
   ONIRIS_CHECK_ARG(x_batch_stride == 0 || x_batch_stride >= (int64_t)L * C, "rope: batch stride smaller than a sequence");
   ONIRIS_CHECK_ARG(xr_batch_stride == 0 || xr_batch_stride >= (int64_t)L * C, "rope: output batch stride smaller than a sequence");
   const dim3 grid(cdiv(L, 64), C / 64, B);
-  hipLaunchKernelGGL(rope_kernel, grid, dim3(256), 0, stream, (const bf16*)x, (bf16*)xr, (bf16*)xt, cos_t, sin_t,
+  ONIRIS_KLAUNCH(rope_kernel, grid, dim3(256), 0, stream, (const bf16*)x, (bf16*)xr, (bf16*)xt, cos_t, sin_t,
                      scale_t, mode, L, P, C, C / 64, pos_offset, pos_mod > 0 ? pos_mod : 1,
                      (long long)(x_batch_stride > 0 ? x_batch_stride : (int64_t)L * C),
                      (long long)(xr_batch_stride > 0 ? xr_batch_stride : (int64_t)L * C));
@@ -1485,7 +1485,7 @@ extern "C" int oniris_attn_bwd_prep(const void* dout, const void* out, float* de
   ONIRIS_CHECK_ARG(dout && out && delta && B > 0 && heads > 0 && L > 0 && C == heads * 64, "attn_bwd_prep: bad arguments");
   ONIRIS_CHECK_ARG(!neg || lse, "attn_bwd_prep: the negated row constants need lse");
   const long long nvec = (long long)B * L * heads;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
+  ONIRIS_KLAUNCH(attn_delta_kernel, dim3((unsigned)((nvec * 8 + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)dout, (const bf16*)out, delta, lse, neg, nvec, L, C, heads);
   ONIRIS_LAUNCH_CHECK();
   if (doutt) return oniris_rope(dout, nullptr, doutt, nullptr, nullptr, nullptr, 0, B, L, 1, C, 0, 1, 0, 0, stream_);

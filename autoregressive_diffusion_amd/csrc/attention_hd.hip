@@ -175,7 +175,7 @@ extern "C" int oniris_qkv_norm_hd(const void* qkv, void* q, void* k, void* v, co
   ONIRIS_CHECK_ARG(rope == 0 || (cos_t && sin_t && scale_t), "qkv_norm_hd: rotary tables missing");
   const long long nitem = (long long)n_tokens * 3 * heads;
   const dim3 grid((unsigned)((nitem + 127) / 128));
-  HD_DISPATCH(head_dim, hipLaunchKernelGGL(qkv_norm_hd_kernel<D>, grid, dim3(128), 0, stream, (const bf16*)qkv, (bf16*)q,
+  HD_DISPATCH(head_dim, ONIRIS_KLAUNCH(qkv_norm_hd_kernel<D>, grid, dim3(128), 0, stream, (const bf16*)qkv, (bf16*)q,
                                            (bf16*)k, (bf16*)v, cos_t, sin_t, scale_t, nitem, heads, P, pos_mod, pos_off, rope, seq_frames))
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -192,7 +192,7 @@ extern "C" int oniris_qkv_norm_hd_bwd(const void* qkv, const void* dq, const voi
   ONIRIS_CHECK_ARG(rope == 0 || (cos_t && sin_t && scale_t), "qkv_norm_hd_bwd: rotary tables missing");
   const long long nitem = (long long)n_tokens * 3 * heads;
   const dim3 grid((unsigned)((nitem + 127) / 128));
-  HD_DISPATCH(head_dim, hipLaunchKernelGGL(qkv_norm_hd_bwd_kernel<D>, grid, dim3(128), 0, stream, (const bf16*)qkv,
+  HD_DISPATCH(head_dim, ONIRIS_KLAUNCH(qkv_norm_hd_bwd_kernel<D>, grid, dim3(128), 0, stream, (const bf16*)qkv,
                                            (const bf16*)dq, (const bf16*)dk, (const bf16*)dv, (bf16*)dqkv, cos_t, sin_t,
                                            scale_t, nitem, heads, P, pos_mod, pos_off, rope, seq_frames))
   ONIRIS_LAUNCH_CHECK();
@@ -207,7 +207,7 @@ extern "C" int oniris_rope_hd(const void* x, void* out, const float* cos_t, cons
                    pos_off >= 0 && (mode == 1 || mode == 2) && seq_frames > 0, "rope_hd: bad arguments");
   const long long nitem = (long long)n_tokens * heads;
   const dim3 grid((unsigned)((nitem + 127) / 128));
-  HD_DISPATCH(head_dim, hipLaunchKernelGGL(rope_hd_kernel<D>, grid, dim3(128), 0, stream, (const bf16*)x, (bf16*)out, cos_t,
+  HD_DISPATCH(head_dim, ONIRIS_KLAUNCH(rope_hd_kernel<D>, grid, dim3(128), 0, stream, (const bf16*)x, (bf16*)out, cos_t,
                                            sin_t, scale_t, nitem, heads, P, pos_mod, pos_off, mode, seq_frames))
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;

@@ -45,14 +45,32 @@ void oniris_set_error(const char* fmt, ...);
 // launches through oniris_launch records its OWN begin and end into them (hipExtLaunchKernel: the timestamps of the
 // dispatch itself, what rocprofv3 reports) -- bracketing events on the stream also time the ~2 us of kernel boundary.
 extern thread_local hipEvent_t oniris_prof_ev[2];
+
+// Dispatch census (oniris_census_*, misc.cpp; tests/conftest.py + tests/test_zz_dispatch_coverage.py): while it is on, every
+// kernel launch of the library notes WHICH instantiation went out (the kernel handle, resolved to its demangled name when the
+// list is read) plus a tag for variants that are chosen at run time inside one instantiation (non-temporal output stores).
+// The test suite uses it to prove that what the timed regions of bench.py launch is what the oracle-comparing tests launched.
+extern int oniris_census_on;
+void oniris_census_note(const void* kernel_handle, const char* tag);
+#define ONIRIS_KLAUNCH(kern, grid, block, shmem, stream, ...)                            \
+  do {                                                                                   \
+    if (oniris_census_on) oniris_census_note((const void*)(kern), nullptr);              \
+    hipLaunchKernelGGL(kern, grid, block, shmem, stream, __VA_ARGS__);                   \
+  } while (0)
+
 template <typename K, typename... A>
-static inline void oniris_launch(K kern, dim3 grid, dim3 block, hipStream_t stream, A... args) {
+static inline void oniris_launch_tagged(const char* tag, K kern, dim3 grid, dim3 block, hipStream_t stream, A... args) {
+  if (oniris_census_on) oniris_census_note((const void*)kern, tag);
   if (oniris_prof_ev[0]) {
     hipExtLaunchKernelGGL(kern, grid, block, 0, stream, oniris_prof_ev[0], oniris_prof_ev[1], 0, args...);
     oniris_prof_ev[0] = oniris_prof_ev[1] = nullptr;
   } else {
     hipLaunchKernelGGL(kern, grid, block, 0, stream, args...);
   }
+}
+template <typename K, typename... A>
+static inline void oniris_launch(K kern, dim3 grid, dim3 block, hipStream_t stream, A... args) {
+  oniris_launch_tagged(nullptr, kern, grid, block, stream, args...);
 }
 
 // Streaming loads / stores of the HBM-bound passes (elementwise.hip, gconv_bwd_fused): tensors far larger than the caches are

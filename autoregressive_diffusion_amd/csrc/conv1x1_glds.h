@@ -231,7 +231,7 @@ static int launch_conv1x1_glds(const OnirisConvArgs& a, hipStream_t stream) {
   const long long ntiles = (long long)d.ntt * d.ncob;
   const int ncu = oniris_persistent_wgs();       // one workgroup per CU (minus the CUs reserved for a gradient exchange in flight)
   const long long nblk = ntiles < ncu ? ntiles : ncu;
-  oniris_launch(conv1x1_glds_kernel, dim3((unsigned)nblk), dim3(C1Cfg::NTHR), stream, d);
+  oniris_launch_tagged(d.nt ? "nt-stores" : nullptr, conv1x1_glds_kernel, dim3((unsigned)nblk), dim3(C1Cfg::NTHR), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

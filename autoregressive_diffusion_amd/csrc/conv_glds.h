@@ -526,7 +526,7 @@ static int launch_conv_glds(const OnirisConvArgs& a, hipStream_t stream) {
   const int ncu = oniris_persistent_wgs();       // one workgroup per CU (minus the CUs reserved for a gradient exchange in flight)
   const long long nblk = ntiles < ncu ? ntiles : ncu;
   auto kern = conv_glds_kernel<NT, PW, NW, MT, WC, CTX, RES>;
-  oniris_launch(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), stream, d);
+  oniris_launch_tagged(d.nt ? "nt-stores" : nullptr, kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

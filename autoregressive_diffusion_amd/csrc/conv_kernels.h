@@ -517,11 +517,11 @@ static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
     if (ks > 1) { d.ksplit = (int)ks; nblk *= ks; }
   }
   auto kern = conv_fwd_kernel<S, TAPS, CK, NT, HAS_CTX, PW, NW>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
+  ONIRIS_KLAUNCH(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
   if (d.ksplit > 1) {
     ONIRIS_LAUNCH_CHECK();
     d.reduce = 1;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(ntile * NW)), dim3(64), 0, stream, d);
+    ONIRIS_KLAUNCH(kern, dim3((unsigned)(ntile * NW)), dim3(64), 0, stream, d);
   }
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;

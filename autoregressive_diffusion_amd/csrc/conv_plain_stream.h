@@ -283,7 +283,7 @@ static int launch_conv_plain_stream(const OnirisConvArgs& a, hipStream_t stream)
   d.seglen = cdiv(d.nfr, nseg);
   d.nseg = cdiv(d.nfr, d.seglen);
   d.nt = (long long)d.nfr * a.H * a.W * a.Cout * 2 >= oniris_ew_nt_bytes();
-  oniris_launch(conv_plain_stream_kernel, dim3(tiles * d.nseg), dim3(256), stream, d);
+  oniris_launch_tagged(d.nt ? "nt-stores" : nullptr, conv_plain_stream_kernel, dim3(tiles * d.nseg), dim3(256), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -401,8 +401,8 @@ static int launch_conv_stream(const OnirisConvArgs& a, hipStream_t stream) {
   d.seglen = cdiv(a.T, nseg);
   d.nseg = cdiv(a.T, d.seglen);
   const bool alias = a.ctx == a.x && a.ctx_bstride == 2 * a.T && d.dir == 1;
-  if (alias) oniris_launch(conv_stream_kernel<true>, dim3(units * d.nseg), dim3(256), stream, d);
-  else oniris_launch(conv_stream_kernel<false>, dim3(units * d.nseg), dim3(256), stream, d);
+  if (alias) oniris_launch_tagged(d.nt ? "nt-stores" : nullptr, conv_stream_kernel<true>, dim3(units * d.nseg), dim3(256), stream, d);
+  else oniris_launch_tagged(d.nt ? "nt-stores" : nullptr, conv_stream_kernel<false>, dim3(units * d.nseg), dim3(256), stream, d);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -166,7 +166,7 @@ extern "C" int oniris_act_fwd(const void* x, const void* skip, void* xo, void* a
   const long long nthr = npix * (C / 8);
   const dim3 grid((unsigned)((nthr + 255) / 256));
   const bool nt = (long long)npix * C * 2 >= oniris_ew_nt_bytes();
-#define ACT_FWD_LAUNCH(NORM_, NT_) hipLaunchKernelGGL((act_fwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2, resample, Ho, Wo)
+#define ACT_FWD_LAUNCH(NORM_, NT_) ONIRIS_KLAUNCH((act_fwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)skip, (bf16*)xo, (bf16*)a, sden, (long long)npix, C1, C2, w1, w2, resample, Ho, Wo)
   if (norm) { if (nt) ACT_FWD_LAUNCH(true, true); else ACT_FWD_LAUNCH(true, false); }
   else { if (nt) ACT_FWD_LAUNCH(false, true); else ACT_FWD_LAUNCH(false, false); }
 #undef ACT_FWD_LAUNCH
@@ -185,7 +185,7 @@ extern "C" int oniris_act_bwd(const void* da, const void* dxo, const void* xo, c
   const long long nthr = npix * (C / 8);
   const dim3 grid((unsigned)((nthr + 255) / 256));
   const bool nt = (long long)npix * C * 2 >= oniris_ew_nt_bytes();
-#define ACT_BWD_LAUNCH(NORM_, NT_) hipLaunchKernelGGL((act_bwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2, dxo_scale)
+#define ACT_BWD_LAUNCH(NORM_, NT_) ONIRIS_KLAUNCH((act_bwd_kernel<NORM_, NT_>), grid, dim3(256), 0, stream, (const bf16*)da, (const bf16*)dxo, (const bf16*)xo, sden, (bf16*)dx, (bf16*)dskip, (const bf16*)dadd, (long long)npix, C1, C2, w1, w2, dxo_scale)
   if (norm) { if (nt) ACT_BWD_LAUNCH(true, true); else ACT_BWD_LAUNCH(true, false); }
   else { if (nt) ACT_BWD_LAUNCH(false, true); else ACT_BWD_LAUNCH(false, false); }
 #undef ACT_BWD_LAUNCH
@@ -268,14 +268,14 @@ extern "C" int oniris_emb_silu_bwd(const void* du, const void* y, const float* c
   while (slices < 16 && P / (slices * 2) >= npl * 4 && (long long)N * slices < tgt) slices *= 2;
   const int ppb = cdiv(P, slices);
   const size_t ndc = (size_t)N * C;
-  if (!dc_is_zero) hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
+  if (!dc_is_zero) ONIRIS_KLAUNCH(zero_f32_kernel, dim3((unsigned)((ndc + 255) / 256)), dim3(256), 0, stream, dc, ndc);
   const int cp = c_pitch > 0 ? c_pitch : C;
   ONIRIS_CHECK_ARG(cp >= C && cp % 4 == 0, "emb_silu_bwd: c_pitch must be a multiple of 4 and >= C");
   if ((long long)N * P * C * 2 >= oniris_ew_nt_bytes())
-    hipLaunchKernelGGL(emb_silu_bwd_kernel<true>, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
+    ONIRIS_KLAUNCH(emb_silu_bwd_kernel<true>, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
                        (bf16*)dy, dc, P, C, ppb, cp);
   else
-    hipLaunchKernelGGL(emb_silu_bwd_kernel<false>, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
+    ONIRIS_KLAUNCH(emb_silu_bwd_kernel<false>, dim3(N, slices), dim3(256), 0, stream, (const bf16*)du, (const bf16*)y, c,
                        (bf16*)dy, dc, P, C, ppb, cp);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -313,10 +313,10 @@ extern "C" int oniris_mpsum_bwd(const void* g, const void* out, void* dres, void
   size_t nb = (n8 + 255) / 256;
   if (nb > 8192) nb = 8192;
   if (numel * 2 >= oniris_ew_nt_bytes())
-    hipLaunchKernelGGL(mpsum_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
+    ONIRIS_KLAUNCH(mpsum_bwd_kernel<true>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
                        (bf16*)dres, (bf16*)dv, n8, ta, tb, clip);
   else
-    hipLaunchKernelGGL(mpsum_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
+    ONIRIS_KLAUNCH(mpsum_bwd_kernel<false>, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)g, (const bf16*)out,
                        (bf16*)dres, (bf16*)dv, n8, ta, tb, clip);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -347,7 +347,7 @@ extern "C" int oniris_mpsum_mask(void* g, const void* out, int64_t numel, float 
   const size_t n8 = (size_t)numel / 8;
   size_t nb = (n8 + 255) / 256;
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(mpsum_mask_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (bf16*)g, (const bf16*)out, n8, clip,
+  ONIRIS_KLAUNCH(mpsum_mask_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (bf16*)g, (const bf16*)out, n8, clip,
                      (const int*)clip_flag);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -408,7 +408,7 @@ extern "C" int oniris_resample(const void* in, void* out, const void* add, int64
   const long long n8 = npix_out * (C / 8);
   long long nb = (n8 + 255) / 256;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out, (const bf16*)add, n8,
+  ONIRIS_KLAUNCH(resample_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out, (const bf16*)add, n8,
                      H, W, C, mode, scale);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -492,7 +492,7 @@ extern "C" int oniris_resample_filter(const void* in, void* out, const void* add
   const long long n8 = npix_out * (C / 8);
   long long nb = (n8 + 255) / 256;
   if (nb > 16384) nb = 16384;
-  hipLaunchKernelGGL(resample_filter_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out,
+  ONIRIS_KLAUNCH(resample_filter_kernel, dim3((unsigned)nb), dim3(256), 0, stream, (const bf16*)in, (bf16*)out,
                      (const bf16*)add, n8, H, W, C, mode, scale, tp);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -592,7 +592,7 @@ extern "C" int oniris_dart_input(const float* images, const float* noise, const 
   const int HW = H * W;
   int gx = cdiv(HW, 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(dart_input_kernel, dim3(gx, B * S * T), dim3(256), 0, stream, images, noise, sigma, (bf16*)xcl, S, T, C,
+  ONIRIS_KLAUNCH(dart_input_kernel, dim3(gx, B * S * T), dim3(256), 0, stream, images, noise, sigma, (bf16*)xcl, S, T, C,
                      HW, sigma_data, c_noise_out, cpad);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -604,7 +604,7 @@ extern "C" int oniris_dart_loss(const void* F, const float* images, const float*
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(F && images && noise && sigma && out_gain && losses && B > 0 && (S == 1 || S == 2) && T > 0 && C > 0 &&
                    C <= 8 && H > 0 && W > 0, "dart_loss: bad arguments");
-  hipLaunchKernelGGL(dart_loss_kernel<false>, dim3(B * S * T), dim3(1024), 0, stream, (const bf16*)F, images, noise, sigma,
+  ONIRIS_KLAUNCH(dart_loss_kernel<false>, dim3(B * S * T), dim3(1024), 0, stream, (const bf16*)F, images, noise, sigma,
                      out_gain, (const float*)nullptr, losses, (bf16*)nullptr, (float*)nullptr, S, T, C, H * W, sigma_data);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -616,7 +616,7 @@ extern "C" int oniris_dart_loss_bwd(const void* F, const float* images, const fl
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(F && images && noise && sigma && out_gain && dlosses && dF && dgain_part && B > 0 && (S == 1 || S == 2) &&
                    T > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "dart_loss_bwd: bad arguments");
-  hipLaunchKernelGGL(dart_loss_kernel<true>, dim3(B * S * T), dim3(1024), 0, stream, (const bf16*)F, images, noise, sigma,
+  ONIRIS_KLAUNCH(dart_loss_kernel<true>, dim3(B * S * T), dim3(1024), 0, stream, (const bf16*)F, images, noise, sigma,
                      out_gain, dlosses, (float*)nullptr, (bf16*)dF, dgain_part, S, T, C, H * W, sigma_data);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -674,7 +674,7 @@ extern "C" int oniris_loss_tail(const float* mse, const float* sigma, const floa
   ONIRIS_CHECK_ARG(mse && sigma && coef && out && dcoef && B > 0 && T > 0 && sig_pitch >= sig_off + T && sig_off >= 0 &&
                    nterms >= 1 && sigma_data > 0.f, "loss_tail: bad arguments");
   ONIRIS_CHECK_ARG(!ring_sigma || (ring_loss && ring_pos && count && cap > 0), "loss_tail: incomplete history ring");
-  hipLaunchKernelGGL(loss_tail_kernel, dim3(1), dim3(256), 0, stream, mse, sigma, coef, out, dcoef, ring_sigma, ring_loss,
+  ONIRIS_KLAUNCH(loss_tail_kernel, dim3(1), dim3(256), 0, stream, mse, sigma, coef, out, dcoef, ring_sigma, ring_loss,
                      ring_pos, count, cap, B * T, T, sig_pitch, sig_off, nterms, sigma_data);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -707,7 +707,7 @@ extern "C" int oniris_precond_out(const void* F, const float* x, const float* si
   ONIRIS_CHECK_ARG(F && x && sigma && out_gain && D && N > 0 && C > 0 && C <= 8 && H > 0 && W > 0, "precond_out: bad arguments");
   int gx = cdiv(H * W, 256);
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(precond_out_kernel, dim3(gx, N), dim3(256), 0, stream, (const bf16*)F, x, sigma, out_gain, D, C, H * W,
+  ONIRIS_KLAUNCH(precond_out_kernel, dim3(gx, N), dim3(256), 0, stream, (const bf16*)F, x, sigma, out_gain, D, C, H * W,
                      sigma_data);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -748,7 +748,7 @@ extern "C" int oniris_sampler_update(int mode, float* x_hat, const float* x_pred
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG((mode == 0 || mode == 1) && x_hat && x_pred && d_io && x_out && n > 0 && t_a != 0.f && (mode == 0 || x_aux) &&
                    nsig >= 0 && (size_t)nsig <= n, "sampler_update: bad arguments");
-  hipLaunchKernelGGL(sampler_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mode, x_hat, x_pred, d_io,
+  ONIRIS_KLAUNCH(sampler_update_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, mode, x_hat, x_pred, d_io,
                      x_aux, x_out, n, t_a, dt, sigma_buf, nsig, sigma_next);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -779,7 +779,7 @@ extern "C" int oniris_gates(const float* c_noise, const float* params, const int
                             int N, int T, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(c_noise && params && ca && cb && L > 0 && N > 0 && T > 0, "gates: bad arguments");
-  hipLaunchKernelGGL(gates_kernel, dim3(cdiv(N, 256) > 64 ? 64 : cdiv(N, 256), L), dim3(256), 0, stream, c_noise, params,
+  ONIRIS_KLAUNCH(gates_kernel, dim3(cdiv(N, 256) > 64 ? 64 : cdiv(N, 256), L), dim3(256), 0, stream, c_noise, params,
                      (const int*)nctx, ca, cb, N, T);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -828,7 +828,7 @@ extern "C" int oniris_embed_eval(const float* c_noise, const int64_t* labels, co
   ONIRIS_CHECK_ARG(c_noise && freqs && phases && w_noise && emb && N > 0 && cnoise > 0 && cnoise <= 512 && cemb > 0,
                    "embed_eval: bad arguments (cnoise <= 512)");
   ONIRIS_CHECK_ARG(!labels || !w_label || label_dim > 0, "embed_eval: label_dim missing");
-  hipLaunchKernelGGL(embed_eval_kernel, dim3(N), dim3(256), 0, stream, c_noise, (const long long*)labels, freqs, phases,
+  ONIRIS_KLAUNCH(embed_eval_kernel, dim3(N), dim3(256), 0, stream, c_noise, (const long long*)labels, freqs, phases,
                      w_noise, w_label, (bf16*)emb, cnoise, cemb, label_dim);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -885,7 +885,7 @@ extern "C" int oniris_gates_bwd(const float* c_noise, const float* params, const
                                 const float* dcb, float* dparams, int L, int N, int T, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(c_noise && params && dca && dcb && dparams && L > 0 && N > 0 && T > 0, "gates_bwd: bad arguments");
-  hipLaunchKernelGGL(gates_bwd_kernel, dim3(L), dim3(256), 0, stream, c_noise, params, (const int*)nctx, dca, dcb, dparams, N, T);
+  ONIRIS_KLAUNCH(gates_bwd_kernel, dim3(L), dim3(256), 0, stream, c_noise, params, (const int*)nctx, dca, dcb, dparams, N, T);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -933,7 +933,7 @@ extern "C" int oniris_emb_scale(const void* c_all, const float* gain, const int3
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(c_all && gain && seg && c && N > 0 && Ctot > 0, "emb_scale: bad arguments");
   const size_t total = (size_t)N * Ctot;
-  hipLaunchKernelGGL(emb_scale_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0, stream,
+  ONIRIS_KLAUNCH(emb_scale_kernel, dim3((unsigned)((total + 255) / 256 > 2048 ? 2048 : (total + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)c_all, gain, (const int*)seg, c, N, Ctot);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -943,7 +943,7 @@ extern "C" int oniris_emb_scale_bwd(const float* dc, const void* c_all, const fl
                                     float* dgain_part, int N, int Ctot, int K, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(dc && c_all && gain && start && dc_all && dgain_part && N > 0 && Ctot > 0 && K > 0, "emb_scale_bwd: bad arguments");
-  hipLaunchKernelGGL(emb_scale_bwd_kernel, dim3(K, EMB_BWD_CHUNKS), dim3(256), 0, stream, dc, (const bf16*)c_all, gain,
+  ONIRIS_KLAUNCH(emb_scale_bwd_kernel, dim3(K, EMB_BWD_CHUNKS), dim3(256), 0, stream, dc, (const bf16*)c_all, gain,
                      (const int*)start, (bf16*)dc_all, dgain_part, N, Ctot);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -969,7 +969,7 @@ extern "C" int oniris_embed_pre(const float* c_noise, const int64_t* labels, con
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(c_noise && freqs && phases && four && N > 0 && cnoise > 0 && cnoiseP >= cnoise, "embed_pre: bad arguments");
   ONIRIS_CHECK_ARG(!onehot || (labels && label_dim > 0 && labelP >= label_dim), "embed_pre: labels missing");
-  hipLaunchKernelGGL(embed_pre_kernel, dim3(N), dim3(64), 0, stream, c_noise, (const long long*)labels, freqs, phases,
+  ONIRIS_KLAUNCH(embed_pre_kernel, dim3(N), dim3(64), 0, stream, c_noise, (const long long*)labels, freqs, phases,
                      (bf16*)four, (bf16*)onehot, N, cnoise, cnoiseP, label_dim, labelP);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -1003,7 +1003,7 @@ __global__ void embed_post_bwd_kernel(const bf16* __restrict__ demb, const bf16*
 extern "C" int oniris_embed_post(const void* e1, const void* e2, void* emb, size_t n, float t, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(e1 && emb && n > 0, "embed_post: bad arguments");
-  hipLaunchKernelGGL(embed_post_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream,
+  ONIRIS_KLAUNCH(embed_post_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)e1, (const bf16*)e2, (bf16*)emb, n, t);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -1013,7 +1013,7 @@ extern "C" int oniris_embed_post_bwd(const void* demb, const void* e1, const voi
                                      oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(demb && e1 && de1 && n > 0 && (!e2 || de2), "embed_post_bwd: bad arguments");
-  hipLaunchKernelGGL(embed_post_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream,
+  ONIRIS_KLAUNCH(embed_post_bwd_kernel, dim3((unsigned)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0, stream,
                      (const bf16*)demb, (const bf16*)e1, (const bf16*)e2, (bf16*)de1, (bf16*)de2, n, t);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;

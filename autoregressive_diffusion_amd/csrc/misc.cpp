@@ -4,7 +4,12 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
 #include <vector>
+#include <cxxabi.h>
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include "common.h"
 #include "../../include/oniris.h"
@@ -32,16 +37,80 @@ extern "C" int oniris_profile_disarm(void) {          // 1: the pair was still a
   oniris_prof_ev[0] = oniris_prof_ev[1] = nullptr;
   return armed;
 }
-extern "C" int oniris_abi_version(void) { return 13; }
+extern "C" int oniris_abi_version(void) { return 14; }
 
+// Size from which a tensor is streamed with non-temporal accesses.  ONIRIS_EW_NT_MB (default 96; <= 0: never) seeds it;
+// oniris_set_ew_nt_bytes replaces it at run time (the tests force every NT instantiation onto small oracle-sized tensors).
+static long long g_ew_nt_bytes = -1;
 long long oniris_ew_nt_bytes(void) {
-  static long long v = -1;
-  if (v < 0) {
+  if (g_ew_nt_bytes < 0) {
     const char* e = getenv("ONIRIS_EW_NT_MB");
     const long long mb = e ? atoll(e) : 96;
-    v = mb <= 0 ? (1LL << 62) : mb * (1LL << 20);          // 0 / negative: never
+    g_ew_nt_bytes = mb <= 0 ? (1LL << 62) : mb * (1LL << 20);          // 0 / negative: never
   }
-  return v;
+  return g_ew_nt_bytes;
+}
+extern "C" long long oniris_set_ew_nt_bytes(long long bytes) {      // returns the previous threshold; bytes < 0: "never"
+  const long long old = oniris_ew_nt_bytes();
+  g_ew_nt_bytes = bytes < 0 ? (1LL << 62) : bytes;
+  return old;
+}
+
+// ---- dispatch census (common.h): (kernel handle, tag) -> launches
+int oniris_census_on = 0;
+static std::mutex g_census_mu;
+static std::map<std::pair<const void*, std::string>, long long> g_census;
+void oniris_census_note(const void* h, const char* tag) {
+  std::lock_guard<std::mutex> lock(g_census_mu);
+  ++g_census[std::make_pair(h, std::string(tag ? tag : ""))];
+}
+extern "C" int oniris_census(int on) {                 // 1: clear the list and start noting, 0: stop (the list stays readable)
+  std::lock_guard<std::mutex> lock(g_census_mu);
+  if (on) g_census.clear();
+  oniris_census_on = on ? 1 : 0;
+  return ONIRIS_OK;
+}
+static std::string census_name(const void* h) {
+  const char* raw = hipKernelNameRefByPtr(h, nullptr);
+  Dl_info info;
+  if ((!raw || !*raw) && dladdr(h, &info) && info.dli_sname) raw = info.dli_sname;
+  (void)hipGetLastError();
+  if (!raw || !*raw) {
+    char buf[32];
+    snprintf(buf, sizeof(buf), "kernel@%p", h);
+    return buf;
+  }
+  int status = 0;
+  char* dem = abi::__cxa_demangle(raw, nullptr, nullptr, &status);
+  std::string name = (status == 0 && dem) ? dem : raw;
+  free(dem);
+  const size_t paren = name.rfind('(');                 // "void k<..>(Args)" -> "k<..>"
+  if (paren != std::string::npos && name.back() == ')') name.resize(paren);
+  if (name.rfind("void ", 0) == 0) name.erase(0, 5);
+  const std::string stub = "__device_stub__";
+  const size_t at = name.find(stub);
+  if (at != std::string::npos) name.erase(at, stub.size());
+  return name;
+}
+extern "C" long long oniris_census_read(char* buf, long long cap) {   // "<launches>\t<kernel>[ [tag]]\n" per entry; returns the bytes needed
+  std::map<std::string, long long> out;
+  {
+    std::lock_guard<std::mutex> lock(g_census_mu);
+    for (const auto& kv : g_census) {
+      std::string key = census_name(kv.first.first);
+      if (!kv.first.second.empty()) key += " [" + kv.first.second + "]";
+      out[key] += kv.second;
+    }
+  }
+  std::string text;
+  for (const auto& kv : out) text += std::to_string(kv.second) + "\t" + kv.first + "\n";
+  const long long need = (long long)text.size() + 1;
+  if (buf && cap > 0) {
+    const long long n = need <= cap ? need - 1 : cap - 1;
+    memcpy(buf, text.data(), (size_t)n);
+    buf[n] = 0;
+  }
+  return need;
 }
 
 int oniris_cu_reserve = 0;

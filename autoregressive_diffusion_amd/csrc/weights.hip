@@ -258,9 +258,9 @@ extern "C" int oniris_weight_prep(const OnirisWeightDesc* descs_dev, int ndesc, 
                                   int training, oniris_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   ONIRIS_CHECK_ARG(descs_dev && ndesc > 0 && total_rows > 0 && total_tiles > 0, "weight_prep: bad arguments");
-  hipLaunchKernelGGL(weight_prep_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc, training);
+  ONIRIS_KLAUNCH(weight_prep_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc, training);
   ONIRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(weight_wb_kernel, dim3(total_tiles, 18), dim3(256), 0, stream, descs_dev, ndesc);
+  ONIRIS_KLAUNCH(weight_wb_kernel, dim3(total_tiles, 18), dim3(256), 0, stream, descs_dev, ndesc);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -270,7 +270,7 @@ extern "C" int oniris_weight_bwd(const OnirisWeightDesc* descs_dev, int ndesc, i
   ONIRIS_CHECK_ARG(descs_dev && ndesc > 0 && total_rows > 0, "weight_bwd: bad arguments");
   static int chunk_max_nsp = -1;          // (ONIRIS_WBWD_CHUNK_NSP: A/B knob of the transposing form's slab-count limit)
   if (chunk_max_nsp < 0) { const char* e = getenv("ONIRIS_WBWD_CHUNK_NSP"); chunk_max_nsp = e ? atoi(e) : 1 << 30; }
-  hipLaunchKernelGGL(weight_bwd_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc, chunk_max_nsp);
+  ONIRIS_KLAUNCH(weight_bwd_kernel, dim3(total_rows), dim3(256), 0, stream, descs_dev, ndesc, chunk_max_nsp);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -347,7 +347,7 @@ static int launch_adamw(float* p, const float* g, float* m, float* v, size_t n, 
   size_t nb = (n / 4 + 255) / 256;
   if (nb > 4096) nb = 4096;
   if (nb == 0) nb = 1;
-  hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
+  ONIRIS_KLAUNCH(adamw_kernel, dim3((unsigned)nb), dim3(256), 0, stream, p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, bc1, bc2, grad_scale, gnorm_sq, max_norm, ema0, w0, ema1, w1);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
@@ -397,9 +397,9 @@ extern "C" int oniris_sqnorm(const float* g, size_t n, float* out, oniris_stream
   size_t nb = (n / 4 + 255) / 256;
   if (nb > ONIRIS_SQNORM_WS) nb = ONIRIS_SQNORM_WS;
   if (nb == 0) nb = 1;
-  hipLaunchKernelGGL(sqnorm_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g, n, out + 1);
+  ONIRIS_KLAUNCH(sqnorm_partial_kernel, dim3((unsigned)nb), dim3(256), 0, stream, g, n, out + 1);
   ONIRIS_LAUNCH_CHECK();
-  hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)(out + 1), (int)nb, out);
+  ONIRIS_KLAUNCH(sqnorm_final_kernel, dim3(1), dim3(256), 0, stream, (const float*)(out + 1), (int)nb, out);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }
@@ -614,7 +614,7 @@ extern "C" int oniris_gconv_bwd_fused(int mode, const void* g, const void* raw, 
   const int csp = cscale_pitch > 0 ? cscale_pitch : C;
   ONIRIS_CHECK_ARG(csp >= C && csp % 4 == 0, "gconv_bwd_fused: cscale_pitch must be a multiple of 4 and >= C");
   const bool nt = 2LL * B * T * P * C * 2 >= oniris_ew_nt_bytes();       // (the gradient tensor: both slots)
-#define GCONV_BWD_LAUNCH(MODE_, NT_, NTH_, FLAG_, CAS_) hipLaunchKernelGGL((gconv_bwd_fused_kernel<MODE_, NT_>), dim3(B * T, slices), dim3(NTH_), 0, stream, (const bf16*)g, \
+#define GCONV_BWD_LAUNCH(MODE_, NT_, NTH_, FLAG_, CAS_) ONIRIS_KLAUNCH((gconv_bwd_fused_kernel<MODE_, NT_>), dim3(B * T, slices), dim3(NTH_), 0, stream, (const bf16*)g, \
                        (const bf16*)raw, (const bf16*)y3, coef_own, coef_ctx, cscale, (const bf16*)xo, (bf16*)dout, \
                        (bf16*)dres, (bf16*)dy3, d_coef_own, d_coef_ctx, d_cscale, T, P, C, ta, tb, clip, ppb, csp, FLAG_, CAS_)
   if (mode == 1) { if (nt) GCONV_BWD_LAUNCH(1, true, nth, nullptr, nullptr); else GCONV_BWD_LAUNCH(1, false, nth, nullptr, nullptr); }
@@ -633,7 +633,7 @@ extern "C" int oniris_gconv_bwd_prep(const void* dout, const void* out, const vo
                    frame_elems > 0 && frame_elems % 8 == 0, "gconv_bwd_prep: bad arguments");
   int slices = 1;                                    // (d_coef_own / d_coef_ctx are ACCUMULATED: zero on entry)
   while (slices < 16 && (long long)B * T * slices < 1024 && frame_elems / (slices * 2) >= 256 * 8 * 2) slices *= 2;
-  hipLaunchKernelGGL(gconv_bwd_prep_kernel, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)out,
+  ONIRIS_KLAUNCH(gconv_bwd_prep_kernel, dim3(B * T, slices), dim3(256), 0, stream, (const bf16*)dout, (const bf16*)out,
                      (const bf16*)y3, coef_own, coef_ctx, S1, S2, (bf16*)dy3, S, T, (size_t)frame_elems);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;

@@ -225,6 +225,41 @@ def _s3_client():
     return boto3.client("s3")
 
 
+def _numpy_safe_globals():
+    """The numpy reconstructors a checkpoint's `kwargs` may need: scalars (np.float64 mean / std of a VAE, np.int64 sizes),
+    small ndarrays and their dtype objects.  Data-only callables: allow-listing them does not open the pickle machinery."""
+    import numpy as np
+    core = getattr(np, "_core", None) or np.core
+    allow = [core.multiarray.scalar, core.multiarray._reconstruct, np.dtype, np.ndarray]
+    dtypes = getattr(np, "dtypes", None)
+    if dtypes is not None:
+        allow += [getattr(dtypes, n) for n in dir(dtypes) if n.endswith("DType")]
+    return allow
+
+
+def _load_checkpoint_file(path):
+    """{"state_dict": tensors, "kwargs": constructor arguments} (reference utils.py:15-64).  The reference loads with
+    weights_only=False (utils.py:59: arbitrary code execution from a downloaded file); nothing in the format needs that, so:
+    (1) the restricted unpickler; (2) if a constructor argument is a numpy scalar / array (statistics passed to a VAE's
+    constructor end up in `kwargs` as they are), the restricted unpickler again with numpy's data reconstructors allow-listed;
+    (3) anything else is refused with a message that names the opt-in: ONIRIS_TRUST_CHECKPOINT=1 loads like the reference."""
+    import os
+    import pickle
+    if os.environ.get("ONIRIS_TRUST_CHECKPOINT") == "1":
+        return torch.load(path, weights_only=False)
+    try:
+        return torch.load(path, weights_only=True)
+    except pickle.UnpicklingError as first:
+        try:
+            with torch.serialization.safe_globals(_numpy_safe_globals()):
+                return torch.load(path, weights_only=True)
+        except pickle.UnpicklingError:
+            raise pickle.UnpicklingError(
+                f"{path}: the checkpoint holds objects beyond tensors, plain Python values and numpy scalars / arrays, which the "
+                "restricted loader refuses.  If you trust the file, set ONIRIS_TRUST_CHECKPOINT=1 to load it the way the reference "
+                f"does (torch.load(weights_only=False), edm2/utils.py:59).  First refusal: {str(first).splitlines()[0]}") from first
+
+
 class BetterModule(nn.Module):
     """save_to_state_dict / from_pretrained with the reference's {"state_dict", "kwargs"} file format (utils.py:13-72): local
     paths, or s3://bucket/key URLs through boto3 like the reference (uploaded from a temporary file; downloads are kept under
@@ -262,9 +297,7 @@ class BetterModule(nn.Module):
                 if not os.path.exists(local):
                     _s3_client().download_file(bucket, key, local)
                 checkpoint = local
-            # {"state_dict": tensors, "kwargs": plain constructor arguments}: nothing in the format needs the pickle machinery
-            # (the reference loads with weights_only=False, utils.py:59 -- arbitrary code execution from a downloaded file)
-            checkpoint = torch.load(checkpoint, weights_only=True)
+            checkpoint = _load_checkpoint_file(checkpoint)
         model = cls(**checkpoint["kwargs"])
         model.load_state_dict(checkpoint["state_dict"])
         return model

@@ -124,6 +124,31 @@ if int(__import__("os").environ.get("ONIRIS_COMM_CUS_ALWAYS", "0")) > 0:
     set_cu_reserve(int(__import__("os").environ["ONIRIS_COMM_CUS_ALWAYS"]))
 
 
+def set_ew_nt_bytes(nbytes):
+    """Size from which tensors are streamed with non-temporal accesses (oniris_set_ew_nt_bytes; default 96 MiB / ONIRIS_EW_NT_MB;
+    negative: never).  Returns the previous threshold.  The arithmetic does not depend on it; tests/ sets 0 so that the NT
+    instantiations the B = 8 bench launches run on oracle-sized tensors."""
+    return int(lib.oniris_set_ew_nt_bytes(int(nbytes)))
+
+
+def census_start():
+    """Start noting every kernel launch of the library (include/oniris.h: dispatch census)."""
+    check(lib.oniris_census(1), "census")
+
+
+def census_stop():
+    """Stop the census; returns {'kernel instantiation[ [tag]]': launches}."""
+    check(lib.oniris_census(0), "census")
+    need = int(lib.oniris_census_read(None, 0))
+    buf = ctypes.create_string_buffer(need)
+    lib.oniris_census_read(buf, need)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        n, name = line.split("\t", 1)
+        out[name] = out.get(name, 0) + int(n)
+    return out
+
+
 def attn_schedule(weights, n_pairs, device, n_wg=None):
     """Device copy of the static balanced schedule (oniris_attn_schedule) of n_pairs x len(weights) work items over
     the persistent workgroups (one per CU); cached per (weights, pairs, device).  Returns (tensor [n_wg][slots], n_wg,

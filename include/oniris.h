@@ -4,7 +4,9 @@
  * edm2/networks_edm2.py, edm2/conv.py and edm2/attention/.  Each entry point below names the reference call
  * site(s) it replaces (file:line relative to the reference root).  Conventions:
  *   - plain pointers and sizes only; every pointer is DEVICE memory unless marked [host];
- *   - the caller allocates every buffer; no hidden allocation, no stream synchronisation, no global state;
+ *   - the caller allocates every buffer; no hidden allocation, no stream synchronisation; process-wide mutable state is
+ *     limited to three host-side knobs, each named where it is declared: oniris_set_cu_reserve (CUs left to RCCL),
+ *     oniris_set_ew_nt_bytes (non-temporal threshold) and the diagnostic dispatch census (oniris_census);
  *   - returns 0 (ONIRIS_OK) or a negative code; oniris_last_error() gives a thread-local message;
  *   - activations are channels-last bf16: a frame-slot tensor is [N][H][W][C] (C % 16 == 0 except outputs);
  *     frame-slot index n = b*(S*T) + s*T + t  (S = 2 clean|noised in training -- the reference's '(b s t)'
@@ -23,7 +25,7 @@ extern "C" {
 typedef void* oniris_stream_t;
 
 const char* oniris_last_error(void);
-int oniris_abi_version(void);   /* 13.  12 -> 13: oniris_dart_input(+ cpad: the packed input is 32 channels wide in the product, so that the stem conv runs on the
+int oniris_abi_version(void);   /* 14.  13 -> 14: oniris_set_ew_nt_bytes, oniris_census / oniris_census_read (diagnostics; no signature changed); 12 -> 13: oniris_dart_input(+ cpad: the packed input is 32 channels wide in the product, so that the stem conv runs on the
                                  * streaming kernels of the 32-channel level); 11 -> 12: oniris_set_cu_reserve; 10 -> 11: OnirisConvArgs.ctx_prod / ctx_prod_mode (appended fields); 9 -> 10: OnirisConvArgs.clip_flag,
                                  * oniris_gconv_bwd_fused(+ clip_flag, coef_own_scaled), oniris_qkv_norm_hd / _hd_bwd / oniris_rope_hd       */
 /* Measurement aid: arm a pair of HIP events (hipEvent_t created with timing); the next MFMA conv / weight-gradient /
@@ -38,6 +40,19 @@ int oniris_profile_disarm(void);
  * overlapping backward, cs_train.py:53-54,108-114).  Process-wide, host-side, takes effect at the next launch; k is rounded
  * up to a multiple of 8 (one CU per XCD).  Returns the previous value, or a negative error code.                        */
 int oniris_set_cu_reserve(int k);
+/* Size in bytes from which the single-pass kernels and the conv output stores stream a tensor with non-temporal accesses
+ * (default 96 MiB, or ONIRIS_EW_NT_MB at first use; bytes < 0: never).  Process-wide, host-side, takes effect at the next
+ * launch; returns the previous threshold.  The results do not depend on it (same arithmetic, other cache policy): the test
+ * suite sets 0 to put every non-temporal instantiation under the oracle on oracle-sized tensors.                       */
+long long oniris_set_ew_nt_bytes(long long bytes);
+/* Dispatch census (diagnostic).  oniris_census(1) clears the list and starts noting every kernel launch of this library;
+ * oniris_census(0) stops.  oniris_census_read writes one line per distinct launch kind, "<launches>\t<kernel instantiation>
+ * [ [tag]]\n" (demangled name with its template arguments; the tag marks variants picked at run time inside one
+ * instantiation, e.g. "nt-stores"), NUL-terminated, truncated to cap; returns the bytes needed (call with NULL, 0 first).
+ * tests/test_zz_dispatch_coverage.py: the set the bench's timed regions launch must be a subset of the set the
+ * oracle-comparing tests launched.                                                                                        */
+int oniris_census(int on);
+long long oniris_census_read(char* buf /* [host] */, long long cap);
 /* sizeof(OnirisWeightDesc, OnirisConvArgs, OnirisWgradArgs, OnirisAttnArgs) for binding self-checks */
 int oniris_struct_sizes(int32_t* out4 /* [host] */);
 

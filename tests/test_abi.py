@@ -5,6 +5,7 @@ import os
 import re
 import numpy as np
 import pytest
+import sys
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ def test_every_declared_symbol_is_exported():
     assert declared == set(_lib.EXPORTED), (declared ^ set(_lib.EXPORTED))
     for name in declared:
         assert hasattr(_lib.lib, name)
-    assert _lib.lib.oniris_abi_version() == 13
+    assert _lib.lib.oniris_abi_version() == 14
 
 
 def test_mask_tables_against_golden():
@@ -246,6 +247,43 @@ def test_better_module_s3_checkpoints(tmp_path, monkeypatch):
     monkeypatch.setitem(sys.modules, "boto3", None)                               # `import boto3` now fails
     with pytest.raises(ImportError, match="boto3"):
         m.save_to_state_dict("s3://models/other.pt")
+
+
+def test_checkpoint_kwargs_with_numpy_values_load_without_the_full_pickle_machinery(tmp_path, monkeypatch):
+    """the reference's VAE is a BetterModule whose `kwargs` are whatever its constructor was given -- numpy
+    statistics included -- and gym_train.py:33 / cs_train.py:32 load such files first thing (reference: weights_only=False).
+    The restricted loader must take them (numpy scalars / arrays are data), refuse anything else with a message that names the
+    opt-in, and the opt-in must load like the reference."""
+    import pickle
+    import numpy as np
+    import pytest
+    import autoregressive_diffusion_amd  # noqa: F401
+    from edm2.utils import BetterModule
+
+    class Stat(BetterModule):
+        def __init__(self, width=3, mean=0.0, std=1.0, table=None):
+            super().__init__()
+            self.kwargs = dict(width=width, mean=mean, std=std, table=table)
+            self.lin = torch.nn.Linear(int(width), int(width))
+    m = Stat(np.int64(4), np.float64(0.25), np.float32(1.5), np.arange(3, dtype=np.float32))
+    path = str(tmp_path / "stat.pt")
+    m.save_to_state_dict(path)
+    with pytest.raises(pickle.UnpicklingError):
+        torch.load(path, weights_only=True)                       # what round 5 did: a hard failure before training
+    back = Stat.from_pretrained(path)
+    assert back.kwargs["mean"] == 0.25 and isinstance(back.kwargs["mean"], np.float64) and back.kwargs["width"] == 4
+    assert np.array_equal(back.kwargs["table"], np.arange(3, dtype=np.float32)) and torch.equal(back.lin.weight, m.lin.weight)
+
+    # an arbitrary class in kwargs is not data
+    torch.save({"state_dict": m.state_dict(), "kwargs": dict(width=4, mean=_NotData())}, str(tmp_path / "odd.pt"))
+    with pytest.raises(pickle.UnpicklingError, match="ONIRIS_TRUST_CHECKPOINT=1"):
+        Stat.from_pretrained(str(tmp_path / "odd.pt"))
+    monkeypatch.setenv("ONIRIS_TRUST_CHECKPOINT", "1")             # the reference's own load (utils.py:59)
+    assert isinstance(Stat.from_pretrained(str(tmp_path / "odd.pt")).kwargs["mean"], _NotData)
+
+
+class _NotData:
+    pass
 
 
 def test_normalized_weight_forward_matches_the_reference_formula():

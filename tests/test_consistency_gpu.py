@@ -15,7 +15,7 @@ import math
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.selfcheck]      # (self-consistency properties: not counted as oracle coverage)
 DEV = "cuda"
 RES, B, CH, T_, CUT, SEED = 16, 4, 16, 8, 3, 42
 TIGHT = 3e-4          # consistency_test.py:32

@@ -76,6 +76,7 @@ def test_loss_tail_kernel_matches_the_torch_formulation_and_logs_on_device():
     assert torch.equal(nw.sigmas, s2) and torch.allclose(nw.losses, l2, rtol=1e-5) and torch.equal(nw.positions, p2)
 
 
+@pytest.mark.selfcheck
 @pytest.mark.gpu
 def test_no_sync_training_step_still_logs_sigma_and_loss():
     """VERDICT r02 missing #2: the benched step (sync=False) used to skip noise_weight.add_data (reference loss.py:43)."""

@@ -97,6 +97,7 @@ def test_weight_perm3():
     assert rel(wf, ref) < 5e-3
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("N,H,cin,cout,k", [(6, 16, 32, 64, 3), (5, 8, 96, 32, 3), (16, 4, 64, 64, 3), (3, 32, 16, 40, 3),
                                             (7, 8, 64, 192, 1), (3, 16, 48, 32, 1), (130, 1, 64, 96, 1), (6, 32, 32, 96, 1),
                                             # 1x1 with >= 8192 positions and Cin % 64 == 0: the LDS-DMA GEMM (conv1x1_glds.h);
@@ -132,6 +133,7 @@ def test_conv_plain(N, H, cin, cout, k):
     assert e[0] < 1e-2 and e[1] < 1e-2 and e[2] < 2e-2
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("B,T,H,cin,cout", [(2, 4, 8, 32, 32), (1, 2, 16, 64, 64), (1, 8, 4, 32, 64), (2, 3, 8, 96, 32),
                                             (1, 2, 32, 16, 32),
                                             # shapes the persistent LDS-DMA kernel takes (16x16 tiles, Cin % 32 == 0):
@@ -278,13 +280,15 @@ def test_one_frame_conv_kept_context_product(B, H, cin, cout, epi):
     F = torch.nn.functional
     kept = None
     for it in range(3):                                                               # three "evaluations": new x, new gates
-        x = nhwc(bfr(torch.randn(B, cin, H, H)))
-        g = (torch.rand(B) * 0.6 + 0.05).to(DEV)
+        x0, g0 = bfr(torch.randn(B, cin, H, H)), torch.rand(B) * 0.6 + 0.05
+        x, g = nhwc(x0), g0.to(DEV)
         kw = {}
         if epi == "silu":
-            kw = dict(cscale=(torch.rand(B, cout) + 0.5).to(DEV))
+            cs0 = torch.rand(B, cout) + 0.5
+            kw = dict(cscale=cs0.to(DEV))
         elif epi == "mpsum":
-            kw = dict(res=nhwc(bfr(torch.randn(B, cout, H, H))), ta=0.7, tb=0.5, clip=2.0)
+            r0 = bfr(torch.randn(B, cout, H, H))
+            kw = dict(res=nhwc(r0), ta=0.7, tb=0.5, clip=2.0)
         plain = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, **kw)
         if kept is None:
             kept = torch.full((B, H, H, Co), float("nan"), device=DEV)
@@ -301,6 +305,14 @@ def test_one_frame_conv_kept_context_product(B, H, cin, cout, epi):
         read = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, ctx_prod=kept, ctx_prod_mode=2, **kw)
         assert torch.equal(plain, read), (it, (plain.float() - read.float()).abs().max().item())
         assert torch.equal(before, kept)                                              # mode 2 only reads
+        # ... and the own-phases-only launch against the fp32 reference directly (the form every evaluation of the rollout runs)
+        e2, _ = O.weight_effective(w2, 1.0, False)
+        yr = O.mp_sum(F.conv2d(x0, e2, padding=1), y3, g0)
+        if epi == "silu":
+            yr = F.silu(yr * cs0[:, :, None, None]) / 0.596
+        elif epi == "mpsum":
+            yr = (0.7 * r0 + 0.5 * yr).clamp(-2.0, 2.0)
+        assert rel(read.float().cpu().permute(0, 3, 1, 2)[:, :cout], yr) < 1e-2
     # a launch the one-frame kernel cannot serve must refuse the mode instead of ignoring it
     x2 = nhwc(bfr(torch.randn(2 * B, cin, H, H)))
     ctx2 = torch.cat([pad, x2.reshape(B, 2, H, H, cin)], 1).contiguous()
@@ -310,6 +322,7 @@ def test_one_frame_conv_kept_context_product(B, H, cin, cout, epi):
                          ctx_bstride=4, ctx_T=4, coff=(0, 1), ctx_prod=kept, ctx_prod_mode=2)
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("N,H,cin,cout,clip", [(9, 32, 128, 128, 2.0), (15, 24, 64, 200, 0.0), (33, 16, 256, 256, 3.0)])
 def test_conv1x1_mpsum_large(N, H, cin, cout, clip):
     """attn_proj-shaped op on the LDS-DMA GEMM: out = clip(ta*res + tb*(W x)) with >= 8192 positions, + gradients."""
@@ -346,17 +359,20 @@ def _attn_ref(x0, wq, wp, B, m, training, just_2d=False, rope=True):
     return p
 
 
-@pytest.mark.parametrize("persistent", [1, 0])
+@pytest.mark.parametrize("persistent,dkv_keys", [(1, 0), (1, 128), (0, 0)])
 @pytest.mark.parametrize("B,T,H,m,chunks", [(2, 4, 8, 1, 1), (1, 8, 4, 2, 1), (1, 2, 16, 1, 1), (1, 16, 8, 2, 1),
                                             # dK/dV with every key block's query list split over 3 workgroups
                                             (1, 16, 8, 2, 3), (2, 4, 8, 1, 3),
                                             # 12 (batch, head) pairs (4 XCD groups), Counter-Strike shape (P = 16, 8 heads)
                                             (3, 16, 8, 4, 1), (1, 32, 4, 8, 1)])
-def test_video_attention_core_train(B, T, H, m, chunks, persistent, monkeypatch):
+def test_video_attention_core_train(B, T, H, m, chunks, persistent, dkv_keys, monkeypatch):
     """qkv -> attention output (the part between the qkv conv and the proj conv), forward + backward; the forward
-    through the persistent wave-specialised kernel (attn_fwd_ws_kernel) and through the grid kernel."""
+    through the persistent wave-specialised kernel (attn_fwd_ws_kernel) and through the grid kernel; dK/dV through the
+    persistent kernel with the item size the launch picks by load (64 keys at these sizes) AND with the 128-key items
+    bench.py's B = 8 step gets (attn_bwd_dkv_ws_kernel<2,128>; ops._dkv_item_keys)."""
     from autoregressive_diffusion_amd import ops
     monkeypatch.setattr(ops, "ATTN_PERSISTENT", persistent)
+    monkeypatch.setattr(ops, "DKV_ITEM_KEYS", dkv_keys)
     monkeypatch.setattr(ops, "ATTN_DKV_CHUNKS", chunks)
     monkeypatch.setattr(ops, "ATTN_DKV_MIN_L", 128)
     torch.manual_seed(5)
@@ -421,8 +437,8 @@ def _c2_attention_oracle(B, T, H, m, seed):
     return _c2_oracle[key]
 
 
-@pytest.mark.parametrize("persistent", [1, 0])
-def test_video_attention_bench_shape_vs_dense_oracle(persistent, monkeypatch):
+@pytest.mark.parametrize("persistent,dkv_keys", [(1, 0), (1, 128), (0, 0)])
+def test_video_attention_bench_shape_vs_dense_oracle(persistent, dkv_keys, monkeypatch):
     """the shape bench.py runs -- BASELINE configs[1]: B = 2, T = 64, P = 64, 4 heads, L = 8192 tokens,
     8 (sequence, head) pairs x 64 query blocks on the longest-first schedule, dK/dV in 4 query chunks (ops defaults, exactly
     what _AttentionFn uses in the step) -- forward AND backward against the dense masked-softmax oracle, through the
@@ -430,6 +446,7 @@ def test_video_attention_bench_shape_vs_dense_oracle(persistent, monkeypatch):
     Tolerance (bf16 operands, fp32 accumulation vs the fp32 oracle): rel L2 <= 1e-2 out, <= 2.5e-2 dqkv."""
     from autoregressive_diffusion_amd import ops
     monkeypatch.setattr(ops, "ATTN_PERSISTENT", persistent)
+    monkeypatch.setattr(ops, "DKV_ITEM_KEYS", dkv_keys)        # 0: by load (64-key items at B = 2); 128: what the B = 8 bench step launches
     assert ops.ATTN_DKV_CHUNKS == 4 and ops.ATTN_DKV_MIN_L == 2048          # the bench's own setting: 8192 // 2048 = 4 chunks
     B, T, H, m = 2, 64, 8, 4
     C, P, N = 64 * m, H * H, B * 2 * T
@@ -444,7 +461,7 @@ def test_video_attention_bench_shape_vs_dense_oracle(persistent, monkeypatch):
     # per-frame errors too: a wrong softmax weight inside the allowed set of a few rows would hide in the global norm
     fo = ((ho - o).reshape(N, -1).norm(dim=1) / o.reshape(N, -1).norm(dim=1)).max().item()
     fg = ((dqkv - dqkv_ref).reshape(N, -1).norm(dim=1) / (dqkv_ref.reshape(N, -1).norm(dim=1) + 1e-12)).max().item()
-    print("video_attention C2 shape", (B, T, H, m), "persistent" if persistent else "grid", "rel out/dqkv", e,
+    print("video_attention C2 shape", (B, T, H, m), "persistent" if persistent else "grid", f"dkv item keys {dkv_keys or 'by load'}", "rel out/dqkv", e,
           "worst frame out/dqkv", (fo, fg))
     assert e[0] < 1e-2 and e[1] < 2.5e-2
     assert fo < 2e-2 and fg < 5e-2
@@ -499,6 +516,7 @@ def test_decode_attention_at_rollout_depth_vs_oracle():
     assert rel(cache[0][:, :n_old * P].reshape(B, n_old, P, m, 64).permute(0, 3, 1, 2, 4), kc) == 0.0
 
 
+@pytest.mark.selfcheck
 def test_fused_qkv_norm_rope_matches_three_launch_path(monkeypatch):
     """oniris_qkv_norm_rope[_bwd] (normalisation + both rotations in one pass, one bf16 rounding) against oniris_qkv_norm +
     2 x oniris_rope (+ their adjoints): same attention output and qkv gradient up to the skipped intermediate rounding."""
@@ -622,6 +640,7 @@ def test_adamw():
     assert rel(p, pr.data) < 1e-5
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("C1,C2,norm", [(64, 0, True), (32, 0, True), (256, 0, True), (64, 32, False), (96, 96, False), (48, 0, False)])
 def test_act_fused(C1, C2, norm):
     """[mp_cat | pixel norm] + mp_silu in one pass (utils.py:83-134) and its adjoint, vs the oracle primitives."""
@@ -658,6 +677,7 @@ def test_act_fused(C1, C2, norm):
     assert max(e) < 1e-2
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("mode,norm", [("down", True), ("up", False), ("down", False)])
 def test_act_with_resample_equals_resample_then_act(mode, norm):
     """ops.act(..., resample=mode) (one forward launch) against ops.resample followed by ops.act: outputs and the input
@@ -685,6 +705,7 @@ def test_act_with_resample_equals_resample_then_act(mode, norm):
         assert torch.equal(u, v)
 
 
+@pytest.mark.usefixtures("nt_policy")
 def test_resample_fused():
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(10)
@@ -700,6 +721,7 @@ def test_resample_fused():
         assert rel(nchw(y), yr) < 5e-3 and rel(nchw(x.grad), xr.grad) < 5e-3
 
 
+@pytest.mark.selfcheck
 @pytest.mark.parametrize("N,H,C1,C2,cout", [(1, 64, 32, 32, 32), (1, 16, 128, 64, 128), (2, 8, 256, 256, 256), (1, 32, 64, 32, 64),
                                             (3, 8, 128, 256, 256)])
 def test_conv_cat_act_matches_act_then_conv(N, H, C1, C2, cout):
@@ -760,6 +782,7 @@ def test_resample_general_filter(f):
     ops.GradSlot.live = []
 
 
+@pytest.mark.selfcheck
 def test_clip_flags_survive_a_second_forward_before_backward():
     """the forward's "did the clip change anything" flag is read by the backward.  A second grad-enabled forward
     before that backward (two micro-batches summed into one loss; a train-mode evaluation in between) rewinds and refills the
@@ -798,6 +821,7 @@ def test_clip_flags_survive_a_second_forward_before_backward():
 
 # H = 16: the LDS-DMA tile kernel's epilogues (cout = 64) and the streaming kernel's (cout = 32); clipped = False: the +-256 clip
 # is armed but never reached -- the usual case, in which the backward pre-pass reads no mask (OnirisConvArgs.clip_flag)
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("gated,H,cout,clipped", [(False, 8, 64, True), (True, 8, 64, True), (True, 16, 64, True),
                                                   (True, 16, 64, False), (True, 16, 32, True), (True, 16, 32, False),
                                                   # the plain streaming kernel's epilogues (8 frames of 128x128 pixels = 1024 tiles)

@@ -33,6 +33,7 @@ def packed_weight(pw, cout, cin, kshape):
     return wf.permute(1, 2, 0).reshape(cout, cin, *kshape).contiguous()
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("N,H,cin,cout,k", [(6, 16, 64, 64, 3), (4, 32, 32, 96, 3), (8, 8, 256, 128, 3), (9, 32, 128, 136, 1), (6, 32, 32, 96, 1)])
 def test_conv_plain_bf16_faithful(N, H, cin, cout, k):
     from autoregressive_diffusion_amd import ops
@@ -50,6 +51,7 @@ def test_conv_plain_bf16_faithful(N, H, cin, cout, k):
     assert e <= TIGHT
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("B,T,H,cin,cout,epi", [(2, 4, 16, 64, 64, "none"), (1, 6, 32, 32, 32, "mpsum"), (2, 3, 8, 128, 128, "silu"),
                                                 (1, 4, 16, 256, 128, "mpsum"), (1, 5, 32, 96, 32, "none"),
                                                 # several tiles per persistent workgroup (1024 tiles on 256 CUs) / the streaming kernel
@@ -154,6 +156,7 @@ def test_attention_core_bf16_faithful(kind, B, T, H, m):
     assert ep <= TIGHT
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("N,H,C", [(6, 16, 64), (3, 32, 32), (10, 8, 256)])
 def test_act_bf16_faithful(N, H, C):
     """Pixel norm + mp_silu (networks_edm2.py:70-77 with utils.py normalize / mp_silu): both outputs of the fused pass."""
@@ -170,6 +173,7 @@ def test_act_bf16_faithful(N, H, C):
     assert e[0] <= TIGHT and e[1] <= 2 * TIGHT        # (silu of the ROUNDED norm or of the fp32 one: whichever the kernel does, within a flip)
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("B,T,H,cin,cout", [(2, 4, 16, 64, 64), (1, 6, 32, 32, 32), (2, 3, 8, 128, 256), (1, 5, 16, 128, 64),
                                             (2, 4, 4, 512, 512), (1, 3, 8, 512, 512)])
 def test_gated_conv_train_backward_bf16_faithful(B, T, H, cin, cout):
@@ -252,6 +256,7 @@ def test_attention_core_backward_bf16_faithful(kind, B, T, H, m):
     assert max(e) <= TIGHT
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("B,T,H,cin,cout,epi", [(2, 4, 16, 64, 64, "silu"), (1, 6, 32, 32, 32, "silu"), (2, 3, 8, 128, 128, "mpsum"),
                                                 (1, 5, 16, 128, 64, "mpsum_clipped"), (1, 6, 32, 32, 32, "mpsum_clipped"), (1, 6, 32, 32, 32, "mpsum")])
 def test_gated_conv_train_backward_epilogues_bf16_faithful(B, T, H, cin, cout, epi):
@@ -321,6 +326,7 @@ def test_gated_conv_train_backward_epilogues_bf16_faithful(B, T, H, cin, cout, e
     assert max(e.values()) <= TIGHT
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("form,N,H,C,Cs", [("enc", 6, 16, 64, 0), ("enc", 3, 32, 32, 0), ("dec", 4, 16, 64, 32), ("dec", 2, 32, 32, 64)])
 def test_act_backward_bf16_faithful(form, N, H, C, Cs):
     """Backward of the fused activation pass: pixel norm + mp_silu (encoder blocks, networks_edm2.py:70-77) and mp_cat + mp_silu
@@ -557,6 +563,7 @@ def test_qkv_norm_hd_bf16_faithful(B, T, H, m, d):
     assert max(e) <= TIGHT and pad == 0.0 and eb <= TIGHT
 
 
+@pytest.mark.usefixtures("nt_policy")
 @pytest.mark.parametrize("N,H,cin,cout,k,clip", [(9, 32, 128, 128, 1, 1.0), (6, 16, 256, 256, 1, 0.0), (8, 32, 64, 64, 3, 1.5), (130, 8, 64, 96, 1, 2.0)])
 def test_plain_conv_mpsum_bf16_faithful(N, H, cin, cout, k, clip):
     """MPConv with the fused mp_sum (+ clip) epilogue -- the attention projection (attention_modules.py:43,77 + networks_edm2.py
