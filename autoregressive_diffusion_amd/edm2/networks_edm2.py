@@ -63,11 +63,16 @@ class Block(nn.Module):
         # xs: the activation's xo is the residual of conv_res1 (no 1x1 skip conv in between): that conv parks the residual gradient
         # as (gradient of its output, ta) and the activation's backward kernel applies the factor -- ta * g is never written
         skip_conv_done = False
-        xs = ops.GradSlot() if (private_out and ops.ALIAS2 and self.training and torch.is_grad_enabled()
-                                and not (self.flavor == "dec" and self.conv_skip is not None)) else None
+        want_xs = (private_out and ops.ALIAS2 and self.training and torch.is_grad_enabled()
+                   and not (self.flavor == "dec" and self.conv_skip is not None))
+        if self.flavor == "enc" and self.conv_skip is not None:
+            x, in_slot = self.conv_skip._cl(x, in_slot=in_slot), None
+        # ... only when the activation's backward will RUN and take what was parked: an input that carries no gradient (a frozen
+        # stem / frozen first encoder blocks while fine-tuning) has no backward node, and a parked gradient would be left over at
+        # the end of backward (GradSlot.check_all_taken would blame a partial backward) -- then conv_res1 returns the
+        # residual gradient to autograd, which drops it
+        xs = ops.GradSlot() if (want_xs and (x.requires_grad or (skip is not None and skip.requires_grad))) else None
         if self.flavor == "enc":
-            if self.conv_skip is not None:
-                x, in_slot = self.conv_skip._cl(x, in_slot=in_slot), None
             x, a = ops.act(x, norm=True, in_slot=in_slot, resample=rs, xo_slot=xs)     # x <- pixel norm(x); a = mp_silu(x)
         elif (skip is not None and self.conv_skip is not None and not self.training
               and ops.conv_cat_act_ok(x, skip, self.conv_skip.weight.pw)):
@@ -247,7 +252,8 @@ class UNet(BetterModule):
                                                         c=cs[id(block)], in_slot=slot, private_out=bool(use_slots))
                 else:
                     xcl, cache["enc", name] = block._cl(xcl, B, c_noise, cache.get(("enc", name)), update_cache, just_2d)
-                slot = ops.GradSlot() if use_slots else None
+                # (an output of a frozen encoder prefix carries no gradient: nobody would take what the decoder parks for it)
+                slot = ops.GradSlot() if (use_slots and xcl.requires_grad) else None
                 skips.append((xcl, slot))
                 cb = stage_hooks.get(("enc", name))
                 if cb is not None and xcl.requires_grad:              # everything downstream of here is final when

@@ -367,7 +367,8 @@ class WeightBank:
         fill instead of 184 allocations + fills, and the slices keep their addresses, so the descriptor table on the device
         stays valid (no rebuild + upload per step).  Handing a slice out again is only sound while nobody else still looks at
         it -- a loop that kept `g = p.grad` across zero_grad() expects `g` to stay what it was: the pool is used while its
-        storage has no holder but the bank (checked: storage use count + reference counts of the slices), fresh tensors otherwise.
+        storage has no holder but the bank (checked: storage use count + reference counts of the slices), fresh tensors otherwise
+        (a one-time RuntimeWarning says so; ONIRIS_GRAD_POOL=0 opts out of the pool altogether).
         A weight whose gradient was created here and that no weight-gradient launch targets in the backward pass that follows
         gets None back at the end of that pass (`_finish`): the reference leaves such parameters without a gradient (emb_time,
         networks_edm2.py:205-207) and torch.optim skips them."""
@@ -388,7 +389,17 @@ class WeightBank:
         uses = use_count(pool.untyped_storage()._cdata) if use_count is not None else -1
         if self._gpool_uses is None:
             self._gpool_uses = uses
-        pooled = uses >= 0 and uses == self._gpool_uses and all(_sys.getrefcount(w.gview) == 2 for w in released)   # (2: the slot + the argument)
+        pooled = (GRAD_POOL and uses >= 0 and uses == self._gpool_uses
+                  and all(_sys.getrefcount(w.gview) == 2 for w in released))   # (2: the slot + the argument)
+        if GRAD_POOL and not pooled and not getattr(self, "_gpool_warned", False):
+            # both checks lean on interpreter / torch internals (CPython reference counts, a private storage use count): say so
+            # ONCE when they switch the pool off -- fresh tensors are always correct, they cost a descriptor rebuild + upload per step
+            self._gpool_warned = True
+            import warnings
+            warnings.warn("oniris: released weight gradients are handed out as fresh tensors instead of slices of the pooled buffer "
+                          "(somebody else still holds a released gradient or the pool's storage, or torch's storage use count is "
+                          "unavailable); correct, but every step rebuilds and uploads the weight descriptor table.  "
+                          "ONIRIS_GRAD_POOL=0 switches the pool off for good and silences this.", RuntimeWarning, stacklevel=3)
         if pooled:
             if len(released) == len(trainable):
                 pool.zero_()
@@ -503,6 +514,7 @@ ATTN_DKV_PERSISTENT = int(_os.environ.get("ONIRIS_DKV_PERSISTENT", "1"))   # 0: 
 ATTN_DQ_PERSISTENT = int(_os.environ.get("ONIRIS_DQ_PERSISTENT", "1"))      # 0: VideoAttention dQ through the grid kernel
 WGRAD_VARIANT = int(_os.environ.get("ONIRIS_WGRAD", "0"))   # < 0: register-staged wgrad kernel everywhere (A/B knob)
 BIG_TILE = int(_os.environ.get("ONIRIS_BIG_TILE", "4"))     # conv tuning knob (see OnirisConvArgs.big_tile)
+GRAD_POOL = int(_os.environ.get("ONIRIS_GRAD_POOL", "1"))    # 0: gradients released by a foreign zero_grad() always come back as fresh tensors (WeightBank._reassign)
 GRAD_SLOTS = int(_os.environ.get("ONIRIS_GRAD_SLOTS", "1"))  # 0: skip / residual gradients are joined by autograd (A/B, partial backward)
 
 

@@ -325,7 +325,7 @@ class OnirisDDP(nn.Module):
         BetterModule._ddp_params_and_buffers_to_ignore while torch's constructor runs): torch's reducer owns every autograd-
         accumulated parameter, this object the kernel-owned weights in `flat`; nobody calls its forward() -- the wrapped
         module's own forward calls inner_pre_forward() / inner_post_forward(out) -- and "are gradients exchanged in this
-        pass" is torch DDP's `require_backward_grad_sync` (its no_sync()), read at forward AND at backward time.
+        pass" is torch DDP's `require_backward_grad_sync` (its no_sync()) as it stood when the FORWARD ran -- torch's own rule (_pass_synced).
         force_collectives: issue the collectives in a one-rank group too (tests / profiling of the exchange path).
         auto_wait: the end of every synced backward also orders the current stream behind the exchange (a stream-side wait,
         the host does not block), so `optimizer.step()` may follow `loss.backward()` directly, as in the reference's loops;
@@ -424,6 +424,19 @@ class OnirisDDP(nn.Module):
     def _sync_enabled(self, v):
         self._sync_flag = bool(v)
 
+    def _pass_synced(self):
+        """Is the backward pass that is running now one whose gradients are exchanged?
+        Inner mode (under torch's DistributedDataParallel): torch's own rule -- the value `require_backward_grad_sync` had when
+        the FORWARD ran (torch prepares its reducer in forward and nowhere else; distributed.py `_pre_forward`).  cs_train.py:108-110
+        wraps only `loss.backward()` in `unet.no_sync()`, so under torch DDP every micro-step of that loop is exchanged, and so it is
+        here: both parameter groups (torch's reducer's and the kernel-owned weights) are in the same state after every backward,
+        and an `optimizer.step()` behind a backward that ran inside `no_sync()` sees averaged gradients on all of them, as with
+        plain torch DDP.  A forward inside `no_sync()` defers the exchange to the next synced pass -- again as torch.
+        Stand-alone OnirisDDP: its own `no_sync()` is honoured at forward AND at backward time (documented in INTEGRATION.md)."""
+        if self._torch_ddp is not None:
+            return self._fwd_synced
+        return self._sync_enabled and self._fwd_synced
+
     def _bank(self):
         """The WeightBank of the wrapped tree (it lives on the module whose forward entered `weights_ready` first: the UNet,
         also when a Precond around it is what got wrapped)."""
@@ -482,7 +495,7 @@ class OnirisDDP(nn.Module):
             weights with no pending slab) and start their exchange; RCCL runs it on its own stream, beside the backward
             kernels that are still to come.  Stages that did not fire by themselves (their activation needed no
             gradient) go out with the next one."""
-            if self._sync_enabled and self._fwd_synced and self._active() and not self._sent[i]:
+            if self._pass_synced() and self._active() and not self._sent[i]:
                 bank = self._bank()
                 if bank is not None:
                     bank.backward()
@@ -500,7 +513,7 @@ class OnirisDDP(nn.Module):
 
     def _end_of_backward(self):
         self._queued = False
-        if not (self._sync_enabled and self._fwd_synced):
+        if not self._pass_synced():
             return
         self.allreduce_grads()                           # (finalises weight gradients + gathers the small ones first)
         if self.auto_wait:

@@ -621,7 +621,8 @@ def main():
     ap.add_argument("--net", choices=["gym", "cs"], default="gym",
                     help="gym = BASELINE configs[1] (the headline metric); cs = the Counter-Strike net of configs[2]/[3] "
                          "(32x32 latents, 310 M parameters, no conditioning) as an extra measurement")
-    ap.add_argument("--extra-rollout-frames", type=int, default=256, help=argparse.SUPPRESS)
+    ap.add_argument("--extra-rollout-frames", type=int, default=256,
+                    help="generated frames of the `extra.rollout_<n>` record (BASELINE configs[4]: 256)")
     ap.add_argument("--cpu-frames", type=int, default=64,
                     help="frames of the CPU-baseline sample: 64 = BASELINE configs[1] at B = 1 (BASELINE.md section 3: about two "
                          "minutes of host time); smaller = a shorter sample; 0 = skip")
@@ -700,12 +701,13 @@ def main():
             extra["cs_t64"] = train(args, "cs", 8, 4, rank, world, dev, wd, light=True, light_batch=2, light_frames=64)
             torch.cuda.empty_cache()
             # BASELINE configs[4] at its stated size: 256 generated frames (31 evaluations each) behind a 10-frame context
-            extra["rollout_256"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=256), quiet=True)
-            extra["rollout_256"]["note"] = ("configs[4]: 256 generated frames, plotting.py:165 settings (16 Heun steps = 31 UNet "
-                                            "evaluations per frame), one sequence, KV / activation caches growing from 10 to 266 frames")
+            nroll = int(args.extra_rollout_frames)
+            extra[f"rollout_{nroll}"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=nroll), quiet=True)
+            extra[f"rollout_{nroll}"]["note"] = (f"configs[4]: {nroll} generated frames, plotting.py:165 settings (16 Heun steps = 31 UNet "
+                                                 f"evaluations per frame), one sequence, KV / activation caches growing from 10 to {10 + nroll} frames")
             r8 = rollout(types.SimpleNamespace(batch=8, ctx_frames=8, gen_frames=8), quiet=True)
             extra["rollout_b8"] = {k: r8[k] for k in ("value", "unit", "ms_per_unet_eval", "frames_generated", "batch", "finite")}
-            extra["rollout_b8"]["note"] = "the same sampler on 8 sequences at once (throughput; rollout_32 is the one-sequence latency case)"
+            extra["rollout_b8"]["note"] = f"the same sampler on 8 sequences at once (throughput; rollout_{nroll} is the one-sequence latency case)"
         except Exception as e:                                   # (never lose the headline to an extra)
             extra["error"] = f"{type(e).__name__}: {e}"
         out["extra"] = extra
