@@ -778,6 +778,15 @@ def _rows_f32(t):
     return t
 
 
+def _wants_wgrad(pw):
+    """Does a weight-gradient launch have anybody to serve?  A row-concatenated group (WeightBank.add_group) does as soon as ONE
+    member is trainable: weight_bwd_kernel finishes every member on its own and leaves frozen ones (no .grad) alone."""
+    members = getattr(pw, "members", None)
+    if members:
+        return any(m.param.requires_grad for m in members)
+    return pw.param.requires_grad
+
+
 class _ConvOp(torch.autograd.Function):
     """One fused conv op on channels-last bf16 activations.
 
@@ -928,9 +937,9 @@ class _ConvOp(torch.autograd.Function):
                 _conv_launch(dout, dy3, pw2.wb, pw3.wb, dx, ca_own, sel, B, 2, T, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb, 9,
                              ctx_bstride=T, ctx_T=T, coff=(2, 1), ctx_fill=0.0)
             grp = []                                 # own-frame weight + the two context taps: ONE split-K launch
-            if pw2.param.requires_grad:
+            if _wants_wgrad(pw2):
                 grp.append(_wgrad_args(x, dout, pw2, ca_own, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, 9, N, N, 0, 0.0))
-            if pw3.param.requires_grad:
+            if _wants_wgrad(pw3):
                 for j, coff in enumerate((-2, -1)):
                     grp.append(_wgrad_args(x, dy3, pw3, None, B, T, H, W, Cin, pw3.CinP, Co, pw3.CoutP, 9, 2 * T, T, coff,
                                            1.0, tap0=9 * j))
@@ -946,9 +955,9 @@ class _ConvOp(torch.autograd.Function):
                 else:
                     _conv_launch(dout, None, pw2.wb, None, dx, plain_coef, None, 1, 1, N, H, W, Co, pw2.CinPb, Cin, pw2.CoutPb,
                                  pw2.taps)
-            if pw2.param.requires_grad:
+            if _wants_wgrad(pw2):
                 _wgrad_launch(x, dout, pw2, plain_coef, 1, N, H, W, Cin, pw2.CinP, Co, pw2.CoutP, pw2.taps, N, N, 0, 0.0)
-        if pw2.param.requires_grad or (gated and pw3.param.requires_grad):
+        if _wants_wgrad(pw2) or (gated and _wants_wgrad(pw3)):
             pw2.bank.request_finish()
         if cfg.res_slot is not None and dres is not None:
             cfg.res_slot.put(dres)                   # joins the other gradient of `res` inside that consumer's kernel
@@ -1002,7 +1011,10 @@ def conv(x, pw, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, in_slot=None, r
     epi = "mpsum" if res is not None else ("emb_silu" if cscale is not None else "none")
     cfg = ConvCfg(pw, None, epi=epi, ta=ta, tb=tb, clip=clip, need_grad=torch.is_grad_enabled(), in_slot=in_slot,
                   res_slot=res_slot, grad_private=grad_private, res_alias=res_alias)
-    return _ConvOp.apply(x, pw.param, None, None, None, cscale, res, cfg)
+    sched = pw.param
+    if getattr(pw, "members", None) and not sched.requires_grad:      # a group whose first member is frozen: any trainable member
+        sched = next((m.param for m in pw.members if m.param.requires_grad), sched)     # keeps the node in the graph
+    return _ConvOp.apply(x, sched, None, None, None, cscale, res, cfg)
 
 
 def gated_conv_train(x, gate, pw2, pw3, B, T, coefs=None, res=None, ta=0.0, tb=0.0, clip=0.0, cscale=None, grad_private=False,
