@@ -66,6 +66,13 @@ class AttnArgs(C.Structure):
                 ("k_bstride", c_int64), ("split_ws", c_void_p), ("kv_splits", c_int32), ("pad2_", c_int32)]
 
 
+class AttnF32Args(C.Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("out", c_void_p), ("lse", c_void_p),
+                ("dout", c_void_p), ("delta", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+                ("BH", c_int32), ("Lq", c_int32), ("Lk", c_int32), ("D", c_int32), ("mask_mode", c_int32), ("P", c_int32),
+                ("T", c_int32), ("q_frame_off", c_int32), ("scale", c_float), ("pad_", c_int32)]
+
+
 EPI_NONE, EPI_EMB_SILU, EPI_MPSUM = 0, 1, 2
 
 # every symbol include/oniris.h declares (tests/test_abi.py checks the list against the header)
@@ -77,6 +84,10 @@ _SIGS = {
     "oniris_profile_disarm": (c_int, []),
     "oniris_set_cu_reserve": (c_int, [c_int]),
     "oniris_set_ew_nt_bytes": (c_int64, [c_int64]),
+    "oniris_conv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oniris_wgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "oniris_attn_f32_fwd": (c_int, [c_void_p, c_void_p]),
+    "oniris_attn_f32_bwd": (c_int, [c_void_p, c_void_p]),
     "oniris_census": (c_int, [c_int]),
     "oniris_census_read": (c_int64, [C.c_char_p, c_int64]),
     "oniris_train_mask": (c_int, [c_int, c_int, c_void_p, c_void_p, C.POINTER(c_int)]),

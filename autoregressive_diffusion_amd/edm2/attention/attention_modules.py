@@ -6,6 +6,7 @@ import torch
 from torch import nn
 
 from ... import ops
+from ... import fp32 as _fp32
 from ..conv import MPConv, weights_ready
 from ..utils import to_cl, from_cl
 from .RoPe import RotaryEmbedding
@@ -82,6 +83,8 @@ class VideoAttention(_AttentionBase):
     def forward(self, x, batch_size, cache=None, update_cache=False, just_2d=False):
         if self.num_heads == 0:
             return x, None
+        if _fp32.active():
+            return _fp32.video_attention(self, x, batch_size, cache, update_cache, just_2d)
         with weights_ready(self):
             y, cache = self._cl(to_cl(x), batch_size, cache, update_cache, just_2d)
             return from_cl(y, x.dtype), cache
@@ -96,5 +99,7 @@ class FrameAttention(_AttentionBase):
     def forward(self, x, batch_size=None, cache=None, update_cache=False, just_2d=True):
         if self.num_heads == 0:
             return x, None
+        if _fp32.active():
+            return _fp32.frame_attention(self, x), None
         with weights_ready(self):
             return from_cl(self._frame_cl(to_cl(x), 0.0), x.dtype), None

@@ -9,6 +9,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from .. import fp32 as _fp32
 from .utils import to_cl, from_cl, BF16, strip_runtime_state
 
 _tls = threading.local()
@@ -88,6 +89,8 @@ class MPConv(nn.Module):
         return ops.conv(x, self.weight.pw, res, ta, tb, clip, in_slot=in_slot, res_slot=res_slot)
 
     def forward(self, x, gain=1):
+        if _fp32.active():                                      # Precond(use_fp16=False) / force_fp32=True: fp32 end to end
+            return _fp32.mpconv(self, x, gain)
         with weights_ready(self):
             if x.ndim == 2:                                     # linear (conv.py:38-39)
                 pad = (-x.shape[1]) % 8
@@ -307,6 +310,8 @@ class MPCausal3DGatedConv(nn.Module):
         cache["_ctx_product"] = (ops.gated_conv_ctx_product(pad, pw2, pw3, B), pad, wsig)
 
     def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
+        if _fp32.active():
+            return _fp32.gated_conv(self, x, emb, batch_size, c_noise, cache, update_cache, just_2d)
         with weights_ready(self):
             cl = to_cl(x, pad_to=-(-x.shape[1] // 8) * 8)
             if cache is not None and "activations" in cache and cache["activations"].shape[-1] != cl.shape[-1]:

@@ -67,6 +67,9 @@ class EDM2Loss:
     @staticmethod
     def _fusable(net, images, noise, sigma):
         unet = _core(getattr(net, "unet", None))
+        from .. import fp32 as _fp32
+        if _fp32.active() or not getattr(net, "use_fp16", True):          # the fp32 path has no packed bf16 form: eager formulation
+            return False
         return (images.is_cuda and images.dtype == torch.float32 and noise.dtype == torch.float32 and images.is_contiguous()
                 and noise.is_contiguous() and getattr(unet, "_oniris_cl_io", False) and images.shape[2] <= 8
                 and getattr(unet, "img_channels", 99) == images.shape[2] and not images.requires_grad)

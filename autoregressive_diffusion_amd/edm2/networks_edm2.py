@@ -10,6 +10,7 @@ from torch import nn
 import torch.nn.functional as F
 
 from .. import ops
+from .. import fp32 as _fp32
 from .loss_weight import MultiNoiseLoss
 from .utils import BetterModule, MPFourier, to_cl, from_cl, BF16, strip_runtime_state
 from .conv import MPConv, MPCausal3DGatedConv, Gating, weights_ready, batched_gates
@@ -122,6 +123,8 @@ class Block(nn.Module):
                 child.load_from_2d(sd[name])
 
     def forward(self, x, emb, batch_size, c_noise, cache=None, update_cache=False, just_2d=False):
+        if _fp32.active():
+            return _fp32.block(self, x, emb, batch_size, c_noise, cache, update_cache, just_2d)
         with weights_ready(self):
             pad = (-emb.shape[1]) % 8
             e = F.pad(emb, (0, pad)).to(BF16)[:, None, None, :].contiguous()
@@ -197,6 +200,10 @@ class UNet(BetterModule):
         """_cl_io = (B, tt): `x` is already the packed UNet input (B*tt, H, W, ops.IN_PAD) bf16 with the ones channel
         (ops.dart_input) and the raw channels-last output (B*tt, H, W, 8k) bf16 is returned WITHOUT out_gain -- the
         fused DART loss applies it (ops.dart_loss).  Default: the reference signature (:191)."""
+        if _fp32.active():
+            if _cl_io is not None:
+                raise RuntimeError("the packed bf16 input / output form of UNet.forward does not exist in the fp32 path")
+            return _fp32.unet(self, x, c_noise, conditioning, cache, update_cache, just_2d)
         if cache is None:
             cache = {}
         with weights_ready(self):
@@ -474,19 +481,6 @@ class Precond(BetterModule):
         core = getattr(self.unet, "module", self.unet)
         return core._ddp_fused_parameters() if hasattr(core, "_ddp_fused_parameters") else []
 
-    _fp32_warned = False
-
-    @classmethod
-    def _warn_fp32(cls, why):
-        """The reference's `use_fp16=False` / `force_fp32=True` select fp32 arithmetic for the whole net (networks_edm2.py:285,
-        294).  Here every operand between kernels is bf16 (fp32 accumulation) whatever the switch says: say so, once."""
-        if not cls._fp32_warned:
-            cls._fp32_warned = True
-            import warnings
-            warnings.warn(f"Precond({why}): this implementation always computes with bf16 operands and fp32 accumulation "
-                          "(DESIGN.md section 3, 'Numerics'); the switch is accepted for signature compatibility and changes "
-                          "nothing.  D_x is returned in fp32 as in the reference.", RuntimeWarning, stacklevel=3)
-
     def forward(self, x, sigma, conditioning=None, force_fp32=False, cache=None, update_cache=False, just_2d=False):
         inner = self._ddp_inner()          # torch DistributedDataParallel around the Precond itself
         if inner is None:
@@ -497,12 +491,23 @@ class Precond(BetterModule):
         return out
 
     def _forward(self, x, sigma, conditioning=None, force_fp32=False, cache=None, update_cache=False, just_2d=False):
-        if force_fp32 or not self.use_fp16:
-            self._warn_fp32("force_fp32=True" if force_fp32 else "use_fp16=False")
         if cache is None:
             cache = {}
         cache["shape"] = x.shape
         x = x.to(torch.float32)
+        if force_fp32 or not self.use_fp16:
+            # the reference's precision switch (networks_edm2.py:285,294: dtype = fp32 unless use_fp16 and not force_fp32): the whole
+            # net in fp32 on fp32 activations -- fp32.py (HIP fp32 contractions; a verification mode, never the timed path).  Caches
+            # written by such a call are fp32 and belong to fp32 calls only.
+            sg = sigma.to(torch.float32)[:, :, None, None, None]
+            sd = self.sigma_data
+            c_skip = sd ** 2 / (sg ** 2 + sd ** 2)
+            c_out = sg * sd / (sg ** 2 + sd ** 2).sqrt()
+            c_in = 1 / (sd ** 2 + sg ** 2).sqrt()
+            c_noise = sigma.to(torch.float32).reshape(sigma.shape[:2]).log() / 4
+            with _fp32.fp32_arithmetic():
+                F_x, cache = self.unet.forward(c_in * x, c_noise, conditioning, cache, update_cache, just_2d)
+            return c_skip * x + c_out * F_x.to(torch.float32), cache
         core = unwrap_ddp(self.unet)       # (torch's DistributedDataParallel hides the UNet's attributes; the CALL still goes through it)
         if (not torch.is_grad_enabled() and x.is_cuda and x.is_contiguous() and x.shape[2] <= 8 and sigma.shape == x.shape[:2]
                 and getattr(core, "_oniris_cl_io", False) and getattr(core, "img_channels", -1) == x.shape[2]):

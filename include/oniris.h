@@ -25,7 +25,7 @@ extern "C" {
 typedef void* oniris_stream_t;
 
 const char* oniris_last_error(void);
-int oniris_abi_version(void);   /* 14.  13 -> 14: oniris_set_ew_nt_bytes, oniris_census / oniris_census_read (diagnostics; no signature changed); 12 -> 13: oniris_dart_input(+ cpad: the packed input is 32 channels wide in the product, so that the stem conv runs on the
+int oniris_abi_version(void);   /* 14.  13 -> 14: oniris_set_ew_nt_bytes, oniris_census / oniris_census_read (diagnostics), the fp32 verification path (oniris_conv_f32 / wgrad_f32 / attn_f32_*); no signature changed; 12 -> 13: oniris_dart_input(+ cpad: the packed input is 32 channels wide in the product, so that the stem conv runs on the
                                  * streaming kernels of the 32-channel level); 11 -> 12: oniris_set_cu_reserve; 10 -> 11: OnirisConvArgs.ctx_prod / ctx_prod_mode (appended fields); 9 -> 10: OnirisConvArgs.clip_flag,
                                  * oniris_gconv_bwd_fused(+ clip_flag, coef_own_scaled), oniris_qkv_norm_hd / _hd_bwd / oniris_rope_hd       */
 /* Measurement aid: arm a pair of HIP events (hipEvent_t created with timing); the next MFMA conv / weight-gradient /
@@ -522,7 +522,38 @@ int oniris_attn_bwd_dkv(const OnirisAttnArgs* args /* [host] */, oniris_stream_t
  * This library exports no collective wrappers (the four pass-through oniris_comm_* entry points of ABI <= 7 carried no
  * logic and are gone since ABI 8).                                                                                    */
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * fp32 verification path -- Precond(use_fp16=False) / Precond.forward(force_fp32=True) (networks_edm2.py:285,294: the switch
+ * that picks the arithmetic type of the whole net; the reference's modules compute in the dtype of their input, conv.py:37-46).
+ * Activations, weights, products and sums in fp32 (contractions on v_mfma_f32_32x32x2_f32); channels-last fp32 tensors
+ * [N][H][W][C] with ANY channel counts.  Not the timed path: it exists so that the reference's criterion std(diff) <= 3e-4
+ * (edm2/consistency_test.py:23-32) can be held against the fp32 fixtures.  csrc/fp32.hip.
+ * oniris_conv_f32: out[n][y][x][co] = sum_{tap, ci} w[tap][co][ci] * x[n][y + dy][x + dx][ci], taps = 1 (1x1 / linear) or 9 (3x3,
+ * tap = 3 (dy + 1) + (dx + 1), zero padding) -- F.conv2d of MPConv.forward (conv.py:41-46); the data gradient is the same call
+ * on w'[8 - tap][ci][co].  oniris_wgrad_f32: dw[tap][co][ci] += sum_pos dy[pos][co] * x[shift(pos, tap)][ci] (dw zeroed by the
+ * caller; fp32 atomics over position chunks).                                                                              */
+int oniris_conv_f32(const float* x, const float* w, float* out, int64_t N, int H, int W, int Cin, int Cout, int taps,
+                    oniris_stream_t stream);
+int oniris_wgrad_f32(const float* x, const float* dy, float* dw, int64_t N, int H, int W, int Cin, int Cout, int taps,
+                     oniris_stream_t stream);
+/* Softmax attention in fp32 for any head width D <= 256 (attention_modules.py:59-77,105-119; also what serves heads wider than
+ * the 64 channels of the product kernels, networks_edm2.py:28,39).  q [BH][Lq][D], k / v [BH][Lk][D], out [BH][Lq][D],
+ * lse [BH][Lq] (natural log), all fp32 contiguous; logits = scale * q.k.
+ * mask_mode 0: dense.  1: frame-causal, key frame <= query frame + q_frame_off (frames of P tokens; q_frame_off = frames
+ * already cached: causal prefill and cached steps, attention_modules.py:69-77).  2: the DART training mask over 2T frames
+ * (clean | noised) = BlockMask table AND mask_mod as the compiled FlexAttention evaluates it (attention_masking.py:27-53).
+ * _bwd: dq, dk, dv from dout, lse and delta[i] = sum_c dout[i][c] * out[i][c].                                              */
+typedef struct OnirisAttnF32Args {
+  const float* q; const float* k; const float* v; float* out; float* lse;
+  const float* dout; const float* delta; float* dq; float* dk; float* dv;
+  int32_t BH, Lq, Lk, D, mask_mode, P, T, q_frame_off;
+  float scale; int32_t pad_;
+} OnirisAttnF32Args;
+int oniris_attn_f32_fwd(const OnirisAttnF32Args* args, oniris_stream_t stream);
+int oniris_attn_f32_bwd(const OnirisAttnF32Args* args, oniris_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif
