@@ -160,6 +160,74 @@ def attention(q, k, v, mask="dense", P=1, T=1, q_frame_off=0):
     return out.reshape(B, m, Lq, d)
 
 
+def rope(q, k, inv_freq, scale_vec, training, scale_base=64):
+    """RotaryEmbedding.forward (RoPe.py:21-57) from its two buffers: q, k (b, m, frames, hw, c) -> rotated (b, m, frames * hw, c).
+    Angles and xPos scales are rounded to fp16 as in the reference (tables of fp16 values, fp16 cos / sin)."""
+    nk = k.shape[-3] // 2 if training else k.shape[-3]
+    t = torch.arange(nk, device=inv_freq.device).type_as(inv_freq)
+    ang = torch.outer(t, inv_freq)
+    ang = torch.cat((ang, ang), dim=-1).to(torch.float16)
+    sc = scale_vec[None, :] ** ((t - (nk // 2)) / scale_base)[:, None]
+    sc = torch.cat((sc, sc), dim=-1).to(torch.float16).unsqueeze(1)
+    cos, sin = ang.cos().unsqueeze(1), ang.sin().unsqueeze(1)
+    if training:
+        cos, sin, sc = (torch.cat((z, z), dim=0) for z in (cos, sin, sc))
+
+    def rot(x):
+        a, b = x.chunk(2, dim=-1)
+        return torch.cat((-b, a), dim=-1)
+    k = (k * cos + rot(k) * sin) / sc
+    nq = q.shape[-3]
+    q = (q * cos[-nq:] + rot(q) * sin[-nq:]) * sc[-nq:]
+    return q.flatten(-3, -2), k.flatten(-3, -2)
+
+
+def wide_heads_train(qkv, kind, B, T, heads, rope_bufs):
+    """The attention core of the bf16 path for heads WIDER than 64 channels (the product kernels are written for <= 64;
+    networks_edm2.py:28,39 accepts any channels_per_head): qkv (N, P, 3C) bf16 with channel = s * C + head * d + c (the packed
+    attn_qkv order) -> (N, P, C) bf16.  Per-head normalisation and rotation as fp32 torch ops under autograd, scores / values /
+    their gradients through the generic fp32 attention kernel (any width up to 256) -- correct and slow; no BASELINE
+    configuration comes here."""
+    u = _utils()
+    N, P, C3 = qkv.shape
+    C = C3 // 3
+    d = C // heads
+    x = qkv.float().reshape(N, P, 3, heads, d)
+    q, k, v = (u.normalize(x[:, :, s], dim=-1) for s in range(3))               # (N, P, m, d)
+    if kind == "video":
+        q, k, v = (z.reshape(B, 2 * T, P, heads, d).permute(0, 3, 1, 2, 4) for z in (q, k, v))     # (b, m, 2T, P, d)
+        qr, kr = rope(q, k, rope_bufs[0], rope_bufs[1], True)
+        o = attention(qr, kr, v.reshape(B, heads, 2 * T * P, d), "train", P=P, T=T)
+        o = o.reshape(B, heads, 2 * T, P, d).permute(0, 2, 3, 1, 4).reshape(N, P, C)
+    else:
+        q, k, v = (z.permute(0, 2, 1, 3) for z in (q, k, v))                    # (N, m, P, d)
+        o = attention(q, k, v, "dense").permute(0, 2, 1, 3).reshape(N, P, C)
+    return o.to(qkv.dtype)
+
+
+@torch.no_grad()
+def wide_heads_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
+    """Eval-mode VideoAttention core for wide heads (attention_modules.py:51-77): the cache is the reference's -- normalised,
+    UN-rotated k and v (b, m, frames, P, d), here fp32 --, every call rotates all keys for the grown key count."""
+    u = _utils()
+    N, _, C3 = qkv.shape
+    C = C3 // 3
+    d = C // heads
+    t = N // B
+    x = qkv.float().reshape(N, P, 3, heads, d)
+    q, k, v = (u.normalize(x[:, :, s], dim=-1).reshape(B, t, P, heads, d).permute(0, 3, 1, 2, 4) for s in range(3))
+    if kv_cache is not None:
+        k, v = torch.cat((kv_cache[0], k), dim=2), torch.cat((kv_cache[1], v), dim=2)
+    new_cache = (k, v) if update_cache else kv_cache
+    qr, kr = rope(q, k, rope_bufs[0], rope_bufs[1], False)
+    vf = v.reshape(B, heads, -1, d)
+    if t == 1:
+        o = attention(qr, kr, vf, "dense")
+    else:
+        o = attention(qr, kr, vf, "causal", P=P, q_frame_off=k.shape[2] - t)
+    return o.reshape(B, heads, t, P, d).permute(0, 2, 3, 1, 4).reshape(N, P, C).to(qkv.dtype), new_cache
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # per-element glue (the reference's edm2/utils.py formulas on NCHW fp32)
 

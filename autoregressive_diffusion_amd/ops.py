@@ -1791,11 +1791,15 @@ class _AttentionFn(torch.autograd.Function):
 HEAD_DIMS_PADDED = (8, 16, 24, 32, 40, 48, 56)     # served through the 64-channel kernels on zero-padded heads (csrc/attention_hd.hip)
 
 
+HEAD_DIM_WIDE_MAX = 256                            # 64 < d <= 256, d % 8 == 0: the generic fp32 attention kernel (fp32.wide_heads_*; slow)
+
+
 def _head_dim(C, heads):
     d = C // max(heads, 1)
-    if heads <= 0 or C != heads * d or (d != 64 and d not in HEAD_DIMS_PADDED):
-        raise NotImplementedError(f"attention head dimension {C}/{heads}: 64, or a multiple of 8 below 64 through the padded path "
-                                  "(heads wider than 64 channels would need attention kernels of their own)")
+    wide = 64 < d <= HEAD_DIM_WIDE_MAX and d % 8 == 0
+    if heads <= 0 or C != heads * d or (d != 64 and d not in HEAD_DIMS_PADDED and not wide):
+        raise NotImplementedError(f"attention head dimension {C}/{heads}: 64 (native), a multiple of 8 below 64 (padded into the "
+                                  f"64-channel kernels) or a multiple of 8 up to {HEAD_DIM_WIDE_MAX} (generic fp32 attention kernel)")
     return d
 
 
@@ -1850,7 +1854,11 @@ class _AttentionHdFn(torch.autograd.Function):
 
 
 def attention_train(qkv, kind, B, T, heads, rope_bufs=None):
-    fn = _AttentionFn if _head_dim(qkv.shape[-1] // 3, heads) == 64 else _AttentionHdFn
+    d = _head_dim(qkv.shape[-1] // 3, heads)
+    if d > 64:                                      # no BASELINE configuration: generality (networks_edm2.py:28,39), not speed
+        from . import fp32 as _fp32
+        return _fp32.wide_heads_train(qkv, kind, B, T, heads, rope_bufs)
+    fn = _AttentionFn if d == 64 else _AttentionHdFn
     return fn.apply(qkv, kind, B, T, heads, rope_bufs, torch.is_grad_enabled())
 
 
@@ -2031,6 +2039,9 @@ def _attention_eval_hd(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
 def attention_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P):
     """Eval-mode VideoAttention core (attention_modules.py:51-77): qkv (B*t, P, 3C) of the NEW frames.
     kv_cache: (K, V) normalised, un-rotated, (B, t_cached*P, C) or None.  Returns out (B*t,P,C), new cache."""
+    if _head_dim(qkv.shape[-1] // 3, heads) > 64:
+        from . import fp32 as _fp32
+        return _fp32.wide_heads_eval(qkv, B, heads, rope_bufs, kv_cache, update_cache, P)
     if _head_dim(qkv.shape[-1] // 3, heads) != 64:
         return _attention_eval_hd(qkv, B, heads, rope_bufs, kv_cache, update_cache, P)
     N, P_, C3 = qkv.shape

@@ -103,8 +103,9 @@ def test_attn_schedule_is_a_balanced_partition():
 
 def test_attention_modules_head_dimensions():
     """64-channel heads (every shipped configuration, networks_edm2.py:28,39) and -- through the padded path -- every multiple of
-    8 below 64 (the reference's unit tests build 4 heads of 16 channels, consistency_test.py:39,61); anything else (a width that
-    does not divide the channels, is not a multiple of 8, or exceeds 64) must be refused instead of computing garbage."""
+    8 below 64 (the reference's unit tests build 4 heads of 16 channels, consistency_test.py:39,61); wider heads up to 256 channels go
+    to the generic fp32 attention kernel; anything else (a width that does not divide the channels, is not a multiple of 8, or
+    exceeds 256) must be refused instead of computing garbage."""
     import pytest
     import autoregressive_diffusion_amd  # noqa: F401
     from edm2.attention import VideoAttention, FrameAttention
@@ -114,7 +115,8 @@ def test_attention_modules_head_dimensions():
         cls(channels=64, num_heads=0)
         cls(channels=96, num_heads=2)          # 48-channel heads
         cls(channels=48, num_heads=2)          # 24
-        for channels, heads in ((64, 3), (256, 2), (24, 2)):      # not a divisor, 128, 12
+        cls(channels=256, num_heads=2)         # 128-channel heads: the generic fp32 attention kernel (round 6)
+        for channels, heads in ((64, 3), (24, 2), (1024, 2)):     # not a divisor, 12, 512
             with pytest.raises(NotImplementedError):
                 cls(channels=channels, num_heads=heads)
 
