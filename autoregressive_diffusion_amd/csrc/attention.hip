@@ -1299,11 +1299,13 @@ extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t st
                    "attn_bwd_dq: null pointer");
   if (d.a.sched) {                                  // persistent, statically balanced, wave-specialised kernel (attention_bwd_dq_ws.h):
     // the forward's work list (query blocks of 128 rows); lse / delta point at the NEGATED rows (oniris_attn_bwd_prep)
-    ONIRIS_CHECK_ARG(d.a.mask_mode == 2 && d.a.kv_num && d.a.kv_idx && d.a.tab_cols <= 64 && d.a.sched_wgs > 0 && d.a.sched_slots > 0,
-                     "attn_bwd_dq: the scheduled kernel needs the DART training table with <= 64 blocks per row");
+    ONIRIS_CHECK_ARG(d.a.mask_mode != 0 && d.a.kv_num && d.a.kv_idx && d.a.tab_cols <= 64 && d.a.sched_wgs > 0 && d.a.sched_slots > 0,
+                     "attn_bwd_dq: the scheduled kernel needs a table-driven mask with <= 64 blocks per row");
     ONIRIS_CHECK_ARG(d.a.Lq % 128 == 0 && d.a.Lq == d.a.Lk && d.a.Lq / 128 < 65536,
                      "attn_bwd_dq: the scheduled kernel needs Lq == Lk, a multiple of 128 (got %d, %d)", d.a.Lq, d.a.Lk);
-    oniris_launch(attn_bwd_dq_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    // mask_mode 1 + a block-diagonal table = dense attention inside every frame (FrameAttention with P = 128 * 2^k tokens)
+    if (d.a.mask_mode == 1) oniris_launch(attn_bwd_dq_ws_kernel<1>, dim3(d.a.sched_wgs), dim3(512), stream, d);
+    else oniris_launch(attn_bwd_dq_ws_kernel<2>, dim3(d.a.sched_wgs), dim3(512), stream, d);
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }

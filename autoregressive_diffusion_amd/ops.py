@@ -99,6 +99,19 @@ def device_tables(kind, n_frames, image_size, device):
     return _table_cache[key]
 
 
+def frame_tables(n_frames, image_size, device):
+    """Block-diagonal (kv, q) tables: table block r (one frame of `image_size` = 128 * 2^k tokens) lists itself and nothing else.
+    With mask_mode 1 (key frame <= query frame: everything inside a frame) the table-driven persistent kernels compute dense
+    attention INSIDE every frame of a long pseudo-sequence -- FrameAttention (attention_modules.py:105-119) on the work lists of
+    the VideoAttention kernels."""
+    key = ("frame", n_frames, image_size, str(device))
+    if key not in _table_cache:
+        num = np.ones(n_frames, dtype=np.int32)
+        idx = np.arange(n_frames, dtype=np.int32).reshape(n_frames, 1)
+        _table_cache[key] = tuple(torch.from_numpy(a).to(device) for a in (num, idx, num.copy(), idx.copy())) + (image_size,)
+    return _table_cache[key]
+
+
 _sched_cache = {}
 _cu_count = {}
 ATTN_PERSISTENT = int(__import__("os").environ.get("ONIRIS_ATTN_PERSISTENT", "1"))   # 0: grid kernels (A/B knob)
@@ -1616,19 +1629,38 @@ def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mo
     return a
 
 
+# 1: FrameAttention with frames of 128 * 2^k tokens on the persistent work lists (block-diagonal table, mask_mode 1).  Measured at
+# the bench shape (1024 frames of 16x16 tokens, 2 heads; scratch/r06_frame_attn_ab.py, profiles/r06_ab_frame_ws.txt): forward
+# 194-202 us vs 180-196 us on the grid kernels, backward 494-507 vs 382-417 us -- two-block items do not amortise the persistent
+# kernels' per-item prologue / epilogue, so the grid kernels stay the default; the path is kept under test (VERDICT r05 next #5b).
+FRAME_WS = int(_os.environ.get("ONIRIS_FRAME_WS", "0"))
+
+
+def _host_table(kind, n, P):
+    """(kv_num, kv_idx, block) on the host: the DART training table of T = n frames ('video') or the block-diagonal table of n
+    frames ('frame', frame_tables)."""
+    if kind == "video":
+        return train_mask_table(n, P)
+    return np.ones(n, dtype=np.int32), np.arange(n, dtype=np.int32).reshape(n, 1), P
+
+
 def _train_sched(T, P, n_pairs, dev, which):
-    """Schedule of the DART training table's blocks over the persistent workgroups: which = 'fwd' (query blocks of 128
-    rows weighted by their key-block count) or 'dkv' (key blocks weighted by their query-block count)."""
-    num, idx, blk = train_mask_table(T, P)
+    return _table_sched("video", T, P, n_pairs, dev, which)
+
+
+def _table_sched(kind, n, P, n_pairs, dev, which):
+    """Schedule of a table's blocks over the persistent workgroups: which = 'fwd' (query blocks of 128 rows weighted by their
+    key-block count) or 'dkv' (key blocks weighted by their query-block count).  kind / n: see _host_table."""
+    num, idx, blk = _host_table(kind, n, P)
     if which == "fwd":
         per = blk // 128
         w = np.repeat(num * per + 1, per)                    # a table row of `blk` tokens = per 128-row query blocks
     elif which == "dkv":                                     # items of 64 keys: 2 per 128-token block, whole query list each
-        qn, _ = mask_transpose(num, idx)
+        qn = mask_transpose(num, idx)[0] if kind == "video" else num          # (block-diagonal: its own transpose)
         per = blk // 128
         w = np.repeat(qn * per + 1, 2 * per)
     else:                                                    # 'dkv128': items of 128 keys (twice the work per listed block)
-        qn, _ = mask_transpose(num, idx)
+        qn = mask_transpose(num, idx)[0] if kind == "video" else num
         per = blk // 128
         w = np.repeat(qn * per + 1, per)
     return attn_schedule(w, n_pairs, dev)
@@ -1637,15 +1669,15 @@ def _train_sched(T, P, n_pairs, dev, which):
 DKV_ITEM_KEYS = int(_os.environ.get("ONIRIS_DKV_ITEM_KEYS", "0"))     # 64 / 128: force the dK/dV item size (A/B, tests); 0: by load
 
 
-def _dkv_item_keys(T, P, n_pairs, dev):
+def _dkv_item_keys(kind, T, P, n_pairs, dev):
     """128-key items for the persistent dK/dV kernel when the launch has enough of them: the heaviest item (the first key block:
     every later query block attends it) must stay well below a workgroup's average load, or the launch takes as long as that
     one item (C2 at B = 2: 8 pairs x 64 items of up to 64 units on 256 workgroups = 35 units on average -> 64-key items;
     B = 8: 140 on average -> 128-key items)."""
     if DKV_ITEM_KEYS in (64, 128):
         return DKV_ITEM_KEYS
-    num, idx, blk = train_mask_table(T, P)
-    qn, _ = mask_transpose(num, idx)
+    num, idx, blk = _host_table(kind, T, P)
+    qn = mask_transpose(num, idx)[0] if kind == "video" else num
     w = qn * (blk // 128) + 1
     n_wg = max(8, (_cu_count.get(str(dev)) or torch.cuda.get_device_properties(dev).multi_processor_count) - _cu_reserve)
     return 128 if float(w.sum()) * (blk // 128) * n_pairs / n_wg >= 1.5 * float(w.max()) else 64
@@ -1666,15 +1698,23 @@ def _attn_core_fwd(qr, kr, v, kind, B, T, heads, P):
     else:
         frames, Bq, L = 1, N, P
         mask_mode, tabs = 0, None
+        g = next(g for g in (8, 4, 2, 1) if N % g == 0)
+        if (FRAME_WS and ATTN_PERSISTENT and P % 128 == 0 and (P & (P - 1)) == 0 and (N // g) * (P // 128) < 65536
+                and g * heads < 32768):
+            # FrameAttention with frames of 128 * 2^k tokens (16x16 latents: the gym net) on the persistent work lists: the N frames
+            # are g pseudo-sequences of N / g frames under a block-diagonal table + the frame-causal mask (everything inside a
+            # frame): 2-block items back to back on one workgroup per CU instead of a grid of 2-block workgroups
+            frames, Bq, L, mask_mode = N // g, g, (N // g) * P, 1
+            tabs = frame_tables(frames, P, dev)
+    fl = _attn_flops(kind, N if kind != "video" else Bq, T, heads, P if kind != "video" else L, P)
     out = torch.empty((N, P, C), dtype=BF16, device=dev)
     lse = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
     a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
-    fl = _attn_flops(kind, Bq, T, heads, L, P)
     ks = 2 if (mask_mode != 0 and L >= 2048) else 1
     name = f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>"
-    if mask_mode == 2 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64 and L % 128 == 0 and Bq * heads < 32768:
+    if mask_mode != 0 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64 and L % 128 == 0 and Bq * heads < 32768:
         # persistent kernel: query blocks of 128 rows, cost = key blocks of its table row + 1 (fixed per-item work)
-        sched = _train_sched(T, P, Bq * heads, dev, "fwd")
+        sched = _table_sched(kind, T if kind == "video" else frames, P, Bq * heads, dev, "fwd")
         a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
         name = f"attn_fwd_ws_kernel<MODE={mask_mode}>"
     _profiled(name, fl, lambda: check(lib.oniris_attn_fwd(ctypes.byref(a), _stream()), "attn_fwd"))
@@ -1686,19 +1726,20 @@ def _attn_core_bwd(qr, kr, v, out, lse, dout, tabs, meta):
     kind, B, T, heads, Bq, L, frames, P, C, mask_mode = meta
     dev = qr.device
     delta = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
-    dkv_ws = (mask_mode == 2 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and tabs[3].shape[1] <= 64 and L % 128 == 0
+    dkv_ws = (mask_mode != 0 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and tabs[3].shape[1] <= 64 and L % 128 == 0
               and Bq * heads < 32768)
+    tab_n = T if kind == "video" else frames            # what the table was built from (frames of the training half / of a pseudo-sequence)
     neg = torch.empty((2, Bq, heads, L), dtype=torch.float32, device=dev) if dkv_ws else None     # -lse | -delta
     check(lib.oniris_attn_bwd_prep(_p(dout), _p(out), _p(delta), None, _p(lse) if dkv_ws else None, _p(neg), Bq, heads, L, C,
                                    _stream()), "attn_bwd_prep")
     dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
     a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
     a.dout, a.delta, a.dq, a.dk, a.dv = _p(dout), _p(delta), _p(dq), _p(dk), _p(dv)
-    fl = _attn_flops(kind, Bq, T, heads, L, P)
+    fl = _attn_flops(kind, B if kind != "video" else Bq, T, heads, P if kind != "video" else L, P)
     ks = 2 if (mask_mode != 0 and L >= 2048) else 1
     if dkv_ws and ATTN_DQ_PERSISTENT and tabs[1].shape[1] <= 64:
         # persistent dQ kernel on the forward's work list (query blocks, longest first); reads the NEGATED row constants
-        sched = _train_sched(T, P, Bq * heads, dev, "fwd")
+        sched = _table_sched(kind, tab_n, P, Bq * heads, dev, "fwd")
         a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
         a.lse, a.delta = _p(neg[0]), _p(neg[1])
         _profiled(f"attn_bwd_dq_ws_kernel<MODE={mask_mode}>", 1.5 * fl,
@@ -1711,8 +1752,8 @@ def _attn_core_bwd(qr, kr, v, out, lse, dout, tabs, meta):
     if dkv_ws:
         # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
         # dK / dV leave the kernel finished (no fp32 partial sums, no reduction launch); it reads the NEGATED row constants
-        keys = _dkv_item_keys(T, P, Bq * heads, dev)
-        sched = _train_sched(T, P, Bq * heads, dev, "dkv128" if keys == 128 else "dkv")
+        keys = _dkv_item_keys(kind, tab_n, P, Bq * heads, dev)
+        sched = _table_sched(kind, tab_n, P, Bq * heads, dev, "dkv128" if keys == 128 else "dkv")
         a.sched, a.sched_wgs, a.sched_slots = _p(sched[0]), sched[1], sched[2]
         a.dkv_item_keys = keys
         a.lse, a.delta = _p(neg[0]), _p(neg[1])

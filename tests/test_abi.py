@@ -395,8 +395,8 @@ def test_dkv_item_keys_follow_the_launch_size():
     from autoregressive_diffusion_amd import ops
     ops._cu_count["cpu"] = 256
     try:
-        assert ops._dkv_item_keys(64, 64, 2 * 4, "cpu") == 64
-        assert ops._dkv_item_keys(64, 64, 8 * 4, "cpu") == 128
-        assert ops._dkv_item_keys(32, 16, 2 * 8, "cpu") == 64           # Counter-Strike T = 32: 4 table blocks per pair
+        assert ops._dkv_item_keys("video", 64, 64, 2 * 4, "cpu") == 64
+        assert ops._dkv_item_keys("video", 64, 64, 8 * 4, "cpu") == 128
+        assert ops._dkv_item_keys("video", 32, 16, 2 * 8, "cpu") == 64           # Counter-Strike T = 32: 4 table blocks per pair
     finally:
         del ops._cu_count["cpu"]

@@ -540,10 +540,15 @@ def test_fused_qkv_norm_rope_matches_three_launch_path(monkeypatch):
     assert e[0] < 6e-3 and e[1] < 1e-2
 
 
-def test_frame_attention_core_train():
+@pytest.mark.parametrize("N,H,m,frame_ws", [(5, 16, 2, 1), (16, 16, 2, 1), (24, 16, 1, 1), (5, 16, 2, 0), (6, 8, 2, 1), (3, 4, 1, 1)])
+def test_frame_attention_core_train(N, H, m, frame_ws, monkeypatch):
+    """FrameAttention's core (dense softmax inside every frame, attention_modules.py:105-119), forward + backward.  Frames of
+    128 * 2^k tokens (16x16 latents) run on the persistent work lists of the VideoAttention kernels -- g pseudo-sequences of
+    N / g frames under a block-diagonal table, mask_mode 1 (ops.frame_tables; g = 1, 8, 8 for N = 5, 16, 24) --, smaller frames
+    and ONIRIS_FRAME_WS=0 on the grid kernels."""
     from autoregressive_diffusion_amd import ops
+    monkeypatch.setattr(ops, "FRAME_WS", frame_ws)
     torch.manual_seed(6)
-    N, H, m = 5, 16, 2
     C, P = 64 * m, H * H
     qkv0 = bfr(torch.randn(N, 3 * C, H, H))
     go0 = bfr(torch.randn(N, C, H, H))
@@ -557,7 +562,7 @@ def test_frame_attention_core_train():
     out.backward(nhwc(go0).reshape(N, P, C))
     dqkv = x.grad.reshape(N, H, H, 3, m * 64).permute(0, 4, 3, 1, 2).reshape(N, 3 * C, H, H).float().cpu()
     e = (rel(nchw(out.reshape(N, H, H, C)), o), rel(dqkv, qr_in.grad))
-    print("frame_attention rel err out/dqkv", e)
+    print("frame_attention", (N, H, m), "work lists" if frame_ws and (H * H) % 128 == 0 else "grid kernels", "rel err out/dqkv", e)
     assert e[0] < 1e-2 and e[1] < 2.5e-2
 
 
