@@ -63,7 +63,7 @@ class AttnArgs(C.Structure):
                 ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
                 ("dkv_part", c_void_p), ("dkv_chunks", c_int32), ("dkv_item_keys", c_int32),
                 ("sched", c_void_p), ("sched_wgs", c_int32), ("sched_slots", c_int32), ("v_bstride", c_int64),
-                ("k_bstride", c_int64), ("split_ws", c_void_p), ("kv_splits", c_int32), ("pad2_", c_int32)]
+                ("k_bstride", c_int64), ("split_ws", c_void_p), ("kv_splits", c_int32), ("frame_kernel", c_int32)]
 
 
 class AttnF32Args(C.Structure):
@@ -84,6 +84,9 @@ _SIGS = {
     "oniris_profile_disarm": (c_int, []),
     "oniris_set_cu_reserve": (c_int, [c_int]),
     "oniris_set_ew_nt_bytes": (c_int64, [c_int64]),
+    "oniris_frame_attn_bwd": (c_int, [c_void_p, c_void_p]),
+    "oniris_frame_attn_qkv_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "oniris_frame_attn_qkv_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "oniris_conv_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_wgrad_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "oniris_attn_f32_fwd": (c_int, [c_void_p, c_void_p]),

@@ -368,6 +368,7 @@ __global__ void attn_split_reduce_kernel(const float* __restrict__ ws, bf16* __r
 }
 
 #include "attention_ws.h"
+#include "attention_frame.h"
 
 // ================================================================================================================
 // backward: dQ   (the forward's structure: lane = query row, LDS-DMA double-buffered K / V tiles, KS key streams
@@ -1261,6 +1262,13 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }
+  if (frame_attn_ok(d.a)) {                          // dense attention inside frames of 64 / 128 / 256 tokens (attention_frame.h)
+    FrameAttnDev f{d.a, (long long)d.a.B * d.a.Lq, d.a.Lq / 64};
+    ONIRIS_CHECK_ARG((f.ntok + 255) / 256 < (1LL << 31), "attn_fwd: too many tokens");
+    oniris_launch(frame_attn_fwd_kernel, dim3((unsigned)((f.ntok + 255) / 256), d.a.heads), dim3(256), stream, f);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
   // two key streams per workgroup (64 query rows) when the key lists are long and causal, else one (128 rows)
   const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048;
   if (d.a.kv_splits > 1) {                           // split-KV decode: partials + reduction (two launches)
@@ -1309,6 +1317,12 @@ extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t st
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }
+  if (frame_attn_ok(d.a)) {                          // dense attention inside frames of 64 / 128 / 256 tokens (attention_frame.h)
+    FrameAttnDev f{d.a, (long long)d.a.B * d.a.Lq, d.a.Lq / 64};
+    oniris_launch(frame_attn_dq_kernel, dim3((unsigned)((f.ntok + 255) / 256), d.a.heads), dim3(256), stream, f);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
   const bool split = d.a.mask_mode != 0 && d.a.Lk >= 2048;
   const dim3 grid(cdiv(d.a.Lq, split ? 64 : 128), d.a.heads, d.a.B);
   if (split) {
@@ -1321,6 +1335,66 @@ extern "C" int oniris_attn_bwd_dq(const OnirisAttnArgs* args, oniris_stream_t st
       default: ONIRIS_KLAUNCH((attn_bwd_dq_kernel<2, 1>), grid, dim3(256), 0, stream, d); break;
     }
   }
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_frame_attn_bwd(const OnirisAttnArgs* args, oniris_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  AttnDev d;
+  int rc = attn_prepare(args, d, "frame_attn_bwd");
+  if (rc) return rc;
+  ONIRIS_CHECK_ARG(d.a.q && d.a.k && d.a.v && d.a.out && d.a.dout && d.a.lse && d.a.dq && d.a.dk && d.a.dv, "frame_attn_bwd: null pointer");
+  OnirisAttnArgs chk = d.a;
+  chk.frame_kernel = 0;
+  ONIRIS_CHECK_ARG(frame_attn_ok(chk), "frame_attn_bwd: dense attention inside frames of 64 / 128 / 256 tokens only (mask_mode 0, Lq == Lk, "
+                                       "no table / schedule / ring strides / split)");
+  FrameAttnDev f{d.a, (long long)d.a.B * d.a.Lq, d.a.Lq / 64};
+  ONIRIS_CHECK_ARG((f.ntok + 255) / 256 < (1LL << 31), "frame_attn_bwd: too many tokens");
+  oniris_launch(frame_attn_bwd_kernel, dim3((unsigned)((f.ntok + 255) / 256), d.a.heads), dim3(512), stream, f);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+static int frame_qkv_dev(FrameQkvDev& f, const void* qkv, void* out, float* lse, const void* dout, void* dqkv, int64_t n_frames, int P,
+                         int heads, const char* who) {
+  ONIRIS_CHECK_ARG(qkv && out && lse && n_frames > 0 && heads > 0, "%s: bad arguments", who);
+  ONIRIS_CHECK_ARG(P == 64 || P == 128 || P == 256, "%s: frames of 64 / 128 / 256 tokens (got %d)", who, P);
+  f.qkv = (const bf16*)qkv; f.out = (bf16*)out; f.lse = lse; f.dout = (const bf16*)dout; f.dqkv = (bf16*)dqkv;
+  f.ntok = (long long)n_frames * P; f.P = P; f.heads = heads; f.C = heads * 64; f.tiles = P / 64;
+  ONIRIS_CHECK_ARG((f.ntok + 255) / 256 < (1LL << 31) && heads < 65536, "%s: too many tokens", who);
+  return ONIRIS_OK;
+}
+
+extern "C" int oniris_frame_attn_qkv_fwd(const void* qkv, void* out, float* lse, int64_t n_frames, int P, int heads,
+                                         oniris_stream_t stream_) {
+  FrameQkvDev f{};
+  int rc = frame_qkv_dev(f, qkv, out, lse, nullptr, nullptr, n_frames, P, heads, "frame_attn_qkv_fwd");
+  if (rc) return rc;
+  oniris_launch(frame_attn_qkv_fwd_kernel, dim3((unsigned)((f.ntok + 255) / 256), heads), dim3(256), (hipStream_t)stream_, f);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+
+#ifdef FRAME_STAMP
+extern "C" int oniris_frame_attn_qkv_fwd_stamp(const void* qkv, void* out, float* lse, void* stamps, int64_t n_frames, int P, int heads,
+                                               oniris_stream_t stream_) {
+  FrameQkvDev f{};
+  int rc = frame_qkv_dev(f, qkv, out, lse, nullptr, stamps, n_frames, P, heads, "frame_attn_qkv_fwd_stamp");
+  if (rc) return rc;
+  oniris_launch(frame_attn_qkv_fwd_kernel, dim3((unsigned)((f.ntok + 255) / 256), heads), dim3(256), (hipStream_t)stream_, f);
+  ONIRIS_LAUNCH_CHECK();
+  return ONIRIS_OK;
+}
+#endif
+
+extern "C" int oniris_frame_attn_qkv_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int64_t n_frames,
+                                         int P, int heads, oniris_stream_t stream_) {
+  FrameQkvDev f{};
+  int rc = frame_qkv_dev(f, qkv, (void*)out, (float*)lse, dout, dqkv, n_frames, P, heads, "frame_attn_qkv_bwd");
+  if (rc) return rc;
+  ONIRIS_CHECK_ARG(dout && dqkv, "frame_attn_qkv_bwd: dout / dqkv");
+  oniris_launch(frame_attn_qkv_bwd_kernel, dim3((unsigned)((f.ntok + 255) / 256), heads), dim3(512), (hipStream_t)stream_, f);
   ONIRIS_LAUNCH_CHECK();
   return ONIRIS_OK;
 }

@@ -574,12 +574,13 @@ def _timed_launch(fn):
     return e0, e1
 
 
-def _profiled(key, flops, fn):
-    """Run fn() (a kernel launch on the current stream); when KernelProfile is on, time it with HIP events."""
+def _profiled(key, flops, fn, nbytes=None):
+    """Run fn() (a kernel launch on the current stream); when KernelProfile is on, time it with HIP events.  nbytes: the launch's
+    algorithmic HBM bytes where its roofline is the memory system's (t_min = max(FLOPs / MFMA peak, bytes / 6.3 TB/s))."""
     if not KernelProfile.enabled:
         return fn()
     e0, e1 = _timed_launch(fn)
-    KernelProfile.records.append((key, flops, e0, e1))
+    KernelProfile.records.append((key, flops, e0, e1) if nbytes is None else (key, flops, e0, e1, float(nbytes)))
 
 
 def train_frame_pairs(T, P):
@@ -1626,7 +1627,21 @@ def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mo
         a.tab_cols, a.qtab_cols = idx.shape[1], qi.shape[1]
     a.B, a.heads, a.Lq, a.Lk, a.C = B, heads, Lq, Lk, C
     a.mask_mode, a.P, a.T = mask_mode, P, T
+    a.frame_kernel = 0 if FRAME_KERNEL else 1
     return a
+
+
+# 1: dense attention inside frames of 64 / 128 / 256 tokens (FrameAttention, just_2d) on the whole-frame kernels of
+# csrc/attention_frame.h; 0: on the generic grid kernels (A/B, tests)
+FRAME_KERNEL = int(_os.environ.get("ONIRIS_FRAME_KERNEL", "1"))
+
+
+FRAME_BWD_FUSED = int(_os.environ.get("ONIRIS_FRAME_BWD_FUSED", "1"))      # 0: attn_delta + dQ + dK/dV as three launches (A/B, tests)
+
+
+def _frame_kernel_serves(mask_mode, Lq, Lk):
+    """Mirrors frame_attn_ok() (csrc/attention_frame.h) for launches without table, schedule, ring strides or split-KV."""
+    return bool(FRAME_KERNEL) and mask_mode == 0 and Lq == Lk and Lq in (64, 128, 256)
 
 
 # 1: FrameAttention with frames of 128 * 2^k tokens on the persistent work lists (block-diagonal table, mask_mode 1).  Measured at
@@ -1711,7 +1726,7 @@ def _attn_core_fwd(qr, kr, v, kind, B, T, heads, P):
     lse = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
     a = _attn_args(qr, kr, v, None, None, None, out, lse, tabs, Bq, heads, L, L, C, mask_mode, P, T)
     ks = 2 if (mask_mode != 0 and L >= 2048) else 1
-    name = f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>"
+    name = "frame_attn_fwd_kernel" if _frame_kernel_serves(mask_mode, L, L) else f"attn_fwd_kernel<MODE={mask_mode},KS={ks}>"
     if mask_mode != 0 and ATTN_PERSISTENT and tabs[1].shape[1] <= 64 and L % 128 == 0 and Bq * heads < 32768:
         # persistent kernel: query blocks of 128 rows, cost = key blocks of its table row + 1 (fixed per-item work)
         sched = _table_sched(kind, T if kind == "video" else frames, P, Bq * heads, dev, "fwd")
@@ -1725,6 +1740,14 @@ def _attn_core_bwd(qr, kr, v, out, lse, dout, tabs, meta):
     """dq (w.r.t. the unscaled q), dk, dv of _attn_core_fwd."""
     kind, B, T, heads, Bq, L, frames, P, C, mask_mode = meta
     dev = qr.device
+    if _frame_kernel_serves(mask_mode, L, L) and FRAME_BWD_FUSED:
+        # dense attention inside frames of 64 / 128 / 256 tokens: delta, dQ, dK, dV in ONE launch that reads q, k, v, out, dout once
+        dq, dk, dv = torch.empty_like(qr), torch.empty_like(kr), torch.empty_like(v)
+        a = _attn_args(qr, kr, v, None, None, None, out, lse, None, Bq, heads, L, L, C, mask_mode, P, T)
+        a.dout, a.dq, a.dk, a.dv = _p(dout), _p(dq), _p(dk), _p(dv)
+        fl = _attn_flops(kind, B, T, heads, P, P)
+        _profiled("frame_attn_bwd_kernel", 3.5 * fl, lambda: check(lib.oniris_frame_attn_bwd(ctypes.byref(a), _stream()), "frame_attn_bwd"))
+        return dq, dk, dv
     delta = torch.empty((Bq, heads, L), dtype=torch.float32, device=dev)
     dkv_ws = (mask_mode != 0 and ATTN_PERSISTENT and ATTN_DKV_PERSISTENT and tabs[3].shape[1] <= 64 and L % 128 == 0
               and Bq * heads < 32768)
@@ -1747,7 +1770,7 @@ def _attn_core_bwd(qr, kr, v, out, lse, dout, tabs, meta):
         a.sched, a.sched_wgs, a.sched_slots = None, 0, 0
         a.lse, a.delta = _p(lse), _p(delta)
     else:
-        _profiled(f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
+        _profiled("frame_attn_dq_kernel" if _frame_kernel_serves(mask_mode, L, L) else f"attn_bwd_dq_kernel<MODE={mask_mode},KS={ks}>", 1.5 * fl,
                   lambda: check(lib.oniris_attn_bwd_dq(ctypes.byref(a), _stream()), "attn_bwd_dq"))
     if dkv_ws:
         # persistent kernel: items of 64 keys with their whole query list, longest first over one workgroup per CU:
@@ -1768,6 +1791,46 @@ def _attn_core_bwd(qr, kr, v, out, lse, dout, tabs, meta):
         _profiled(f"attn_bwd_dkv_kernel<MODE={mask_mode}>", 2.0 * fl,
                   lambda: check(lib.oniris_attn_bwd_dkv(ctypes.byref(a), _stream()), "attn_bwd_dkv"))     # (+ the partial-sum reduce)
     return dq, dk, dv
+
+
+FRAME_QKV_FUSED = int(_os.environ.get("ONIRIS_FRAME_QKV_FUSED", "1"))      # 0: qkv normalisation as passes of their own around the frame kernels (A/B, tests)
+
+
+class _FrameAttentionQkvFn(torch.autograd.Function):
+    """FrameAttention's core on frames of 64 / 128 / 256 tokens straight from the attn_qkv output (oniris_frame_attn_qkv_fwd / _bwd,
+    csrc/attention_frame.h): qkv (N, P, 3C) bf16 -> (N, P, C); the per-head normalisation and its adjoint run inside the two
+    launches, nothing but qkv, out and lse is kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        _need_gpu(qkv)
+        qkv = qkv.contiguous()
+        N, P, C3 = qkv.shape
+        C = C3 // 3
+        out = torch.empty((N, P, C), dtype=BF16, device=qkv.device)
+        lse = torch.empty((N, heads, P), dtype=torch.float32, device=qkv.device)
+        fl = _attn_flops("frame", N, 1, heads, P, P)
+        # HBM-bound (128 FLOP per byte at 256 tokens per frame): qkv read once, out + lse written
+        _profiled("frame_attn_qkv_fwd_kernel", fl,
+                  lambda: check(lib.oniris_frame_attn_qkv_fwd(_p(qkv), _p(out), _p(lse), N, P, heads, _stream()), "frame_attn_qkv_fwd"),
+                  nbytes=2.0 * N * P * 4 * C + 4.0 * N * heads * P)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        N, P, _ = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        fl = _attn_flops("frame", N, 1, ctx.heads, P, P)
+        C = qkv.shape[2] // 3
+        _profiled("frame_attn_qkv_bwd_kernel", 3.5 * fl,
+                  lambda: check(lib.oniris_frame_attn_qkv_bwd(_p(qkv), _p(out), _p(lse), _p(dout), _p(dqkv), N, P, ctx.heads, _stream()),
+                                "frame_attn_qkv_bwd"),
+                  nbytes=2.0 * N * P * 8 * C + 4.0 * N * ctx.heads * P)            # qkv, out, dout read; dqkv written
+        return dqkv, None
 
 
 class _AttentionFn(torch.autograd.Function):
@@ -1899,6 +1962,9 @@ def attention_train(qkv, kind, B, T, heads, rope_bufs=None):
     if d > 64:                                      # no BASELINE configuration: generality (networks_edm2.py:28,39), not speed
         from . import fp32 as _fp32
         return _fp32.wide_heads_train(qkv, kind, B, T, heads, rope_bufs)
+    if (d == 64 and kind == "frame" and FRAME_KERNEL and FRAME_QKV_FUSED and qkv.shape[1] in (64, 128, 256)
+            and not (FRAME_WS and qkv.shape[1] % 128 == 0)):
+        return _FrameAttentionQkvFn.apply(qkv, heads)
     fn = _AttentionFn if d == 64 else _AttentionHdFn
     return fn.apply(qkv, kind, B, T, heads, rope_bufs, torch.is_grad_enabled())
 

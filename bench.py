@@ -537,7 +537,8 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
         # MFMA launches (conv forward / dgrad / wgrad, attention) of max(FLOPs / MFMA peak, algorithmic bytes / 6.3 TB/s)
         if agg3:
             algo = ALGO_FWD_FLOPS.get((netname, T))
-            prof_fl = sum((2.5 / 3.5 if k.startswith("attn_bwd") and "MODE=2" in k else 1.0) * v["flops"] for k, v in agg3.items()) / 3
+            prof_fl = sum((2.5 / 3.5 if (k.startswith("attn_bwd") and "MODE=2" in k) or k.startswith("frame_attn_qkv_bwd") else 1.0) * v["flops"]
+                          for k, v in agg3.items()) / 3
             fl = 3.0 * algo * B if algo is not None else prof_fl
             ms3 = per_mode["ms_3d_step"]
             tmin = sum(v["t_min"] for v in agg3.values()) / 3 * 1e3
@@ -555,7 +556,8 @@ def train(args, netname, steps, warmup, rank, world, dev, wd, light=False, light
         # attention at both attention levels -- conv.py:60 `just_2d`): algorithmic FLOPs = the sum over its MFMA launches
         # (attention backward priced at 2.5 x its forward, as above) x 1, against its own wall time
         if agg2:
-            fl2 = sum((2.5 / 3.5 if k.startswith("attn_bwd") else 1.0) * v["flops"] for k, v in agg2.items())
+            fl2 = sum((2.5 / 3.5 if k.startswith("attn_bwd") or k.startswith("frame_attn_qkv_bwd") or k == "frame_attn_bwd_kernel" else 1.0) * v["flops"]
+                      for k, v in agg2.items())
             ms2 = per_mode["ms_2d_step"]
             tmin2 = sum(v["t_min"] for v in agg2.values()) * 1e3
             roof_step_2d = dict(bound="mfma", flops_per_step=fl2, flops_source="sum of the launches' algorithmic FLOPs",

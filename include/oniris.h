@@ -494,8 +494,25 @@ typedef struct OnirisAttnArgs {
    * that many workgroups, which leave un-normalised partials (O, l) in split_ws [kv_splits][B][heads][Lq][65] fp32; a
    * second kernel adds them and normalises (one new frame against a long KV ring would otherwise run on heads * B CUs)  */
   float* split_ws;
-  int32_t kv_splits, pad2_;
+  /* frame_kernel (was padding): dense attention inside frames of 64 / 128 / 256 tokens (mask_mode 0, Lq == Lk, no table, no ring
+   * strides, no split) runs on kernels of its own (csrc/attention_frame.h: one workgroup per 256 consecutive tokens of a head,
+   * K | V staged once); 1 = keep such launches on the generic grid kernels (A/B, tests).                                   */
+  int32_t kv_splits, frame_kernel;
 } OnirisAttnArgs;
+
+/* Dense attention inside frames of 64 / 128 / 256 tokens (FrameAttention.forward, attention_modules.py:105-119; VideoAttention's
+ * just_2d branch, :36-45): the WHOLE backward in one launch -- delta = dout . out, dq, dk, dv -- reading q, k, v, out, dout once
+ * (the op is HBM-bound: 128 FLOP per byte at 256 tokens per frame).  Takes the forward's arguments (mask_mode 0, Lq == Lk == P,
+ * lse from oniris_attn_fwd, plain -- not negated) plus dout, dq, dk, dv; no delta, no scratch.  csrc/attention_frame.h.          */
+int oniris_frame_attn_bwd(const OnirisAttnArgs* args, oniris_stream_t stream);
+/* The same layer core straight from the attn_qkv output (FrameAttention.forward, attention_modules.py:108-115: rearrange, normalize(dim=-1),
+ * scaled_dot_product_attention): qkv [n_frames * P][3 C] bf16 with channel = s * C + head * 64 + c (the packed attn_qkv order), C =
+ * heads * 64, P in {64, 128, 256}.  The per-head normalisation of q, k, v happens inside (registers / LDS), the backward applies its
+ * adjoint to the fp32 dq, dk, dv and writes dqkv [n_frames * P][3 C]: no q / k / v / dq / dk / dv tensors exist (the normalisation
+ * passes were half of the layer's HBM traffic).  out [n_frames * P][C] bf16, lse [n_frames][heads][P] fp32 (log2 domain).          */
+int oniris_frame_attn_qkv_fwd(const void* qkv, void* out, float* lse, int64_t n_frames, int P, int heads, oniris_stream_t stream);
+int oniris_frame_attn_qkv_bwd(const void* qkv, const void* out, const float* lse, const void* dout, void* dqkv, int64_t n_frames,
+                              int P, int heads, oniris_stream_t stream);
 
 /* Static load balancing of block-sparse attention [host]: n_pairs (batch, head) pairs x n_blocks work items per pair
  * (query blocks for the forward / dQ, key blocks for dK/dV), weight[blk] = cost of block blk (its list length in the

@@ -540,14 +540,23 @@ def test_fused_qkv_norm_rope_matches_three_launch_path(monkeypatch):
     assert e[0] < 6e-3 and e[1] < 1e-2
 
 
-@pytest.mark.parametrize("N,H,m,frame_ws", [(5, 16, 2, 1), (16, 16, 2, 1), (24, 16, 1, 1), (5, 16, 2, 0), (6, 8, 2, 1), (3, 4, 1, 1)])
-def test_frame_attention_core_train(N, H, m, frame_ws, monkeypatch):
+@pytest.mark.parametrize("frame_kernel", [3, 1, 2, 0])
+@pytest.mark.parametrize("N,H,m,frame_ws", [(5, 16, 2, 1), (16, 16, 2, 1), (24, 16, 1, 1), (5, 16, 2, 0), (6, 8, 2, 1), (3, 4, 1, 1),
+                                            (7, 8, 3, 0), (9, 16, 1, 0), (2, 32, 1, 0)])
+def test_frame_attention_core_train(N, H, m, frame_ws, frame_kernel, monkeypatch):
     """FrameAttention's core (dense softmax inside every frame, attention_modules.py:105-119), forward + backward.  Frames of
     128 * 2^k tokens (16x16 latents) run on the persistent work lists of the VideoAttention kernels -- g pseudo-sequences of
     N / g frames under a block-diagonal table, mask_mode 1 (ops.frame_tables; g = 1, 8, 8 for N = 5, 16, 24) --, smaller frames
     and ONIRIS_FRAME_WS=0 on the grid kernels."""
     from autoregressive_diffusion_amd import ops
     monkeypatch.setattr(ops, "FRAME_WS", frame_ws)
+    # frame_kernel = 1: frames of 64 / 128 / 256 tokens (8x8, 16x16 latents; odd frame counts leave a partial 256-token super-block)
+    # on the whole-frame kernels of csrc/attention_frame.h (forward, dQ, dK / dV); 0: the generic grid kernels
+    # 3 (the product): the two launches that read the raw qkv (normalisation and its adjoint inside); 1: qkv_norm passes around the
+    # frame forward + one-launch backward; 2: ... around the frame forward, frame dQ and grid dK / dV kernels; 0: grid kernels
+    monkeypatch.setattr(ops, "FRAME_KERNEL", min(frame_kernel, 1))
+    monkeypatch.setattr(ops, "FRAME_BWD_FUSED", int(frame_kernel in (1, 3)))
+    monkeypatch.setattr(ops, "FRAME_QKV_FUSED", int(frame_kernel == 3))
     torch.manual_seed(6)
     C, P = 64 * m, H * H
     qkv0 = bfr(torch.randn(N, 3 * C, H, H))
@@ -562,7 +571,9 @@ def test_frame_attention_core_train(N, H, m, frame_ws, monkeypatch):
     out.backward(nhwc(go0).reshape(N, P, C))
     dqkv = x.grad.reshape(N, H, H, 3, m * 64).permute(0, 4, 3, 1, 2).reshape(N, 3 * C, H, H).float().cpu()
     e = (rel(nchw(out.reshape(N, H, H, C)), o), rel(dqkv, qr_in.grad))
-    print("frame_attention", (N, H, m), "work lists" if frame_ws and (H * H) % 128 == 0 else "grid kernels", "rel err out/dqkv", e)
+    path = ("work lists" if frame_ws and (H * H) % 128 == 0 else f"frame kernels (variant {frame_kernel})" if frame_kernel and H * H in (64, 128, 256)
+            else "grid kernels")
+    print("frame_attention", (N, H, m), path, "rel err out/dqkv", e)
     assert e[0] < 1e-2 and e[1] < 2.5e-2
 
 
