@@ -206,7 +206,13 @@ WEIGHT_GN_TOL = dict(enc=5e-2, dec=5e-2)      # (tightened to 2x the measured fl
 # (own-relative, relative to the block's largest gate gradient norm): 2x the values measured on the MI355X (round 5: enc 0.9 % /
 # 0.35 %; dec 7.3 % / 3.2 % -- conv_res1.max_gating of the decoder block, a gradient of 1e-3 that is the difference of two sums of
 # order 1 on a 4-frame fixture; on the full nets against the oracle every such gradient is within 1.8 %, SCALAR_GRAD_BOUNDS)
-G7_GATE_BOUNDS = dict(enc=(1.8e-2, 7e-3), dec=(0.15, 6.5e-2))
+# Round 6: the encoder block's FrameAttention gradient no longer passes through bf16 dq / dk / dv tensors (csrc/attention_frame.h: the
+# normalisation's adjoint is applied to the fp32 accumulators), which re-rolls the rounding noise every downstream sum sees: on this
+# 4-frame fixture conv_res1.max_gating of the ENCODER block (gradient norm 0.225 = 2.5 % of the block's largest) moved from 0.9 % to
+# 5.0 % own-relative = 0.12 % of the largest, while every other figure of the block (y, gx, gemb, weight gradients, the attention
+# core itself against the oracle: 3.9e-3 instead of 4.2e-3) stayed or improved, and on the full nets against the oracle every such
+# gradient is within 0.8 ... 1.7 % as before (SCALAR_GRAD_BOUNDS unchanged).  Bounds at 2x the measured values.
+G7_GATE_BOUNDS = dict(enc=(0.10, 7e-3), dec=(0.15, 6.5e-2))
 
 
 def test_g7_blocks():
@@ -237,7 +243,7 @@ def test_g7_blocks():
         # of its terms (scale-invariant layers downstream).  Measured: 0.9 % (enc), 7.3 % (dec: conv_res1.max_gating, a
         # gradient of 1e-3 that is the difference of two sums of order 1) -- bounds at 2x
         assert wmax < WEIGHT_GN_TOL[tag], gn
-        assert gmax < (0.02 if tag == "enc" else 0.15), gn
+        assert gmax < (0.10 if tag == "enc" else 0.15), gn          # (enc: 0.02 until round 6, see G7_GATE_BOUNDS)
         # the same statement in the form test_cs_shaped_unet_vs_oracle uses for the full nets (SCALAR_GRAD_BOUNDS): error relative to
         # the parameter's own gradient norm where that is at least 1 % of the block's largest gate gradient norm, relative to that
         # largest one for all of them
