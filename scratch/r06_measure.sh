@@ -18,3 +18,5 @@ python scratch/pmc_traffic.py $O/prof_f $O/prof_w $O/r06_pmc_traffic > /dev/null
 rm -rf $O/prof_f $O/prof_w
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ro -o ro -- python3 bench.py --mode rollout --gen-frames 4 --batch 1 > $O/r06_prof_ro.log 2>&1
 cp "$(find $O/prof_ro -name '*kernel_stats.csv' | head -1)" $O/r06_rollout_kernel_stats.csv; rm -rf $O/prof_ro
+ONIRIS_PROFILE_SHAPES=1 python bench.py --steps 4 --warmup 2 --cpu-frames 0 --no-extra > /dev/null 2> $O/r06_conv_shapes.txt
+python scratch/r06_frame_attn_ab.py > $O/r06_ab_frame_attn.txt 2>&1
