@@ -577,6 +577,28 @@ def test_frame_attention_core_train(N, H, m, frame_ws, frame_kernel, monkeypatch
     assert e[0] < 1e-2 and e[1] < 2.5e-2
 
 
+@pytest.mark.parametrize("N,P,m", [(6, 128, 2), (5, 128, 1), (3, 256, 4), (13, 64, 4)])
+def test_frame_attention_kernels_on_128_token_frames(N, P, m):
+    """The frame kernels (csrc/attention_frame.h) take frames of 64, 128 AND 256 tokens -- a 256-token super-block is 4, 2 or 1
+    whole frames.  Square latents only give 64 and 256 (8x8, 16x16); 128 is exercised here directly on (N, P, 3C) token rows,
+    with odd frame counts (partial last super-block), against the dense per-frame softmax of the oracle's formulas."""
+    from autoregressive_diffusion_amd import ops
+    g = torch.Generator().manual_seed(N * P + m)
+    C = 64 * m
+    x0 = bfr(torch.randn(N, P, 3 * C, generator=g))            # packed attn_qkv order: channel = s * C + head * 64 + c
+    go0 = bfr(torch.randn(N, P, C, generator=g))
+    xr = x0.clone().requires_grad_(True)
+    q, k, v = (O.normalize(xr[:, :, s * C:(s + 1) * C].reshape(N, P, m, 64).permute(0, 2, 1, 3), dim=-1) for s in range(3))
+    o = torch.nn.functional.scaled_dot_product_attention(q, k, v).permute(0, 2, 1, 3).reshape(N, P, C)
+    (o * go0).sum().backward()
+    x = x0.to(DEV, torch.bfloat16).requires_grad_(True)
+    out = ops.attention_train(x, "frame", N, 1, m)
+    out.backward(go0.to(DEV, torch.bfloat16))
+    e = (rel(out, o), rel(x.grad, xr.grad))
+    print("frame kernels", (N, P, m), "rel err out/dqkv", e)
+    assert e[0] < 1e-2 and e[1] < 2.5e-2
+
+
 def test_attention_eval_prefill_and_decode():
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(7)
