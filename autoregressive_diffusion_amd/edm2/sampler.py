@@ -7,6 +7,10 @@ import torch
 
 SAMPLER_GRAPH = int(os.environ.get("ONIRIS_SAMPLER_GRAPH", "1"))
 FUSED_FRAME = int(os.environ.get("ONIRIS_SAMPLER_FUSED", "1"))      # 0: the tensor-expression loop below (A/B aid)
+# 1: never let go of a frame's graph while the process lives (experiment: destroying a finished hipGraph exec blocks the host until the
+# device is idle -- 23 ms per frame inside CUDAGraph's destructor, scratch/r06_replay_host.py)
+KEEP_GRAPHS = int(os.environ.get("ONIRIS_SAMPLER_KEEP_GRAPHS", "0"))
+REPLAY_SAME_STREAM = int(os.environ.get("ONIRIS_SAMPLER_SAME_STREAM", "1"))      # 0: replays on the capture stream (rounds 1-5; A/B)
 _graph_pool = None
 _pool_keeper = []          # [(graph, event recorded behind its last replay)]
 
@@ -116,11 +120,20 @@ class _GraphedDenoiser:
             # of the previous frame's graph only now
             # ... and only once its own last replay has run (the host is a frame ahead of the GPU)
             global _pool_keeper
-            _pool_keeper = [e for e in _pool_keeper[:-1] if not e[1].query()] + _pool_keeper[-1:] + [(g, torch.cuda.Event())]
-        self.side.wait_stream(cur)
-        with torch.cuda.stream(self.side):
+            if KEEP_GRAPHS:                  # (experiment, see the knob)
+                _pool_keeper = _pool_keeper + [(g, torch.cuda.Event())]
+            else:
+                _pool_keeper = [e for e in _pool_keeper[:-1] if not e[1].query()] + _pool_keeper[-1:] + [(g, torch.cuda.Event())]
+        if REPLAY_SAME_STREAM:
+            # the replay goes out on the CALLER's stream, like the update kernels around it: with the capture stream as the launch
+            # stream every evaluation cost two cross-stream event waits (two hardware queues: ~25 us of idle GPU per replay and
+            # milliseconds at the frame boundary, profiles/r06_rollout_gaps.txt); a capture needs a side stream, a replay does not
             self.graph.replay()
-        cur.wait_stream(self.side)
+        else:
+            self.side.wait_stream(cur)
+            with torch.cuda.stream(self.side):
+                self.graph.replay()
+            cur.wait_stream(self.side)
         _pool_keeper[-1][1].record(cur)    # (this graph is the newest entry: see the capture above)
         return self.out                    # valid until the next run(): consumed by the update kernel that follows
 

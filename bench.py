@@ -151,10 +151,36 @@ def rollout(args, quiet=False):
     out = {"metric": "rollout generated frames/s (config 5, KV-cached sampler)", "value": B * args.gen_frames / dt,
            "unit": "frames/s", "n_gpus": 1, "ms_per_unet_eval": dt / evals * 1e3, "frames_generated": args.gen_frames,
            "context_frames": ctx_frames + 2, "batch": B, "dtype": "bf16", "data": "synthetic",
-           "finite": bool(torch.isfinite(x).all())}
+           "finite": bool(torch.isfinite(x).all()),
+           "runtime_env": {k: os.environ.get(k) for k in ROLLOUT_ENV}}
     if not quiet:
         print(json.dumps(out))
     return out
+
+
+# Runtime environment of the KV-cached rollout (BASELINE configs[4]).  A generated frame is 31 replays of a ~130-node hipGraph on ONE
+# stream; with the runtime's default of four hardware queues every replayed node and every replay boundary pays for cross-queue ordering
+# (profiles/r06_rollout_gaps.txt: 19 % of a frame idle; profiles/r06_rollout_stream_ab*.txt: 27.2 -> 32.3 frames/s with one queue,
+# nothing else changed).  One hardware queue is right for a single-stream inference process and WRONG for data-parallel training
+# (RCCL's stream must overlap the backward kernels), so it is set for rollout-only processes -- `--mode rollout`, and the child process
+# in which the default training run measures its `extra.rollout_*` records -- never for a training process.  setdefault: an explicit
+# setting in the caller's environment wins.  The training step does not notice it (profiles/r06_hwq_train_ab.txt: 8551 vs 8554 frames/s).
+ROLLOUT_ENV = {"GPU_MAX_HW_QUEUES": "1"}
+
+
+def rollout_child(batch, gen_frames, ctx_frames=8):
+    """bench.py --mode rollout in a CHILD process with ROLLOUT_ENV (this process has initialised the HIP runtime long ago: the
+    variables are read when it comes up).  Returns the child's JSON record."""
+    import subprocess
+    env = dict(os.environ)
+    for k, v in ROLLOUT_ENV.items():
+        env.setdefault(k, v)
+    cmd = [sys.executable, os.path.abspath(__file__), "--mode", "rollout", "--batch", str(batch), "--gen-frames", str(gen_frames),
+           "--ctx-frames", str(ctx_frames)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1200)
+    if r.returncode != 0:
+        raise RuntimeError(f"rollout child exited {r.returncode}: {r.stderr[-400:]}")
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def self_launch(args):
@@ -655,15 +681,36 @@ def main():
         args.batch = 1 if args.mode == "rollout" else (8 if args.net == "gym" else 2)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.mode == "train":
         sys.exit(self_launch(args))              # (this process never imports torch, never touches a GPU)
+    if args.mode == "rollout":
+        for k, v in ROLLOUT_ENV.items():         # before anything touches the HIP runtime (torch is imported inside rollout())
+            os.environ.setdefault(k, v)
     _claim_stdout()
     if args.mode == "rollout":
         return rollout(args)
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     force_dist = bool(os.environ.get("ONIRIS_FORCE_DIST"))          # debug: run the RCCL/DDP path with a single rank
+    # the rollout records of the default run are measured FIRST, each in a child process of its own (ROLLOUT_ENV), while this process
+    # has not touched the GPU yet: a child is started (fork + exec) only from a process without HIP state
+    want_extra = (rank == 0 and world == 1 and not force_dist and args.net == "gym" and not args.no_extra and args.accum == 1
+                  and not os.environ.get("ONIRIS_ONLY_MODE") and not args.dry_run and args.gpus == 1)
+    pre_extra = {}
+    if want_extra:
+        nroll = int(args.extra_rollout_frames)
+        try:
+            pre_extra[f"rollout_{nroll}"] = rollout_child(1, nroll)
+            pre_extra[f"rollout_{nroll}"]["note"] = (f"configs[4]: {nroll} generated frames, plotting.py:165 settings (16 Heun steps = 31 UNet "
+                                                     f"evaluations per frame), one sequence, KV / activation caches growing from 10 to {10 + nroll} "
+                                                     "frames; measured in a process of its own (bench.ROLLOUT_ENV)")
+            r8 = rollout_child(8, 8)
+            pre_extra["rollout_b8"] = {k: r8[k] for k in ("value", "unit", "ms_per_unet_eval", "frames_generated", "batch", "finite", "runtime_env")}
+            pre_extra["rollout_b8"]["note"] = f"the same sampler on 8 sequences at once (throughput; rollout_{nroll} is the one-sequence latency case)"
+        except Exception as e:                                   # (never lose the headline to an extra)
+            pre_extra["rollout_error"] = f"{type(e).__name__}: {e}"
+
+    import torch
+    import torch.distributed as dist
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus disagree")
@@ -702,14 +749,7 @@ def main():
             # BASELINE configs[3]'s per-GPU share: the 310 M net on 64-frame sequences, cs_train.py:59's 2 sequences per GPU
             extra["cs_t64"] = train(args, "cs", 8, 4, rank, world, dev, wd, light=True, light_batch=2, light_frames=64)
             torch.cuda.empty_cache()
-            # BASELINE configs[4] at its stated size: 256 generated frames (31 evaluations each) behind a 10-frame context
-            nroll = int(args.extra_rollout_frames)
-            extra[f"rollout_{nroll}"] = rollout(types.SimpleNamespace(batch=1, ctx_frames=8, gen_frames=nroll), quiet=True)
-            extra[f"rollout_{nroll}"]["note"] = (f"configs[4]: {nroll} generated frames, plotting.py:165 settings (16 Heun steps = 31 UNet "
-                                                 f"evaluations per frame), one sequence, KV / activation caches growing from 10 to {10 + nroll} frames")
-            r8 = rollout(types.SimpleNamespace(batch=8, ctx_frames=8, gen_frames=8), quiet=True)
-            extra["rollout_b8"] = {k: r8[k] for k in ("value", "unit", "ms_per_unet_eval", "frames_generated", "batch", "finite")}
-            extra["rollout_b8"]["note"] = f"the same sampler on 8 sequences at once (throughput; rollout_{nroll} is the one-sequence latency case)"
+            extra.update(pre_extra)                                 # BASELINE configs[4]: measured before this process touched the GPU (above)
         except Exception as e:                                   # (never lose the headline to an extra)
             extra["error"] = f"{type(e).__name__}: {e}"
         out["extra"] = extra
