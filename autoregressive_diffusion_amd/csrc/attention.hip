@@ -299,19 +299,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
       }
   }
   float l = l2[0] + l2[1];
-  if constexpr (KS > 1) {                          // stream 1 hands its partial (O, l) to stream 0 through LDS
-    float* red = (float*)smem;                     // [QW][33][64] floats
+  if constexpr (KS > 1) {                          // streams 1 .. KS-1 hand their partial (O, l) to stream 0 through LDS
+    float* red = (float*)smem;                     // [KS - 1][QW][33][64] floats
     __syncthreads();
-    if (st == 1) {
+    if (st >= 1) {
+      float* rw = red + (size_t)((st - 1) * QW + qwv) * 33 * 64;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) { red[(qwv * 33 + i) * 64 + lane] = o[0][i]; red[(qwv * 33 + 16 + i) * 64 + lane] = o[1][i]; }
-      red[(qwv * 33 + 32) * 64 + lane] = l;
+      for (int i = 0; i < 16; ++i) { rw[i * 64 + lane] = o[0][i]; rw[(16 + i) * 64 + lane] = o[1][i]; }
+      rw[32 * 64 + lane] = l;
     }
     __syncthreads();
     if (st != 0) return;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { o[0][i] += red[(qwv * 33 + i) * 64 + lane]; o[1][i] += red[(qwv * 33 + 16 + i) * 64 + lane]; }
-    l += red[(qwv * 33 + 32) * 64 + lane];
+    for (int s_ = 0; s_ < KS - 1; ++s_) {
+      const float* rr_ = red + (size_t)(s_ * QW + qwv) * 33 * 64;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] += rr_[i * 64 + lane]; o[1][i] += rr_[(16 + i) * 64 + lane]; }
+      l += rr_[32 * 64 + lane];
+    }
   }
   if (qrow >= Lq) return;
   l += __shfl_xor(l, 32);                          // the other half of the keys of every tile lives in lane ^ 32
@@ -975,6 +980,26 @@ __global__ __launch_bounds__(256) void qkv_eval_kernel(const bf16* __restrict__ 
   for (int n = 0; n < 2; ++n)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  // the rotation's table values depend on the lane only: requested FIRST, so that their round trip runs under the tile loads instead
+  // of behind the MFMAs (round 6: the launch is a latency chain, 129 of them make an evaluation)
+  const bool rope = cos_t != nullptr && s != 2;
+  const size_t tb = (size_t)pos * 64;
+  float tc0[16], ts0[16], tc1[16], ts1[16], tq0[16], tq1[16];
+  if (rope) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + 4 * h;
+      const float4 a0 = *(const float4*)(cos_t + tb + c), a1 = *(const float4*)(cos_t + tb + c + 32);
+      const float4 b0 = *(const float4*)(sin_t + tb + c), b1 = *(const float4*)(sin_t + tb + c + 32);
+      const float4 q0 = *(const float4*)(scale_t + tb + c), q1 = *(const float4*)(scale_t + tb + c + 32);
+      tc0[4 * g] = a0.x; tc0[4 * g + 1] = a0.y; tc0[4 * g + 2] = a0.z; tc0[4 * g + 3] = a0.w;
+      tc1[4 * g] = a1.x; tc1[4 * g + 1] = a1.y; tc1[4 * g + 2] = a1.z; tc1[4 * g + 3] = a1.w;
+      ts0[4 * g] = b0.x; ts0[4 * g + 1] = b0.y; ts0[4 * g + 2] = b0.z; ts0[4 * g + 3] = b0.w;
+      ts1[4 * g] = b1.x; ts1[4 * g + 1] = b1.y; ts1[4 * g + 2] = b1.z; ts1[4 * g + 3] = b1.w;
+      tq0[4 * g] = q0.x; tq0[4 * g + 1] = q0.y; tq0[4 * g + 2] = q0.z; tq0[4 * g + 3] = q0.w;
+      tq1[4 * g] = q1.x; tq1[4 * g + 1] = q1.y; tq1[4 * g + 2] = q1.z; tq1[4 * g + 3] = q1.w;
+    }
+  }
   for (int c0 = 0; c0 < C; c0 += KC) {
     if (c0) __syncthreads();
 #pragma unroll
@@ -1009,8 +1034,6 @@ __global__ __launch_bounds__(256) void qkv_eval_kernel(const bf16* __restrict__ 
   ss += __shfl_xor(ss, 32);
   const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
   if (tok >= M) return;
-  const bool rope = cos_t != nullptr && s != 2;
-  const size_t tb = (size_t)pos * 64;
   const long long dense = tok * C + hd * 64;
   const long long ring = (kv_tpb > 0) ? (tok / kv_tpb) * kv_bstride + (kv_off + tok % kv_tpb) * C + hd * 64 : dense;
 #pragma unroll
@@ -1024,9 +1047,9 @@ __global__ __launch_bounds__(256) void qkv_eval_kernel(const bf16* __restrict__ 
       plain[0][kk] = f2bf(u0); plain[1][kk] = f2bf(u1);
       float v0 = u0, v1 = u1;
       if (rope) {
-        v0 = u0 * cos_t[tb + c] - u1 * sin_t[tb + c];         // rotate_half: [-x2, x1]
-        v1 = u1 * cos_t[tb + c + 32] + u0 * sin_t[tb + c + 32];
-        const float s0 = scale_t[tb + c], s1 = scale_t[tb + c + 32];
+        v0 = u0 * tc0[i] - u1 * ts0[i];                       // rotate_half: [-x2, x1]
+        v1 = u1 * tc1[i] + u0 * ts1[i];
+        const float s0 = tq0[i], s1 = tq1[i];
         v0 = (s == 0) ? v0 * s0 : v0 / s0;
         v1 = (s == 0) ? v1 * s1 : v1 / s1;
       }
@@ -1280,6 +1303,15 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
     const long long nthr = (long long)d.a.B * d.a.heads * d.a.Lq * 8;
     ONIRIS_KLAUNCH(attn_split_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, stream,
                        (const float*)d.a.split_ws, (bf16*)d.a.out, d.a.lse, d.a.kv_splits, d.a.B, d.a.heads, d.a.Lq, d.a.C);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
+  // decode of a frame against a short ring (below the split-KV threshold): a handful of workgroups, each a serial walk over the key
+  // tiles (~0.5 us per tile: 13 us per layer at 18 cached frames, three times the launch floor) -- four key streams per workgroup
+  // of 32 query rows cut that walk by four inside ONE launch (round 6)
+  if (d.a.mask_mode == 0 && !(d.a.frame_kernel & 2) && d.a.Lk >= 256 && d.a.Lk > d.a.Lq &&
+      (long long)cdiv(d.a.Lq, 32) * d.a.heads * d.a.B <= 512) {
+    ONIRIS_KLAUNCH((attn_fwd_kernel<0, 4>), dim3(cdiv(d.a.Lq, 32), d.a.heads, d.a.B), dim3(256), 0, stream, d);
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }

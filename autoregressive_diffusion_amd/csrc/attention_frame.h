@@ -933,6 +933,6 @@ __global__ __launch_bounds__(512, 2) void frame_attn_qkv_bwd_kernel(const FrameQ
 
 // the frame kernels serve: dense (mask_mode 0), no table, no KV ring strides, no split-KV, Lq == Lk == P in {64, 128, 256}
 static inline bool frame_attn_ok(const OnirisAttnArgs& a) {
-  return a.frame_kernel == 0 && a.mask_mode == 0 && !a.kv_num && !a.sched && a.kv_splits <= 1 && a.k_bstride == 0 && a.v_bstride == 0 &&
+  return !(a.frame_kernel & 1) && a.mask_mode == 0 && !a.kv_num && !a.sched && a.kv_splits <= 1 && a.k_bstride == 0 && a.v_bstride == 0 &&
          a.Lq == a.Lk && (a.Lq == 64 || a.Lq == 128 || a.Lq == 256);
 }

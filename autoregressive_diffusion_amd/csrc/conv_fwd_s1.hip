@@ -33,6 +33,14 @@ int conv_dispatch_1x1(const OnirisConvArgs& a, hipStream_t st) {
     }
   }
   if (a.big_tile >= 3 && conv1x1_glds_ok(a)) return launch_conv1x1_glds(a, st);     // persistent LDS-DMA GEMM
+  // a handful of tiles (one generated frame of the cached sampler): 32-channel output tiles -- twice the workgroups, half the weight
+  // rows and MFMAs per K round and workgroup, the activation rounds of a two-source launch dealt to twice as many blocks; the launch
+  // is a latency chain, not a bandwidth problem (rollout 34.1 -> 34.9 frames/s, round 6).  Same K order per output: same bits.
+  // (Wider K rounds -- every load of the tile in flight at once -- were measured SLOWER: 8.1 -> 11.1 us per launch; the unrolled
+  // code of a 256-channel round is fetched through a cold instruction cache on every launch.)
+  // (from 768 input channels on the launch may be a split-K pair, whose slice count follows the tile count: left as it was)
+  if (!(a.big_tile & 64) && a.Cin < 768 && (long long)a.B * cdiv(a.T * a.H * a.W, 128) * (a.CoutP / 32) <= 256)
+    return launch_conv_fwd<1, 1, 64, 1, false, 16>(a, st);
   if (a.CoutP % 64 == 0) return launch_conv_fwd<1, 1, 64, 2, false, 16>(a, st);
   // 96 output channels (the 32 -> 96 dgrad of the 64x64-level skip conv): one workgroup per pixel tile instead of three
   // that re-read the same input rows (414 -> ~190 us at B = 8)

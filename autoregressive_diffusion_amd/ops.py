@@ -1627,13 +1627,18 @@ def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mo
         a.tab_cols, a.qtab_cols = idx.shape[1], qi.shape[1]
     a.B, a.heads, a.Lq, a.Lk, a.C = B, heads, Lq, Lk, C
     a.mask_mode, a.P, a.T = mask_mode, P, T
-    a.frame_kernel = 0 if FRAME_KERNEL else 1
+    a.frame_kernel = (0 if FRAME_KERNEL else 1) | (0 if DECODE_STREAMS else 2)
     return a
 
 
 # 1: dense attention inside frames of 64 / 128 / 256 tokens (FrameAttention, just_2d) on the whole-frame kernels of
 # csrc/attention_frame.h; 0: on the generic grid kernels (A/B, tests)
 FRAME_KERNEL = int(_os.environ.get("ONIRIS_FRAME_KERNEL", "1"))
+
+
+# 1: one new frame against a KV ring below the split-KV threshold walks its key tiles in four streams per workgroup (attn_fwd_kernel<0, 4>);
+# 0: one stream (rounds 1-5; A/B, tests)
+DECODE_STREAMS = int(_os.environ.get("ONIRIS_DECODE_STREAMS", "1"))
 
 
 FRAME_BWD_FUSED = int(_os.environ.get("ONIRIS_FRAME_BWD_FUSED", "1"))      # 0: attn_delta + dQ + dK/dV as three launches (A/B, tests)

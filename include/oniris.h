@@ -242,7 +242,8 @@ typedef struct OnirisConvArgs {
   int32_t big_tile;       /* variant: 0 = 4-wave register-staged kernels, 1/2 = 8-wave ones where they fill the chip /
                            * always, >= 3 = persistent LDS-DMA kernel (csrc/conv_glds.h) wherever the shape allows,   *
                            * >= 4 = + the streaming kernels of the 32-channel level (conv_stream.h, conv_plain_stream.h); *
-                           * diagnostic bits: 16 = no conv_eval1_kernel, 32 = copy issue of conv_glds at the phase start, 128 = no conv_plain_stream_kernel            */
+                           * diagnostic bits: 16 = no conv_eval1_kernel, 32 = copy issue of conv_glds at the phase start, 64 = 64-channel output tiles
+                           * in the few-tile 1x1 launches too (conv_fwd_s1.hip), 128 = no conv_plain_stream_kernel            */
   int32_t escale_pitch;   /* floats between consecutive rows of escale (0 = Cout): a UNet's emb-scales are column
                            * blocks of ONE [B*S*T][sum Cout] GEMM output, read in place                            */
   /* Optional split-K workspace (caller-allocated, reusable by consecutive launches on one stream): when given and
@@ -496,7 +497,9 @@ typedef struct OnirisAttnArgs {
   float* split_ws;
   /* frame_kernel (was padding): dense attention inside frames of 64 / 128 / 256 tokens (mask_mode 0, Lq == Lk, no table, no ring
    * strides, no split) runs on kernels of its own (csrc/attention_frame.h: one workgroup per 256 consecutive tokens of a head,
-   * K | V staged once); 1 = keep such launches on the generic grid kernels (A/B, tests).                                   */
+   * K | V staged once); bit 0 set = keep such launches on the generic grid kernels (A/B, tests).  Bit 1 (round 6): a mask_mode 0
+   * launch of at most 512 32-row query blocks against Lk >= 256 keys (one new frame against a KV ring below the split-KV
+   * threshold) runs four key streams per workgroup; Lk > Lq; bit 1 set = keep it on the one-stream kernel (A/B, tests).               */
   int32_t kv_splits, frame_kernel;
 } OnirisAttnArgs;
 

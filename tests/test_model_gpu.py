@@ -527,7 +527,10 @@ GYM_FULL = dict(img_resolution=64, img_channels=8, label_dim=4, model_channels=3
 # 0.07 % / 0.07 % / 0.03 %).  At BASELINE configs[1] itself (gym net, T = 64) every gate / emb_gain gradient that matters is
 # within 0.8 % of the oracle's: the error does not grow with the sequence length, it shrinks (more terms per sum).
 SCALAR_GRAD_BOUNDS = {"cs-shaped": (2.2e-2, 2.8e-3), "cs-full-net": (3.6e-2, 6e-4), "gym-full-net": (2.8e-2, 1.4e-3),
-                      "gym-full-net-T64": (1.6e-2, 1.4e-3), "cs-full-net-T32": (1.2e-2, 5.6e-4)}
+                      "gym-full-net-T64": (1.6e-2, 1.4e-3), "cs-full-net-T32": (1.2e-2, 5.6e-4),
+                      # the 2-D steps of the same nets, measured on their own (round 6: 0.91 % / 7.6e-4 and 1.20 % / 4.0e-4 -- the
+                      # second one had been passing under the 3-D step's 1.2 % by one part in 1e5); 2x the measured values like the rest
+                      "gym-full-net-T64/2d": (1.8e-2, 1.5e-3), "cs-full-net-T32/2d": (2.4e-2, 8e-4)}
 _full_net_oracle = {}     # (base tag, mode) -> the oracle's loss and gradients: the '+bench-variants' re-runs compare with the same result
 
 
@@ -628,10 +631,10 @@ def _full_net_asserts(tag, base, loss, ref_loss, prm, ref_grad, errs, labelled, 
     wo, wt = max(rel_own, key=rel_own.get), max(rel_top, key=rel_top.get)
     print(tag, f"scalar gradients ({len(sc)} parameters, {len(rel_own)} above 1 % of the largest): worst own-relative", wo, rel_own[wo],
           "median", float(np.median(list(rel_own.values()))), "; worst relative to the largest", wt, rel_top[wt])
-    bound_own, bound_top = SCALAR_GRAD_BOUNDS[base]
+    bound_own, bound_top = SCALAR_GRAD_BOUNDS[base + "/2d" if just_2d else base]
     if just_2d:
         # 2-D steps: the context path is off (out = y2, conv.py:60), so no gate scalar has a gradient -- emb_gain and out_gain do:
-        # same two-criterion form, bounds of the 3-D step of the same net
+        # same two-criterion form, bounds measured on the 2-D step
         assert all("gating" not in k or float(r.abs().max()) == 0 for k, (_, r) in sc.items()), [k for k in sc if "gating" in k]
     assert rel_own[wo] < bound_own and rel_top[wt] < bound_top, (wo, rel_own[wo], wt, rel_top[wt])
     if not labelled:

@@ -108,7 +108,10 @@ def test_weight_perm3():
                                             # 32 -> <= 32 channels with >= 512 tiles of 8x16 pixels: the plain streaming kernel
                                             # (conv_plain_stream.h; forward and data gradient): segments with a ragged last one,
                                             # an odd frame count, ragged Cout
-                                            (20, 64, 32, 32, 3), (70, 32, 32, 8, 3), (33, 64, 32, 24, 3)])
+                                            (20, 64, 32, 32, 3), (70, 32, 32, 8, 3), (33, 64, 32, 24, 3),
+                                            # few-tile 1x1 launches (one generated frame of the cached sampler)
+                                            (1, 8, 256, 256, 1), (1, 16, 384, 128, 1), (2, 16, 128, 128, 1), (1, 64, 96, 32, 1),
+                                            (1, 8, 768, 256, 1), (1, 32, 192, 64, 1)])
 def test_conv_plain(N, H, cin, cout, k):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(2)
@@ -599,8 +602,10 @@ def test_frame_attention_kernels_on_128_token_frames(N, P, m):
     assert e[0] < 1e-2 and e[1] < 2.5e-2
 
 
-def test_attention_eval_prefill_and_decode():
+@pytest.mark.parametrize("streams", [1, 0], ids=["four-key-streams", "one-key-stream"])
+def test_attention_eval_prefill_and_decode(streams, monkeypatch):
     from autoregressive_diffusion_amd import ops
+    monkeypatch.setattr(ops, "DECODE_STREAMS", streams)      # decode below the split-KV threshold: attn_fwd_kernel<0, 4> / <0, 1>
     torch.manual_seed(7)
     B, H, m = 2, 8, 1
     C, P = 64 * m, H * H
@@ -782,6 +787,33 @@ def test_conv_cat_act_matches_act_then_conv(N, H, C1, C2, cout):
     assert torch.equal(a, a_ref), "mp_silu(mp_cat) differs from the activation kernel's"
     assert torch.equal(y, y_ref), "1x1 conv of the concatenation differs from the two-launch form"
     assert float(y.float().abs().mean()) > 0.1
+
+
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("N,H,C1,C2,cout", [(1, 8, 256, 256, 256), (1, 16, 256, 128, 128), (1, 32, 64, 32, 64), (8, 8, 256, 256, 256),
+                                            (1, 64, 64, 32, 32)])
+def test_conv1x1_few_tiles_same_bits_on_both_tile_widths(N, H, C1, C2, cout, monkeypatch):
+    """The few-tile 1x1 launches run 32-channel output tiles (conv_fwd_s1.hip, round 6; big_tile bit 64 = the 64-channel tiles of
+    rounds 1-5): the K order of an output element is the same, so plain, attn_proj-epilogue and two-source launches -- whose
+    activation rounds are dealt to the output-channel blocks -- give the same bits."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(N + H + C1)
+    p = torch.nn.Parameter(O.normalize(O.normalize(torch.randn(cout, C1 + C2, 1, 1))).to(DEV))
+    bank, (pw,) = make_bank([p])
+    bank.prepare(training=False)
+    x = nhwc(bfr(torch.randn(N, C1, H, H) * 1.5))
+    skip = nhwc(bfr(torch.randn(N, C2, H, H)))
+    xc = torch.cat([x, skip], -1).contiguous()
+    res = nhwc(bfr(torch.randn(N, cout, H, H)))
+    outs = []
+    for bits in (0, 64):
+        monkeypatch.setattr(ops, "BIG_TILE", (ops.BIG_TILE & ~64) | bits)
+        with torch.no_grad():
+            y, a = ops.conv_cat_act(x, skip, 0.83, 1.21, pw)
+            outs.append((y, a, ops.conv(xc, pw), ops.conv(xc, pw, res=res, ta=0.8, tb=0.6, clip=2.0)))
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert float(outs[0][0].float().abs().mean()) > 0.1
 
 
 @pytest.mark.parametrize("f", [[1, 1], [1, 3, 3, 1], [1, 2, 3, 3, 2, 1], [2, 5]])
