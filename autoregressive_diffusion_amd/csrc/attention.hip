@@ -122,9 +122,9 @@ __device__ __forceinline__ void attn_block_decode(int& x, int& head, int& b) {
     const int xcd = L & 7, k = L >> 3;
     bh = xcd + 8 * (k / nx);
     x = k % nx;
-  } else {
-    bh = L / nx;
-    x = L % nx;
+  } else {                                           // (the grid's own coordinates: no division)
+    x = blockIdx.x; head = blockIdx.y; b = blockIdx.z;
+    return;
   }
   head = bh % gridDim.y;
   b = bh / gridDim.y;
@@ -153,11 +153,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   // kv_splits workgroups share a query block, each walks a contiguous range of its key tiles and leaves an un-normalised
   // partial (O, l) in split_ws; attn_split_reduce_kernel adds them (no running maximum here: partials simply add)
   const int nsp = (MODE == 0 && KS == 1 && a.kv_splits > 1) ? a.kv_splits : 1;
-  const int nqb = gridDim.x / nsp;
   int bx_, head, b;
   attn_block_decode(bx_, head, b);
-  const int sp = bx_ % nsp;
-  const int qbw = nqb - 1 - bx_ / nsp;             // heaviest (latest) query blocks first
+  const int nqb = (nsp == 1) ? (int)gridDim.x : (int)gridDim.x / nsp;
+  const int sp = (nsp == 1) ? 0 : bx_ % nsp;
+  const int qbw = nqb - 1 - ((nsp == 1) ? bx_ : bx_ / nsp);      // heaviest (latest) query blocks first
   const int C = a.C, Lq = a.Lq, Lk = a.Lk;
   const int qw0 = qbw * (32 * QW) + qwv * 32;
   const int qrow = qw0 + r;
@@ -231,7 +231,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnDev d) {
   };
 
   int bsel = 0;
-  const int sub0 = (int)((long long)nsub * sp / nsp), sub1 = (int)((long long)nsub * (sp + 1) / nsp);   // this split's tiles
+  const int sub0 = (nsp == 1) ? 0 : (int)((long long)nsub * sp / nsp);                    // this split's tiles
+  const int sub1 = (nsp == 1) ? nsub : (int)((long long)nsub * (sp + 1) / nsp);
   if (sub0 + st < sub1) issue(key_start(sub0 + st), 0);
   const int niter = (sub1 - sub0 + KS - 1) / KS;
 #pragma unroll 1
@@ -972,7 +973,9 @@ __global__ __launch_bounds__(256) void qkv_eval_kernel(const bf16* __restrict__ 
   __shared__ __attribute__((aligned(16))) unsigned char ws[64 * ROWB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
   const long long m0 = (long long)blockIdx.x * 128;
-  const int vi = blockIdx.y, hpc = C / 64, s = vi / hpc, hd = vi % hpc;
+  // (slot and head from the grid: a division by a run-time value is ~40 instructions in front of the first address of a launch that
+  // lasts 17 K cycles; round 6)
+  const int hd = blockIdx.y, s = blockIdx.z, vi = s * (int)gridDim.y + hd;
   const bf16* wrow = w + (size_t)vi * 64 * CinP;
   const int mrows = (M - m0 < 128) ? (int)(M - m0) : 128;    // rows beyond M are never read back by a valid token
   f32x16 acc[2];
@@ -1035,7 +1038,11 @@ __global__ __launch_bounds__(256) void qkv_eval_kernel(const bf16* __restrict__ 
   const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
   if (tok >= M) return;
   const long long dense = tok * C + hd * 64;
-  const long long ring = (kv_tpb > 0) ? (tok / kv_tpb) * kv_bstride + (kv_off + tok % kv_tpb) * C + hd * 64 : dense;
+  long long ring = dense;
+  if (kv_tpb > 0) {                                          // (one sequence: tok < kv_tpb, no 64-bit division on the way to the stores)
+    const long long sq = (tok < kv_tpb) ? 0 : tok / kv_tpb;
+    ring = sq * kv_bstride + (kv_off + tok - sq * kv_tpb) * C + hd * 64;
+  }
 #pragma unroll
   for (int g = 0; g < 4; ++g) {
     bf16x4 plain[2], rot[2];
@@ -1512,7 +1519,7 @@ extern "C" int oniris_qkv_eval(const void* x, const void* w, void* q, void* k, v
   ONIRIS_CHECK_ARG(kv_tokens_per_batch == 0 || (kv_tokens_per_batch > 0 && n_tokens % kv_tokens_per_batch == 0 &&
                                                 kv_batch_stride >= (kv_token_offset + kv_tokens_per_batch) * C),
                    "qkv_eval: bad KV ring geometry");
-  const dim3 grid((unsigned)((n_tokens + 127) / 128), (unsigned)(3 * C / 64));
+  const dim3 grid((unsigned)((n_tokens + 127) / 128), (unsigned)(C / 64), 3u);        // (x: token tile, y: head, z: q | k | v)
 #define QKV_EVAL_LAUNCH(KC_)                                                                                              \
   ONIRIS_KLAUNCH(qkv_eval_kernel<KC_>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)w, (bf16*)q, (bf16*)k,  \
                      (bf16*)v, (bf16*)kr, cos_t, sin_t, scale_t, (long long)n_tokens, C, CinP,                             \

@@ -29,6 +29,8 @@ struct Patch {
 struct ConvDev {
   OnirisConvArgs a;
   int ntx, nty, ntt, ncob;
+  int grid3d;            // conv_fwd_kernel, 1x1 without split-K: the grid is (position tile, batch element, channel block) -- no division
+                         // by a run-time value in front of the first address (a few-tile launch is a latency chain; round 6)
   int ksplit;            // > 1: the (chunk, phase) rounds of a tile are dealt to `ksplit` workgroups (conv_fwd_kernel)
   int reduce;            // 1: second launch of a split-K conv -- sum the slices' partials and run the epilogue
   int nt;                // conv_glds_kernel: outputs go out with non-temporal stores (tensors beyond oniris_ew_nt_bytes())
@@ -70,18 +72,22 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
   const int ks = d.ksplit, kz = (ks > 1 && !red) ? (int)(blockIdx.x % (unsigned)ks) : 0;
   const int tile_id = red ? (int)(blockIdx.x / (unsigned)NW) : (ks > 1) ? (int)(blockIdx.x / (unsigned)ks) : (int)blockIdx.x;
   int bid = tile_id;
-  int t0 = 0, y0 = 0, x0 = 0, q0 = 0;
-  if constexpr (TAPS == 9) {
-    const int tx = bid % d.ntx; bid /= d.ntx;
-    const int ty = bid % d.nty; bid /= d.nty;
-    const int tc = bid % d.ntt; bid /= d.ntt;
-    t0 = tc * P::FT; y0 = ty * P::PH; x0 = tx * P::PW;
+  int t0 = 0, y0 = 0, x0 = 0, q0 = 0, b, co0;
+  if (TAPS == 1 && d.grid3d) {
+    q0 = (int)blockIdx.x * NPOS; b = (int)blockIdx.y; co0 = (int)blockIdx.z * BN;
   } else {
-    const int tq = bid % d.ntt; bid /= d.ntt;      // ntt = number of 128-position tiles per (b,s)
-    q0 = tq * NPOS;
+    if constexpr (TAPS == 9) {
+      const int tx = bid % d.ntx; bid /= d.ntx;
+      const int ty = bid % d.nty; bid /= d.nty;
+      const int tc = bid % d.ntt; bid /= d.ntt;
+      t0 = tc * P::FT; y0 = ty * P::PH; x0 = tx * P::PW;
+    } else {
+      const int tq = bid % d.ntt; bid /= d.ntt;      // ntt = number of 128-position tiles per (b,s)
+      q0 = tq * NPOS;
+    }
+    b = bid % a.B;
+    co0 = (bid / a.B) * BN;
   }
-  const int b = bid % a.B;
-  const int co0 = (bid / a.B) * BN;
 
   // ---- this lane's position.  For 16-wide patches the 32 positions of a wave (2 patch rows x 16 px) are dealt to
   // the lanes so that each 16-lane group of a ds_read_b128 ({0-3,12-15,20-27} / {4-11,16-19,28-31}) reads 16
@@ -382,7 +388,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8) ? 2 : 2) void conv_fwd_kernel(co
   } else {
     const int q = q0 + p;
     valid = q < T * HWp;
-    tloc = valid ? q / HWp : 0;
+    tloc = (valid && q >= HWp) ? q / HWp : 0;
     pix = (size_t)q;
   }
   constexpr int EROW = BN * 2 + 16;
@@ -505,7 +511,7 @@ static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
   long long nblk = (long long)d.ntx * d.nty * d.ntt * a.B * d.ncob;
   if (nblk <= 0 || nblk > 0x7fffffffLL) { oniris_set_error("conv_fwd: bad grid %lld", nblk); return ONIRIS_EINVAL; }
   // split-K when the caller lent a workspace and the tiles alone leave most of the chip idle
-  d.ksplit = 1; d.reduce = 0;
+  d.ksplit = 1; d.reduce = 0; d.grid3d = 0;
   const long long ntile = nblk;
   if (a.splitk_ws && nblk <= 64) {
     const int nphase = cdiv(a.Cin, CK) * (HAS_CTX ? 3 : 1);
@@ -521,6 +527,12 @@ static int launch_conv_fwd(const OnirisConvArgs& a, hipStream_t stream) {
     if (ks > 1) { d.ksplit = (int)ks; nblk *= ks; }
   }
   auto kern = conv_fwd_kernel<S, TAPS, CK, NT, HAS_CTX, PW, NW>;
+  if (TAPS == 1 && d.ksplit == 1 && a.B <= 65535 && d.ncob <= 65535) {
+    d.grid3d = 1;
+    ONIRIS_KLAUNCH(kern, dim3((unsigned)d.ntt, (unsigned)a.B, (unsigned)d.ncob), dim3(Cfg::NTHR), 0, stream, d);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
   ONIRIS_KLAUNCH(kern, dim3((unsigned)nblk), dim3(Cfg::NTHR), 0, stream, d);
   if (d.ksplit > 1) {
     ONIRIS_LAUNCH_CHECK();

@@ -263,6 +263,41 @@ def test_gated_conv_eval_one_frame_splitk(B, H, cin, cout, epi, monkeypatch):
     assert d <= 2.0 ** -6 * max(1.0, float(outs[0].abs().max()))          # one bf16 ulp of the largest value
 
 
+@pytest.mark.selfcheck
+@pytest.mark.parametrize("B,H,cin,cout,epi", [(1, 8, 256, 256, "silu"), (2, 16, 128, 128, "mpsum"), (1, 8, 512, 256, "none"),
+                                              (8, 8, 256, 256, "mpsum"), (1, 16, 384, 136, "silu")])
+def test_one_frame_conv_same_bits_with_16_and_32_channel_workgroups(B, H, cin, cout, epi, monkeypatch):
+    """conv_eval1_kernel<16> (few workgroups, long reduction: round 6) against conv_eval1_kernel<32> (big_tile bit 256): the (tap, k-step)
+    products are dealt to the waves the same way and the partial tiles are added in the same order, so the same bits -- with the
+    context product stored (mode 1) and read back (mode 2) across the two."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(cin + H + B)
+    p2 = torch.nn.Parameter(torch.randn(cout, cin, 3, 3).to(DEV)); p3 = torch.nn.Parameter(torch.randn(cout, cin, 2, 3, 3).to(DEV))
+    bank, (pw2, pw3) = make_bank([p2, p3])
+    bank.prepare(training=False)
+    x = nhwc(bfr(torch.randn(B, cin, H, H)))
+    pad = bfr(torch.randn(B, cin, 2, H, H)).permute(0, 2, 3, 4, 1).to(DEV, torch.bfloat16).contiguous()
+    g = (torch.rand(B) * 0.6 + 0.05).to(DEV)
+    kw = {}
+    if epi == "silu":
+        kw = dict(cscale=(torch.rand(B, cout) + 0.5).to(DEV))
+    elif epi == "mpsum":
+        kw = dict(res=nhwc(bfr(torch.randn(B, cout, H, H))), ta=0.7, tb=0.5, clip=2.0)
+    Co = ops.roundup(cout, 8)
+    outs = []
+    for bits in (0, 256):
+        monkeypatch.setattr(ops, "BIG_TILE", (ops.BIG_TILE & ~256) | bits)
+        kept = torch.full((B, H, H, Co), float("nan"), device=DEV)
+        plain = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, **kw)
+        stored = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, ctx_prod=kept, ctx_prod_mode=1, **kw)
+        outs.append((plain, stored, kept))
+    monkeypatch.setattr(ops, "BIG_TILE", ops.BIG_TILE & ~256)
+    read = ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, ctx_prod=outs[1][2], ctx_prod_mode=2, **kw)    # 16-channel launch reads the 32-channel launch's product
+    for u, v in zip(*outs):
+        assert torch.equal(u, v)
+    assert torch.equal(read, outs[0][0]) and bool(torch.isfinite(read.float()).all())
+
+
 @pytest.mark.parametrize("B,H,cin,cout,epi", [(1, 8, 256, 256, "silu"), (2, 16, 128, 128, "mpsum"), (3, 32, 64, 64, "none"),
                                               (1, 8, 96, 160, "mpsum"), (2, 64, 32, 32, "silu"), (1, 16, 512, 24, "none")])
 def test_one_frame_conv_kept_context_product(B, H, cin, cout, epi):
