@@ -39,8 +39,15 @@ int conv_dispatch_1x1(const OnirisConvArgs& a, hipStream_t st) {
   // (Wider K rounds -- every load of the tile in flight at once -- were measured SLOWER: 8.1 -> 11.1 us per launch; the unrolled
   // code of a 256-channel round is fetched through a cold instruction cache on every launch.)
   // (from 768 input channels on the launch may be a split-K pair, whose slice count follows the tile count: left as it was)
-  if (!(a.big_tile & 64) && a.Cin < 768 && (long long)a.B * cdiv(a.T * a.H * a.W, 128) * (a.CoutP / 32) <= 256)
+  if (!(a.big_tile & 64) && a.Cin < 768 && (long long)a.B * cdiv(a.T * a.H * a.W, 128) * (a.CoutP / 32) <= 256) {
+    // ... and 32- or 64-position tiles (one / two waves) while that still leaves at most one workgroup per CU: a workgroup pulls its
+    // x rows and weight rows at the per-CU streaming rate (~20 B / clock), 128 rows x 256 channels are 64 KB = 1.4 us by themselves
+    // (38.0 -> 38.7 frames/s)
+    const long long per32 = (long long)a.B * (a.CoutP / 32);
+    if (per32 * cdiv(a.T * a.H * a.W, 32) <= 256) return launch_conv_fwd<1, 1, 64, 1, false, 16, 1>(a, st);
+    if (per32 * cdiv(a.T * a.H * a.W, 64) <= 256) return launch_conv_fwd<1, 1, 64, 1, false, 16, 2>(a, st);
     return launch_conv_fwd<1, 1, 64, 1, false, 16>(a, st);
+  }
   if (a.CoutP % 64 == 0) return launch_conv_fwd<1, 1, 64, 2, false, 16>(a, st);
   // 96 output channels (the 32 -> 96 dgrad of the 64x64-level skip conv): one workgroup per pixel tile instead of three
   // that re-read the same input rows (414 -> ~190 us at B = 8)
