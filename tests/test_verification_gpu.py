@@ -449,7 +449,10 @@ def test_plain_conv_weight_gradient_integer_exact(N, H, cin, cout, k, dens):
     assert e <= 2e-6 and worst <= 1e-5
 
 
-@pytest.mark.parametrize("B,P,m,nk,kind", [(1, 64, 4, 10, "decode"), (2, 64, 4, 40, "decode"), (1, 256, 2, 12, "decode"), (2, 64, 2, 6, "prefill")])
+@pytest.mark.parametrize("B,P,m,nk,kind", [(1, 64, 4, 10, "decode"), (2, 64, 4, 40, "decode"), (1, 256, 2, 12, "decode"), (2, 64, 2, 6, "prefill"),
+                                           # ragged shapes through the four-stream decode kernel: 40 query rows (an 8-row second block),
+                                           # 360 keys (a 40-key last tile, streams with unequal tile counts); 16-token frames
+                                           (1, 40, 2, 9, "decode"), (3, 16, 1, 20, "decode")])
 def test_attention_eval_kernels_bf16_faithful(B, P, m, nk, kind):
     """The sampler's attention launches on prepared q, k, v: one new frame against nk cached frames (dense; from 2048 keys on the key
     tiles are dealt to several workgroups whose un-normalised partials are added: OnirisAttnArgs.kv_splits) and the causal prefill
