@@ -111,7 +111,9 @@ def test_weight_perm3():
                                             (20, 64, 32, 32, 3), (70, 32, 32, 8, 3), (33, 64, 32, 24, 3),
                                             # few-tile 1x1 launches (one generated frame of the cached sampler)
                                             (1, 8, 256, 256, 1), (1, 16, 384, 128, 1), (2, 16, 128, 128, 1), (1, 64, 96, 32, 1),
-                                            (1, 8, 768, 256, 1), (1, 32, 192, 64, 1)])
+                                            (1, 8, 768, 256, 1), (1, 32, 192, 64, 1),
+                                            # ... with a ragged last 32- / 64-position tile (36 and 100 positions per image)
+                                            (1, 6, 128, 64, 1), (2, 10, 64, 32, 1), (5, 10, 192, 96, 1)])
 def test_conv_plain(N, H, cin, cout, k):
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(2)
