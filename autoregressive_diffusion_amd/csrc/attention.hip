@@ -1295,7 +1295,11 @@ extern "C" int oniris_attn_fwd(const OnirisAttnArgs* args, oniris_stream_t strea
   if (frame_attn_ok(d.a)) {                          // dense attention inside frames of 64 / 128 / 256 tokens (attention_frame.h)
     FrameAttnDev f{d.a, (long long)d.a.B * d.a.Lq, d.a.Lq / 64};
     ONIRIS_CHECK_ARG((f.ntok + 255) / 256 < (1LL << 31), "attn_fwd: too many tokens");
-    oniris_launch(frame_attn_fwd_kernel, dim3((unsigned)((f.ntok + 255) / 256), d.a.heads), dim3(256), stream, f);
+    const long long nsb = (f.ntok + 255) / 256;
+    if (d.a.Lq == 256 && nsb * d.a.heads <= 64 && !(d.a.frame_kernel & 4))         // few 256-token frames: two query halves per frame
+      oniris_launch(frame_attn_fwd_kernel<1>, dim3((unsigned)(2 * nsb), d.a.heads), dim3(256), stream, f);
+    else
+      oniris_launch(frame_attn_fwd_kernel<2>, dim3((unsigned)nsb, d.a.heads), dim3(256), stream, f);
     ONIRIS_LAUNCH_CHECK();
     return ONIRIS_OK;
   }

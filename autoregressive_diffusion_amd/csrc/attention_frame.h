@@ -49,6 +49,10 @@ __device__ __forceinline__ void frame_burst(const bf16* g0, const bf16* g1, long
   }
 }
 
+// J = 32-row query blocks per wave: 2 = a workgroup per 256 tokens (training); 1 = a workgroup per 128 tokens of a 256-token frame
+// (round 6: one frame per sequence in the cached sampler is heads workgroups -- two query halves per frame put the launch on twice the
+// CUs with half the MFMA / softmax chain each; K | V of the frame are staged by both)
+template <int J>
 __global__ __launch_bounds__(256, 2) void frame_attn_fwd_kernel(const FrameAttnDev d) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int TB = 64 * 128;
@@ -56,14 +60,15 @@ __global__ __launch_bounds__(256, 2) void frame_attn_fwd_kernel(const FrameAttnD
   const OnirisAttnArgs& a = d.a;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
   const int head = blockIdx.y, C = a.C, P = a.Lq;
-  const long long tok0 = (long long)blockIdx.x * 256;
+  const long long tok0 = (long long)(blockIdx.x / (2 / J)) * 256;            // the 256-token block whose K | V are staged
+  const int qoff = (J == 2) ? 0 : (int)(blockIdx.x & 1) * 128;               // ... and this workgroup's query rows inside it
   const unsigned lds0 = (unsigned)(size_t)(lds_void_t*)smem;
   // Q fragments first (ordinary loads), consumed before any LDS-DMA is in flight
   const bf16* qg = (const bf16*)a.q + head * 64;
-  bf16x8 qf[2][4];
+  bf16x8 qf[J][4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long long qrow = tok0 + wave * 64 + j * 32 + r;
+  for (int j = 0; j < J; ++j) {
+    const long long qrow = tok0 + qoff + wave * (32 * J) + j * 32 + r;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       u32x4 v = u32x4{0u, 0u, 0u, 0u};
@@ -72,12 +77,14 @@ __global__ __launch_bounds__(256, 2) void frame_attn_fwd_kernel(const FrameAttnD
     }
   }
   frame_burst<0, 1>((const bf16*)a.k, (const bf16*)a.v, tok0, d.ntok, C, head, lds0, tid);
-  f32x16 o[2][2];
+  f32x16 o[J][2];
+  float l2[J][2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < J; ++j) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o[j][0][i] = 0.f; o[j][1][i] = 0.f; }
-  float l2[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    l2[j][0] = 0.f; l2[j][1] = 0.f;
+  }
   const int kb0 = r * 128 + ((h ^ ((r >> 1) & 7)) << 4);
   const int grp = lane >> 4, hh = grp >> 1, q4 = (lane & 15) >> 2, pcol = (lane & 3) * 4 + 16 * (grp & 1);
   const int vb0 = (4 * hh + q4) * 128 + pcol * 2, vsw = (q4 >> 1) & 1;
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(256, 2) void frame_attn_fwd_kernel(const FrameAttnD
   };
   dma_wait();
   __syncthreads();
-  const int t0 = ((wave * 64) / P) * d.tiles;              // first key tile of this wave's frame inside the super-block
+  const int t0 = ((qoff + wave * (32 * J)) / P) * d.tiles;  // first key tile of this wave's frame inside the super-block
 #pragma unroll 1
   for (int t = t0; t < t0 + d.tiles; ++t) {
     const unsigned char* Kt = smem + t * 2 * TB;
@@ -111,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void frame_attn_fwd_kernel(const FrameAttnD
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) vf[kt][s2][dt] = vtr(Vt, kt * 32 + 16 * s2, dt);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
+    for (int j = 0; j < J; ++j) {
       f32x16 s[2];
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt) {
@@ -139,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void frame_attn_fwd_kernel(const FrameAttnD
     }
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const long long qrow = tok0 + wave * 64 + j * 32 + r;
+  for (int j = 0; j < J; ++j) {
+    const long long qrow = tok0 + qoff + wave * (32 * J) + j * 32 + r;
     float l = l2[j][0] + l2[j][1];
     l += __shfl_xor(l, 32);
     if (qrow >= d.ntok) continue;

@@ -1627,7 +1627,7 @@ def _attn_args(q, k, v, qt, kt, vt, out, lse, tabs, B, heads, Lq, Lk, C, mask_mo
         a.tab_cols, a.qtab_cols = idx.shape[1], qi.shape[1]
     a.B, a.heads, a.Lq, a.Lk, a.C = B, heads, Lq, Lk, C
     a.mask_mode, a.P, a.T = mask_mode, P, T
-    a.frame_kernel = (0 if FRAME_KERNEL else 1) | (0 if DECODE_STREAMS else 2)
+    a.frame_kernel = (0 if FRAME_KERNEL else 1) | (0 if DECODE_STREAMS else 2) | (0 if FRAME_FWD_HALVES else 4)
     return a
 
 
@@ -1639,6 +1639,11 @@ FRAME_KERNEL = int(_os.environ.get("ONIRIS_FRAME_KERNEL", "1"))
 # 1: one new frame against a KV ring below the split-KV threshold walks its key tiles in four streams per workgroup (attn_fwd_kernel<0, 4>);
 # 0: one stream (rounds 1-5; A/B, tests)
 DECODE_STREAMS = int(_os.environ.get("ONIRIS_DECODE_STREAMS", "1"))
+
+
+# 1: a forward launch over a few 256-token frames (one frame per sequence in the cached sampler) runs two query halves per frame
+# (frame_attn_fwd_kernel<1>); 0: one workgroup per frame and head (A/B, tests)
+FRAME_FWD_HALVES = int(_os.environ.get("ONIRIS_FRAME_FWD_HALVES", "1"))
 
 
 FRAME_BWD_FUSED = int(_os.environ.get("ONIRIS_FRAME_BWD_FUSED", "1"))      # 0: attn_delta + dQ + dK/dV as three launches (A/B, tests)

@@ -500,7 +500,8 @@ typedef struct OnirisAttnArgs {
    * strides, no split) runs on kernels of its own (csrc/attention_frame.h: one workgroup per 256 consecutive tokens of a head,
    * K | V staged once); bit 0 set = keep such launches on the generic grid kernels (A/B, tests).  Bit 1 (round 6): a mask_mode 0
    * launch of at most 512 32-row query blocks against Lk >= 256 keys (one new frame against a KV ring below the split-KV
-   * threshold) runs four key streams per workgroup; Lk > Lq; bit 1 set = keep it on the one-stream kernel (A/B, tests).               */
+   * threshold) runs four key streams per workgroup; Lk > Lq; bit 1 set = keep it on the one-stream kernel (A/B, tests).  Bit 2 (round 6): a
+   * forward launch over at most 64 (frame, head) pairs of 256 tokens runs two query halves per frame; bit 2 set = one workgroup per pair.   */
   int32_t kv_splits, frame_kernel;
 } OnirisAttnArgs;
 

@@ -826,6 +826,31 @@ def test_conv_cat_act_matches_act_then_conv(N, H, C1, C2, cout):
     assert float(y.float().abs().mean()) > 0.1
 
 
+@pytest.mark.parametrize("N,m", [(1, 2), (3, 2), (8, 4), (33, 1)])
+def test_frame_attention_eval_query_halves(N, m, monkeypatch):
+    """FrameAttention of a few 256-token frames without autograd (the 16x16 level of the cached sampler): two query halves per frame
+    (frame_attn_fwd_kernel<1>, round 6) give the bits of the one-workgroup-per-frame launch, and the oracle's SDPA within 1e-2."""
+    from autoregressive_diffusion_amd import ops
+    torch.manual_seed(N + m)
+    C, H = 64 * m, 16
+    p = torch.nn.Parameter(O.normalize(O.normalize(torch.randn(3 * C, C, 1, 1))).to(DEV))
+    bank, (pw,) = make_bank([p], perm3=True)                 # (attn_qkv: packed rows (m c s) -> (s m c), attention_modules.py)
+    bank.prepare(training=False)
+    x0 = bfr(torch.randn(N, C, H, H))
+    outs = []
+    for halves in (1, 0):
+        monkeypatch.setattr(ops, "FRAME_FWD_HALVES", halves)
+        with torch.no_grad():
+            outs.append(ops.frame_attention_eval(nhwc(x0), pw, m))
+    assert torch.equal(outs[0], outs[1])
+    w_eff, _ = O.weight_effective(p.detach().float().cpu(), 1.0, False)
+    q, k, v = O._split_qkv(torch.nn.functional.conv2d(x0, w_eff), m)                    # (N, m, P, 64), normalised
+    ref = torch.nn.functional.scaled_dot_product_attention(q, k, v).transpose(2, 3).reshape(N, C, H, H)
+    e = rel(nchw(outs[0].reshape(N, H, H, C)), ref)
+    print("frame attention eval", (N, m), "rel", e)
+    assert e < 1e-2
+
+
 @pytest.mark.selfcheck
 @pytest.mark.parametrize("N,H,C1,C2,cout", [(1, 8, 256, 256, 256), (1, 16, 256, 128, 128), (1, 32, 64, 32, 64), (8, 8, 256, 256, 256),
                                             (1, 64, 64, 32, 32)])
