@@ -29,7 +29,7 @@
 #include "conv_kernels.h"
 #include "lds_dma.h"
 
-// CO = output channels per workgroup: 32, or 16 for the launches of a handful of workgroups with a long reduction (round 6).  A loader
+// CO = output channels per workgroup: 32, or 16 for the launches of a handful of workgroups (round 6).  A loader
 // wave's LDS-DMA instruction moves 1 KB and the four of them get one out per ~50 cycles (the CU's address path: 20 B / clock, the
 // per-CU streaming rate of MI355X_MICROARCH.md), so a phase of 8 halo + 18 weight instructions is 1.3-1.5 K cycles however the MFMAs
 // are arranged (scratch/r06_eval1_stamp.py); with 16 channels it is 8 + 9 on twice the CUs.  The MFMA keeps its 32 rows: lanes 16..31
@@ -390,9 +390,9 @@ static int launch_conv_eval1_co(const OnirisConvArgs& a, hipStream_t stream) {
 }
 
 static int launch_conv_eval1(const OnirisConvArgs& a, hipStream_t stream) {
-  // 16 output channels per workgroup where 32 would leave the launch on <= 128 CUs with four or more 32-channel phases each
-  // (the 8x8 / 16x16 levels of one sequence: 8 / 16 workgroups walking 4 .. 16 phases); big_tile bit 256 = always 32 (A/B, tests)
+  // 16 output channels per workgroup wherever 32 would leave the launch on <= 128 CUs (every level of one sequence: 8 .. 64
+  // workgroups; 39.2 -> 40.4 frames/s against doing it from 128 input channels on only); big_tile bit 256 = always 32 (A/B, tests)
   const long long wg32 = (long long)(a.CoutP / 32) * (a.W / 8) * (a.H / 8) * a.B;
-  if (wg32 <= 128 && a.Cin >= 128 && !(a.big_tile & 256)) return launch_conv_eval1_co<16>(a, stream);
+  if (wg32 <= 128 && !(a.big_tile & 256)) return launch_conv_eval1_co<16>(a, stream);
   return launch_conv_eval1_co<32>(a, stream);
 }

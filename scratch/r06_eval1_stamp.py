@@ -21,7 +21,7 @@ for (H, cin, cout) in [(8, 256, 256), (16, 128, 128), (32, 64, 64)]:
     res = nhwc(bfr(torch.randn(B, cout, H, H)))
     kept = torch.zeros(B, H, H, cout, device=DEV)
     ops.gated_conv_eval(x, g, pw2, pw3, B, 1, pad, ctx_T=2, ctx_prod=kept, ctx_prod_mode=1, res=res, ta=0.7, tb=0.5, clip=2.0)
-    co = 16 if ((cout // 32) * (H // 8) ** 2 <= 128 and cin >= 128 and not (ops.BIG_TILE & 256)) else 32      # launch_conv_eval1's rule
+    co = 16 if ((cout // 32) * (H // 8) ** 2 <= 128 and not (ops.BIG_TILE & 256)) else 32      # launch_conv_eval1's rule
     nwg = (H // 8) ** 2 * (cout // co)
     st = torch.zeros(nwg, 40, dtype=torch.int64, device=DEV)
     real = ops._conv_launch

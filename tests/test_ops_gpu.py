@@ -222,7 +222,9 @@ def test_gated_conv_eval_matches_oracle():
 
 
 @pytest.mark.parametrize("B,H,cin,cout,epi", [(1, 8, 256, 256, "silu"), (1, 16, 128, 128, "mpsum"), (2, 32, 64, 64, "none"),
-                                              (1, 8, 96, 160, "mpsum"), (1, 64, 32, 32, "silu"), (3, 4, 128, 64, "none")])
+                                              (1, 8, 96, 160, "mpsum"), (1, 64, 32, 32, "silu"), (3, 4, 128, 64, "none"),
+                                              # more than 128 32-channel tiles: conv_eval1_kernel<32> (fewer run <16>)
+                                              (4, 64, 32, 32, "mpsum"), (3, 32, 64, 96, "silu")])
 def test_gated_conv_eval_one_frame_splitk(B, H, cin, cout, epi, monkeypatch):
     """One generated frame per sequence (the sampler's shape): the context pair comes straight from the cache tensor
     and the K loop of the few tiles is split over workgroups (OnirisConvArgs.splitk_ws).  Checked against the fp32
@@ -301,7 +303,8 @@ def test_one_frame_conv_same_bits_with_16_and_32_channel_workgroups(B, H, cin, c
 
 
 @pytest.mark.parametrize("B,H,cin,cout,epi", [(1, 8, 256, 256, "silu"), (2, 16, 128, 128, "mpsum"), (3, 32, 64, 64, "none"),
-                                              (1, 8, 96, 160, "mpsum"), (2, 64, 32, 32, "silu"), (1, 16, 512, 24, "none")])
+                                              (1, 8, 96, 160, "mpsum"), (2, 64, 32, 32, "silu"), (1, 16, 512, 24, "none"),
+                                              (5, 64, 32, 32, "none"), (3, 32, 64, 96, "mpsum")])      # (conv_eval1_kernel<32>)
 def test_one_frame_conv_kept_context_product(B, H, cin, cout, epi):
     """OnirisConvArgs.ctx_prod (ABI 11): the context product of the cached pair stored by an all-phases launch (mode 1) or by
     the context-phases-only launch (mode 3), and read back by own-phases-only launches (mode 2) -- all BIT-identical to the
