@@ -2,6 +2,7 @@
 #include "conv_glds.h"
 #include "conv1x1_glds.h"
 #include "conv_plain_stream.h"
+#include "conv1x1_few.h"
 
 // Plain 3x3 convs (the 2-D training steps, stem / non-gated layers): with big_tile >= 3 and an even frame count they
 // run on the persistent LDS-DMA kernel as "two slots of T/2 frames, no context phases".
@@ -33,6 +34,8 @@ int conv_dispatch_1x1(const OnirisConvArgs& a, hipStream_t st) {
     }
   }
   if (a.big_tile >= 3 && conv1x1_glds_ok(a)) return launch_conv1x1_glds(a, st);     // persistent LDS-DMA GEMM
+  // at most one 32 x 32 tile per CU: the four waves of a workgroup split the K of one tile (conv1x1_few.h; big_tile bit 512: off)
+  if (!(a.big_tile & (64 | 512)) && conv1x1_few_ok(a)) return launch_conv1x1_few(a, st);
   // a handful of tiles (one generated frame of the cached sampler): 32-channel output tiles -- twice the workgroups, half the weight
   // rows and MFMAs per K round and workgroup, the activation rounds of a two-source launch dealt to twice as many blocks; the launch
   // is a latency chain, not a bandwidth problem (rollout 34.1 -> 34.9 frames/s, round 6).  Same K order per output: same bits.

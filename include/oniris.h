@@ -244,7 +244,8 @@ typedef struct OnirisConvArgs {
                            * >= 4 = + the streaming kernels of the 32-channel level (conv_stream.h, conv_plain_stream.h); *
                            * diagnostic bits: 16 = no conv_eval1_kernel, 32 = copy issue of conv_glds at the phase start, 64 = 64-channel output tiles
                            * in the few-tile 1x1 launches too (conv_fwd_s1.hip), 128 = no conv_plain_stream_kernel, 256 = conv_eval1_kernel
-                           * always with 32 output channels per workgroup (csrc/conv_eval1.h)            */
+                           * always with 32 output channels per workgroup (csrc/conv_eval1.h), 512 = no conv1x1_few_kernel (the few-tile
+                           * 1x1 launches on conv_fwd_kernel's 32-channel tiles)            */
   int32_t escale_pitch;   /* floats between consecutive rows of escale (0 = Cout): a UNet's emb-scales are column
                            * blocks of ONE [B*S*T][sum Cout] GEMM output, read in place                            */
   /* Optional split-K workspace (caller-allocated, reusable by consecutive launches on one stream): when given and

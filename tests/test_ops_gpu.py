@@ -858,9 +858,11 @@ def test_frame_attention_eval_query_halves(N, m, monkeypatch):
 @pytest.mark.parametrize("N,H,C1,C2,cout", [(1, 8, 256, 256, 256), (1, 16, 256, 128, 128), (1, 32, 64, 32, 64), (8, 8, 256, 256, 256),
                                             (1, 64, 64, 32, 32)])
 def test_conv1x1_few_tiles_same_bits_on_both_tile_widths(N, H, C1, C2, cout, monkeypatch):
-    """The few-tile 1x1 launches run 32-channel output tiles (conv_fwd_s1.hip, round 6; big_tile bit 64 = the 64-channel tiles of
-    rounds 1-5): the K order of an output element is the same, so plain, attn_proj-epilogue and two-source launches -- whose
-    activation rounds are dealt to the output-channel blocks -- give the same bits."""
+    """The few-tile 1x1 launches on conv_fwd_kernel (round 6): 32-channel x 32- / 64-position tiles (big_tile bit 512) against the
+    64-channel x 128-position tiles of rounds 1-5 (bit 64) -- the K order of an output element is the same, so plain, attn_proj-epilogue
+    and two-source launches, whose activation rounds are dealt to the output-channel blocks, give the same bits.  The default,
+    conv1x1_few_kernel (four waves split the K of one tile), sums in another order: the activation output is the same bits, the conv
+    outputs agree to the bf16 rounding of a sum of four fp32 partials."""
     from autoregressive_diffusion_amd import ops
     torch.manual_seed(N + H + C1)
     p = torch.nn.Parameter(O.normalize(O.normalize(torch.randn(cout, C1 + C2, 1, 1))).to(DEV))
@@ -871,13 +873,17 @@ def test_conv1x1_few_tiles_same_bits_on_both_tile_widths(N, H, C1, C2, cout, mon
     xc = torch.cat([x, skip], -1).contiguous()
     res = nhwc(bfr(torch.randn(N, cout, H, H)))
     outs = []
-    for bits in (0, 64):
-        monkeypatch.setattr(ops, "BIG_TILE", (ops.BIG_TILE & ~64) | bits)
+    for bits in (512, 64, 0):
+        monkeypatch.setattr(ops, "BIG_TILE", (ops.BIG_TILE & ~(64 | 512)) | bits)
         with torch.no_grad():
             y, a = ops.conv_cat_act(x, skip, 0.83, 1.21, pw)
             outs.append((y, a, ops.conv(xc, pw), ops.conv(xc, pw, res=res, ta=0.8, tb=0.6, clip=2.0)))
-    for u, v in zip(*outs):
+    for u, v in zip(outs[0], outs[1]):
         assert torch.equal(u, v)
+    assert torch.equal(outs[2][1], outs[0][1])                                   # mp_silu(mp_cat): no sum in it
+    for u, v in zip(outs[2], outs[0]):
+        d = (u.float() - v.float()).abs().max().item()
+        assert d <= 2.0 ** -7 * max(1.0, float(v.float().abs().max())), d          # one bf16 ulp of the largest value
     assert float(outs[0][0].float().abs().mean()) > 0.1
 
 
