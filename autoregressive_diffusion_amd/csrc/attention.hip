@@ -373,6 +373,7 @@ __global__ void attn_split_reduce_kernel(const float* __restrict__ ws, bf16* __r
   if (lse && part == 0) lse[row] = SOFTMAX_OFF + log2f(fmaxf(l, 1e-30f));
 }
 
+#include <cstdlib>
 #include "attention_ws.h"
 #include "attention_frame.h"
 
@@ -1074,6 +1075,125 @@ __global__ __launch_bounds__(256) void qkv_eval_kernel(const bf16* __restrict__ 
   }
 }
 
+// qkv_eval_kernel for a FEW tiles (one frame per sequence in the cached sampler; round 6, after conv1x1_few.h): a workgroup owns 32 tokens x
+// the 64 channels of one (slot, head) and its four waves split the K -- wave w takes the 64-channel rounds w, w + 4, ... with every operand
+// loaded global -> registers in MFMA fragment layout (no LDS staging, no barrier in the K loop); the partial tiles meet in LDS once and
+// wave 0 runs the epilogue of qkv_eval_kernel (same operations, same order; the conv result sums K in another order).
+__global__ __launch_bounds__(256) void qkv_eval_few_kernel(const bf16* __restrict__ x, const bf16* __restrict__ w,
+                                                           bf16* __restrict__ q, bf16* __restrict__ k, bf16* __restrict__ v,
+                                                           bf16* __restrict__ kr, const float* __restrict__ cos_t,
+                                                           const float* __restrict__ sin_t, const float* __restrict__ scale_t,
+                                                           long long M, int C, int CinP, long long kv_tpb, long long kv_bstride,
+                                                           long long kv_off, int pos) {
+  __shared__ float red[3 * 2 * 16 * 64];           // waves 1..3 -> wave 0: [wave - 1][n-tile][accumulator register][lane]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 31, h = lane >> 5;
+  const long long tok = (long long)blockIdx.x * 32 + r;
+  const int hd = blockIdx.y, s = blockIdx.z, vi = s * (int)gridDim.y + hd;
+  const bool tvalid = tok < M;
+  const bf16* xrow = x + (size_t)(tvalid ? tok : 0) * C;
+  const bf16* wrow0 = w + ((size_t)vi * 64 + r) * CinP;
+  const bf16* wrow1 = wrow0 + (size_t)32 * CinP;
+  const bool rope = cos_t != nullptr && s != 2;
+  const size_t tb = (size_t)pos * 64;
+  // (wave 0 runs the epilogue: its rotary-table values are requested first, like qkv_eval_kernel's)
+  float tc0[16], ts0[16], tc1[16], ts1[16], tq0[16], tq1[16];
+  if (rope && wave == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int c = 8 * g + 4 * h;
+      const float4 a0 = *(const float4*)(cos_t + tb + c), a1 = *(const float4*)(cos_t + tb + c + 32);
+      const float4 b0 = *(const float4*)(sin_t + tb + c), b1 = *(const float4*)(sin_t + tb + c + 32);
+      const float4 q0 = *(const float4*)(scale_t + tb + c), q1 = *(const float4*)(scale_t + tb + c + 32);
+      tc0[4 * g] = a0.x; tc0[4 * g + 1] = a0.y; tc0[4 * g + 2] = a0.z; tc0[4 * g + 3] = a0.w;
+      tc1[4 * g] = a1.x; tc1[4 * g + 1] = a1.y; tc1[4 * g + 2] = a1.z; tc1[4 * g + 3] = a1.w;
+      ts0[4 * g] = b0.x; ts0[4 * g + 1] = b0.y; ts0[4 * g + 2] = b0.z; ts0[4 * g + 3] = b0.w;
+      ts1[4 * g] = b1.x; ts1[4 * g + 1] = b1.y; ts1[4 * g + 2] = b1.z; ts1[4 * g + 3] = b1.w;
+      tq0[4 * g] = q0.x; tq0[4 * g + 1] = q0.y; tq0[4 * g + 2] = q0.z; tq0[4 * g + 3] = q0.w;
+      tq1[4 * g] = q1.x; tq1[4 * g + 1] = q1.y; tq1[4 * g + 2] = q1.z; tq1[4 * g + 3] = q1.w;
+    }
+  }
+  f32x16 acc[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+  const int nround = C >> 6;
+#pragma unroll 1
+  for (int ch = wave; ch < nround; ch += 4) {
+    const int c0 = ch * 64 + h * 8;
+    u32x4 w0[4], w1[4], xv[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = c0 + ks * 16;
+      w0[ks] = *(const u32x4*)(wrow0 + c);
+      w1[ks] = *(const u32x4*)(wrow1 + c);
+      xv[ks] = tvalid ? *(const u32x4*)(xrow + c) : u32x4{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 xf = __builtin_bit_cast(bf16x8, xv[ks]);
+      acc[0] = mfma32(__builtin_bit_cast(bf16x8, w0[ks]), xf, acc[0]);
+      acc[1] = mfma32(__builtin_bit_cast(bf16x8, w1[ks]), xf, acc[1]);
+    }
+  }
+  if (wave != 0) {
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[(((wave - 1) * 2 + n) * 16 + i) * 64 + lane] = acc[n][i];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+      acc[n][i] = ((acc[n][i] + red[((0 * 2 + n) * 16 + i) * 64 + lane]) + red[((1 * 2 + n) * 16 + i) * 64 + lane]) +
+                  red[((2 * 2 + n) * 16 + i) * 64 + lane];
+  float f[2][16], ss = 0.f;
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { f[n][i] = bf2f(f2bf(acc[n][i])); ss += f[n][i] * f[n][i]; }
+  ss += __shfl_xor(ss, 32);
+  const float inv = ((s == 0) ? SCALE_LOG2 : 1.f) / (1e-4f + sqrtf(ss) * 0.125f);
+  if (!tvalid) return;
+  const long long dense = tok * C + hd * 64;
+  long long ring = dense;
+  if (kv_tpb > 0) {
+    const long long sq = (tok < kv_tpb) ? 0 : tok / kv_tpb;
+    ring = sq * kv_bstride + (kv_off + tok - sq * kv_tpb) * C + hd * 64;
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    bf16x4 plain[2], rot[2];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int i = 4 * g + kk;
+      const float u0 = bf2f(f2bf(f[0][i] * inv)), u1 = bf2f(f2bf(f[1][i] * inv));
+      plain[0][kk] = f2bf(u0); plain[1][kk] = f2bf(u1);
+      float v0 = u0, v1 = u1;
+      if (rope) {
+        v0 = u0 * tc0[i] - u1 * ts0[i];
+        v1 = u1 * tc1[i] + u0 * ts1[i];
+        const float s0 = tq0[i], s1 = tq1[i];
+        v0 = (s == 0) ? v0 * s0 : v0 / s0;
+        v1 = (s == 0) ? v1 * s1 : v1 / s1;
+      }
+      rot[0][kk] = f2bf(v0); rot[1][kk] = f2bf(v1);
+    }
+    const int co = 8 * g + 4 * h;
+    if (s == 0) {
+      *(bf16x4*)(q + dense + co) = rot[0]; *(bf16x4*)(q + dense + co + 32) = rot[1];
+    } else if (s == 1) {
+      *(bf16x4*)(k + ring + co) = plain[0]; *(bf16x4*)(k + ring + co + 32) = plain[1];
+      if (kr) { *(bf16x4*)(kr + ring + co) = rot[0]; *(bf16x4*)(kr + ring + co + 32) = rot[1]; }
+    } else {
+      *(bf16x4*)(v + ring + co) = plain[0]; *(bf16x4*)(v + ring + co + 32) = plain[1];
+    }
+  }
+}
+
 // adjoint of qkv_norm_rope_kernel: dq (w.r.t. the UNSCALED rotated q, as the attention backward returns it), dk, dv ->
 // dqkv.  R^T g = g cos - rot(g sin) and the scale vector is equal in both halves, so it commutes with the rotation.
 __global__ void qkv_norm_rope_bwd_kernel(const bf16* __restrict__ qkv, const bf16* __restrict__ dq,
@@ -1523,6 +1643,17 @@ extern "C" int oniris_qkv_eval(const void* x, const void* w, void* q, void* k, v
   ONIRIS_CHECK_ARG(kv_tokens_per_batch == 0 || (kv_tokens_per_batch > 0 && n_tokens % kv_tokens_per_batch == 0 &&
                                                 kv_batch_stride >= (kv_token_offset + kv_tokens_per_batch) * C),
                    "qkv_eval: bad KV ring geometry");
+  // a few tiles (one frame per sequence; at most one workgroup per CU): 32-token tiles, the four waves of a workgroup split the K
+  // (qkv_eval_few_kernel; ONIRIS_QKV_EVAL_FEW=0 in the environment: off, A/B)
+  static const int qkv_few = getenv("ONIRIS_QKV_EVAL_FEW") ? atoi(getenv("ONIRIS_QKV_EVAL_FEW")) : 1;
+  if (qkv_few && ((n_tokens + 31) / 32) * (3LL * C / 64) <= 256) {
+    const dim3 gf((unsigned)((n_tokens + 31) / 32), (unsigned)(C / 64), 3u);
+    ONIRIS_KLAUNCH(qkv_eval_few_kernel, gf, dim3(256), 0, stream, (const bf16*)x, (const bf16*)w, (bf16*)q, (bf16*)k, (bf16*)v, (bf16*)kr,
+                   cos_t, sin_t, scale_t, (long long)n_tokens, C, CinP, (long long)kv_tokens_per_batch, (long long)kv_batch_stride,
+                   (long long)kv_token_offset, pos);
+    ONIRIS_LAUNCH_CHECK();
+    return ONIRIS_OK;
+  }
   const dim3 grid((unsigned)((n_tokens + 127) / 128), (unsigned)(C / 64), 3u);        // (x: token tile, y: head, z: q | k | v)
 #define QKV_EVAL_LAUNCH(KC_)                                                                                              \
   ONIRIS_KLAUNCH(qkv_eval_kernel<KC_>, grid, dim3(256), 0, stream, (const bf16*)x, (const bf16*)w, (bf16*)q, (bf16*)k,  \

@@ -829,7 +829,7 @@ def test_conv_cat_act_matches_act_then_conv(N, H, C1, C2, cout):
     assert float(y.float().abs().mean()) > 0.1
 
 
-@pytest.mark.parametrize("N,m", [(1, 2), (3, 2), (8, 4), (33, 1)])
+@pytest.mark.parametrize("N,m", [(1, 2), (3, 2), (8, 4), (33, 1), (16, 2)])       # (the last three: qkv_eval_kernel<256 / 64 / 128>, the first two qkv_eval_few_kernel)
 def test_frame_attention_eval_query_halves(N, m, monkeypatch):
     """FrameAttention of a few 256-token frames without autograd (the 16x16 level of the cached sampler): two query halves per frame
     (frame_attn_fwd_kernel<1>, round 6) give the bits of the one-workgroup-per-frame launch, and the oracle's SDPA within 1e-2."""
